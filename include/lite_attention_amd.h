@@ -1,0 +1,140 @@
+/*
+ * lite_attention_amd.h — C-ABI of the MI355X (gfx950) QK-Skip attention forward.
+ *
+ * This is the drop-in boundary of the hot path. It replaces, one for one, what the
+ * reference reaches through `torch.ops.lite_attention.fwd`:
+ *
+ *   la_fwd                <- mha_fwd                hopper/_internal/cpp/flash_api.cpp:667-1249
+ *                            (+ set_params_fprop    flash_api.cpp:45-163,
+ *                               run_mha_fwd         flash_api.cpp:362-380,
+ *                               run_flash_fwd       hopper/_internal/cpp/flash_fwd_launch_template.h:52-363)
+ *   la_fwd_args           <- Flash_fwd_params + QKSkipMaskArgs
+ *                                                   hopper/_internal/cpp/flash.h:12-18,48-185
+ *   la_get_tile_sizes     <- tile_size_fwd_sm90     hopper/_internal/cpp/tile_size.h:10-62
+ *                            (and its Python twin LiteAttention.get_MN, hopper/lite_attention.py:87-111)
+ *   la_skip_list_stats    <- LiteAttention.calc_percentage   hopper/lite_attention.py:61-85
+ *                            (device-side, corrected statistic)
+ *   la_combine            <- mha_combine / flash_fwd_combine (LSE-weighted merge of partial outputs,
+ *                            hopper/_internal/cpp/flash_api.cpp fwd_combine; oracle
+ *                            hopper/tests/test_flash_attn.py:1178-1187)
+ *
+ * Rules of the boundary:
+ *   - plain C: pointers, sizes, scalars. No torch types, no C++ types, no exceptions.
+ *   - every pointer is a DEVICE pointer unless the name says `host`.
+ *   - the library owns nothing, allocates nothing on the device and keeps no global mutable
+ *     state; outputs and skip lists are caller-owned. `write_list` is mutated in place.
+ *   - launches are asynchronous on the given hipStream_t (passed as void*); no host sync.
+ *   - return value: LA_OK (0) or a negative la_status; on error nothing has been launched.
+ */
+#ifndef LITE_ATTENTION_AMD_H
+#define LITE_ATTENTION_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LA_ABI_VERSION 1
+
+typedef enum la_status {
+    LA_OK = 0,
+    LA_ERR_NULL_ARG = -1,        /* a required pointer is NULL                                   */
+    LA_ERR_STRUCT_SIZE = -2,     /* args->struct_size != sizeof(la_fwd_args): ABI mismatch        */
+    LA_ERR_DTYPE = -3,           /* dtype not built (flash_api.cpp:715 "only supports fp16, bf16, fp8") */
+    LA_ERR_HEAD_DIM = -4,        /* head_dim not instantiated / not a multiple of 8 (flash_api.cpp:854) */
+    LA_ERR_SHAPE = -5,           /* non-positive sizes, num_heads % num_heads_k != 0 (flash_api.cpp:777) */
+    LA_ERR_STRIDE = -6,          /* last dim must be contiguous (flash_api.cpp:726-728) / 16-byte rows  */
+    LA_ERR_TILE_MISMATCH = -7,   /* block_m/block_n echo != la_get_tile_sizes (list indexing would be wrong) */
+    LA_ERR_LISTS = -8,           /* read list without write list, or vice versa                   */
+    LA_ERR_UNSUPPORTED = -9,     /* feature outside the hot path (causal, GQA, dv != d, ...)      */
+    LA_ERR_LAUNCH = -10,         /* hipLaunchKernel failed; see la_last_hip_error()               */
+    LA_ERR_SEQLEN = -11          /* sequence too long for the per-workgroup list staging in LDS   */
+} la_status;
+
+typedef enum la_dtype {
+    LA_DTYPE_BF16 = 0,
+    LA_DTYPE_FP16 = 1,           /* reserved: not built in this round                             */
+    LA_DTYPE_FP8_E4M3 = 2        /* OCP e4m3fn (gfx950), bf16 output                              */
+} la_dtype;
+
+/*
+ * Forward arguments. Strides are in ELEMENTS (as Flash_fwd_params, flash_api.cpp:84-103).
+ * Tensors: q (B,Sq,H,D)  k (B,Sk,Hk,D)  v (B,Sk,Hk,Dv)  o (B,Sq,H,Dv)  lse (B,H,Sq) fp32 contiguous.
+ *
+ * Skip lists (reader/writer semantics of
+ * hopper/_internal/cpp/mainloop_fwd_sm90_tma_gmma_ws.hpp:47-192):
+ *   int32 [B_alloc, H, Qt, Kt+1] contiguous, Qt = ceil(Sq/block_m), Kt = ceil(Sk/block_n);
+ *   row = [L, start_0, end_0, start_1, end_1, ...]; ranges descending, both ends inclusive.
+ *   read_list == NULL  -> dense mode (is_skipable = false, flash_api.cpp:931-936).
+ *   must_do_list: same row format, token->tile converted by the caller
+ *                 (hopper/lite_attention.py:228-235); ranges are (start inclusive, end EXCLUSIVE).
+ *                 must_do_is_1d != 0 -> ONE row of Kt+1 ints shared by every (b,h,q-tile)
+ *                 (the reference materialises the full 4-D repeat per call, lite_attention.py:239-241).
+ */
+typedef struct la_fwd_args {
+    uint32_t struct_size;        /* = sizeof(la_fwd_args)                                         */
+    int32_t  dtype;              /* la_dtype of q,k,v                                             */
+
+    const void* q;
+    const void* k;
+    const void* v;
+    void*       o;               /* bf16 (also for fp8 inputs, flash_api.cpp:859)                 */
+    float*      lse;             /* may be NULL: LSE not stored                                   */
+
+    int64_t q_batch_stride, q_row_stride, q_head_stride;
+    int64_t k_batch_stride, k_row_stride, k_head_stride;
+    int64_t v_batch_stride, v_row_stride, v_head_stride;
+    int64_t o_batch_stride, o_row_stride, o_head_stride;
+
+    int32_t batch, seqlen_q, seqlen_k;
+    int32_t num_heads, num_heads_k;
+    int32_t head_dim, head_dim_v;
+
+    float   softmax_scale;       /* scores = q.k * softmax_scale (flash_api.cpp:125)              */
+
+    /* fp8 only: per-(batch, kv-head) descales, fp32; NULL = 1.0 (flash_api.cpp:1003-1022) */
+    const float* q_descale; const float* k_descale; const float* v_descale;
+    int64_t q_descale_batch_stride, q_descale_head_stride;
+    int64_t k_descale_batch_stride, k_descale_head_stride;
+    int64_t v_descale_batch_stride, v_descale_head_stride;
+
+    const int32_t* read_list;    /* QKSkipMaskArgs::attn_read_list   flash.h:13                   */
+    int32_t*       write_list;   /* QKSkipMaskArgs::attn_write_list  flash.h:15                   */
+    const int32_t* must_do_list; /* QKSkipMaskArgs::attn_must_do_list flash.h:14; may be NULL     */
+    int32_t        must_do_is_1d;
+    float          thr;          /* QKSkipMaskArgs::thr flash.h:17 (log2 domain)                  */
+
+    int32_t block_m, block_n;    /* echo of la_get_tile_sizes(); checked                          */
+} la_fwd_args;
+
+/* Tile sizes (kBlockM, kBlockN) of the kernel that la_fwd will run for (head_dim, element size).
+ * Skip-list geometry depends on them, so host code must take them from here. */
+int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n);
+
+/* The forward pass. `stream` is a hipStream_t. */
+int la_fwd(const la_fwd_args* args, void* stream);
+
+/* Counts listed (= to be computed) tiles of a skip list on the device:
+ *   out_counts[0] = sum over rows of sum over ranges (start - end + 1), rows = n_batch*H*Qt
+ *   out_counts[1] = number of rows
+ * `list` is [>=n_batch, H, Qt, Kt+1]; out_counts is a device int64[2], zeroed by the call. */
+int la_skip_list_stats(const int32_t* list, int32_t n_batch, int32_t num_heads, int32_t q_tiles,
+                       int32_t k_tiles, int64_t* out_counts, void* stream);
+
+/* LSE-weighted merge of `num_splits` partial attention results (sequence-parallel K/V splits):
+ *   o_partial   fp32 or bf16 [num_splits, B, Sq, H, Dv] contiguous (partial_is_bf16 selects)
+ *   lse_partial fp32 [num_splits, B, H, Sq] contiguous
+ *   o bf16 [B,Sq,H,Dv] contiguous, lse fp32 [B,H,Sq] (may be NULL). */
+int la_combine(const void* o_partial, int32_t partial_is_bf16, const float* lse_partial,
+               void* o, float* lse, int32_t num_splits, int32_t batch, int32_t seqlen_q,
+               int32_t num_heads, int32_t head_dim_v, void* stream);
+
+const char* la_status_string(int status);
+int         la_abi_version(void);
+int         la_last_hip_error(void);   /* hipError_t of the last failed launch on this thread */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LITE_ATTENTION_AMD_H */

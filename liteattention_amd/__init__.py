@@ -1,0 +1,17 @@
+"""liteattention_amd — MI355X-native QK-Skip attention (drop-in for ``lite_attention``).
+
+Public surface = the reference's (/root/reference/hopper/__init__.py:4-6) plus the functional op.
+Importing this package loads the HIP extension; it raises if the extension is missing.
+"""
+__version__ = "0.1.0"
+
+from . import _cabi
+
+_cabi.load()   # fail loudly, at import, when libliteattention_amd.so is absent — no CPU fallback
+
+from .flash_attn_interface import (flash_attn_combine, flash_attn_func, get_tile_sizes,  # noqa: E402
+                                   skip_list_stats)
+from .lite_attention import LiteAttention, SeqParallelLiteAttention  # noqa: E402
+
+__all__ = ["LiteAttention", "SeqParallelLiteAttention", "flash_attn_func", "flash_attn_combine",
+           "get_tile_sizes", "skip_list_stats", "__version__"]

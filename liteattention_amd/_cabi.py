@@ -1,0 +1,107 @@
+"""ctypes binding of the C-ABI in include/lite_attention_amd.h.
+
+This is the only place the package touches native code. It NEVER falls back to a CPU or eager
+implementation: if the shared library is missing or a symbol is absent, import-time loading raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Tuple
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libliteattention_amd.so")
+
+LA_ABI_VERSION = 1
+LA_DTYPE_BF16, LA_DTYPE_FP16, LA_DTYPE_FP8_E4M3 = 0, 1, 2
+
+LA_OK = 0
+LA_ERR_NULL_ARG, LA_ERR_STRUCT_SIZE, LA_ERR_DTYPE, LA_ERR_HEAD_DIM, LA_ERR_SHAPE = -1, -2, -3, -4, -5
+LA_ERR_STRIDE, LA_ERR_TILE_MISMATCH, LA_ERR_LISTS, LA_ERR_UNSUPPORTED, LA_ERR_LAUNCH, LA_ERR_SEQLEN = (
+    -6, -7, -8, -9, -10, -11)
+
+EXPORTED_SYMBOLS = (
+    "la_abi_version", "la_get_tile_sizes", "la_fwd", "la_skip_list_stats", "la_combine",
+    "la_status_string", "la_last_hip_error",
+)
+
+
+class LaFwdArgs(ctypes.Structure):
+    """Mirror of ``la_fwd_args`` (field order and types must match the header)."""
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("dtype", ctypes.c_int32),
+        ("q", ctypes.c_void_p), ("k", ctypes.c_void_p), ("v", ctypes.c_void_p),
+        ("o", ctypes.c_void_p), ("lse", ctypes.c_void_p),
+        ("q_batch_stride", ctypes.c_int64), ("q_row_stride", ctypes.c_int64), ("q_head_stride", ctypes.c_int64),
+        ("k_batch_stride", ctypes.c_int64), ("k_row_stride", ctypes.c_int64), ("k_head_stride", ctypes.c_int64),
+        ("v_batch_stride", ctypes.c_int64), ("v_row_stride", ctypes.c_int64), ("v_head_stride", ctypes.c_int64),
+        ("o_batch_stride", ctypes.c_int64), ("o_row_stride", ctypes.c_int64), ("o_head_stride", ctypes.c_int64),
+        ("batch", ctypes.c_int32), ("seqlen_q", ctypes.c_int32), ("seqlen_k", ctypes.c_int32),
+        ("num_heads", ctypes.c_int32), ("num_heads_k", ctypes.c_int32),
+        ("head_dim", ctypes.c_int32), ("head_dim_v", ctypes.c_int32),
+        ("softmax_scale", ctypes.c_float),
+        ("q_descale", ctypes.c_void_p), ("k_descale", ctypes.c_void_p), ("v_descale", ctypes.c_void_p),
+        ("q_descale_batch_stride", ctypes.c_int64), ("q_descale_head_stride", ctypes.c_int64),
+        ("k_descale_batch_stride", ctypes.c_int64), ("k_descale_head_stride", ctypes.c_int64),
+        ("v_descale_batch_stride", ctypes.c_int64), ("v_descale_head_stride", ctypes.c_int64),
+        ("read_list", ctypes.c_void_p), ("write_list", ctypes.c_void_p), ("must_do_list", ctypes.c_void_p),
+        ("must_do_is_1d", ctypes.c_int32), ("thr", ctypes.c_float),
+        ("block_m", ctypes.c_int32), ("block_n", ctypes.c_int32),
+    ]
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the HIP extension. Raises NativeLibraryError (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m liteattention_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU/eager fallback for this op.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name in EXPORTED_SYMBOLS:
+        if not hasattr(lib, name):
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}")
+    lib.la_abi_version.restype = ctypes.c_int
+    lib.la_get_tile_sizes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    lib.la_get_tile_sizes.restype = ctypes.c_int
+    lib.la_fwd.argtypes = [ctypes.POINTER(LaFwdArgs), ctypes.c_void_p]
+    lib.la_fwd.restype = ctypes.c_int
+    lib.la_skip_list_stats.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                       ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    lib.la_skip_list_stats.restype = ctypes.c_int
+    lib.la_combine.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                               ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                               ctypes.c_void_p]
+    lib.la_combine.restype = ctypes.c_int
+    lib.la_status_string.argtypes = [ctypes.c_int]
+    lib.la_status_string.restype = ctypes.c_char_p
+    lib.la_last_hip_error.restype = ctypes.c_int
+    if lib.la_abi_version() != LA_ABI_VERSION:
+        raise NativeLibraryError(f"ABI version mismatch: library {lib.la_abi_version()} vs binding {LA_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def status_string(code: int) -> str:
+    return load().la_status_string(code).decode()
+
+
+def get_tile_sizes(head_dim: int, element_size: int) -> Tuple[int, int]:
+    """(kBlockM, kBlockN) of the kernel la_fwd runs for this head_dim / element size."""
+    m, n = ctypes.c_int(0), ctypes.c_int(0)
+    rc = load().la_get_tile_sizes(int(head_dim), int(element_size), ctypes.byref(m), ctypes.byref(n))
+    if rc != LA_OK:
+        raise RuntimeError(f"la_get_tile_sizes(head_dim={head_dim}, element_size={element_size}): {status_string(rc)}")
+    return m.value, n.value

@@ -1,0 +1,55 @@
+"""In-tree build of the HIP extension: ``hipcc --offload-arch=gfx950 -shared`` -> libliteattention_amd.so.
+
+Replaces the reference's nvcc/CUTLASS build (/root/reference/hopper/setup.py:381-674): no network, no
+downloaded toolchain, no feature-flag matrix — the build is {bf16} x {head_dim 128} for gfx950 only.
+The .so is written next to this file so that it travels with the source tree.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
+LIB_NAME = "libliteattention_amd.so"
+LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
+SOURCES = ["la_fwd_kernel.hip", "la_aux_kernels.hip", "la_api.hip"]
+HEADERS = ["la_kernel_params.h", "la_tiles.h"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(INCLUDE, "lite_attention_amd.h")]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into one shared library. Returns its path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-I", INCLUDE, "-I", CSRC]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    tmp = LIB_PATH + ".tmp"
+    cmd += ["-o", tmp]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

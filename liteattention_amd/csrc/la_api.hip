@@ -1,0 +1,140 @@
+// la_api.hip — the C-ABI (include/lite_attention_amd.h): validation, parameter fill, dispatch.
+//
+// Replaces mha_fwd + set_params_fprop + run_mha_fwd of the reference
+// (/root/reference/hopper/_internal/cpp/flash_api.cpp:45-163, 362-380, 667-1249). The checks mirror
+// the reference's TORCH_CHECKs (cited per check) but return codes instead of throwing; the Python
+// layer turns codes into the reference's exception types.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lite_attention_amd.h"
+#include "la_kernel_params.h"
+#include "la_tiles.h"
+
+namespace {
+thread_local int g_last_hip_error = 0;
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+}  // namespace
+
+extern "C" {
+
+int la_abi_version(void) { return LA_ABI_VERSION; }
+
+int la_last_hip_error(void) { return g_last_hip_error; }
+
+const char* la_status_string(int status) {
+    switch (status) {
+        case LA_OK: return "ok";
+        case LA_ERR_NULL_ARG: return "required pointer is NULL";
+        case LA_ERR_STRUCT_SIZE: return "la_fwd_args.struct_size mismatch (ABI version skew)";
+        case LA_ERR_DTYPE: return "FlashAttention only supports fp16, bf16, and fp8_e4m3 type; this build instantiates bf16";
+        case LA_ERR_HEAD_DIM: return "head_size not instantiated in this build (bf16: 128)";
+        case LA_ERR_SHAPE: return "invalid shape (sizes must be positive; number of heads in key/value must divide number of heads in query)";
+        case LA_ERR_STRIDE: return "Input tensor must have contiguous last dimension and 16-byte aligned rows";
+        case LA_ERR_TILE_MISMATCH: return "block_m/block_n do not match la_get_tile_sizes(): skip lists would be mis-indexed";
+        case LA_ERR_LISTS: return "attn_read_list and attn_write_list must be given together";
+        case LA_ERR_UNSUPPORTED: return "feature outside the QK-Skip hot path (GQA/MQA, head_dim_v != head_dim)";
+        case LA_ERR_LAUNCH: return "HIP kernel launch failed (see la_last_hip_error)";
+        case LA_ERR_SEQLEN: return "seqlen_k too long: expanded skip list does not fit in LDS";
+        default: return "unknown la_status";
+    }
+}
+
+int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n) {
+    const la::TileShape t = la::tile_shape(head_dim, element_size);
+    if (t.block_m == 0) return element_size == 2 ? LA_ERR_HEAD_DIM : LA_ERR_DTYPE;
+    if (block_m) *block_m = t.block_m;
+    if (block_n) *block_n = t.block_n;
+    return LA_OK;
+}
+
+int la_fwd(const la_fwd_args* a, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (a == nullptr) return LA_ERR_NULL_ARG;
+    if (a->struct_size != sizeof(la_fwd_args)) return LA_ERR_STRUCT_SIZE;
+    if (a->dtype != LA_DTYPE_BF16) return LA_ERR_DTYPE;                                  // flash_api.cpp:715
+    if (!a->q || !a->k || !a->v || !a->o) return LA_ERR_NULL_ARG;
+    if (a->batch <= 0 || a->seqlen_q <= 0 || a->seqlen_k < 0 || a->num_heads <= 0 || a->num_heads_k <= 0 ||
+        a->head_dim <= 0 || a->head_dim_v <= 0)
+        return LA_ERR_SHAPE;                                                             // flash_api.cpp:776-778
+    if (a->num_heads % a->num_heads_k != 0) return LA_ERR_SHAPE;                          // flash_api.cpp:777
+    if (a->head_dim % 8 != 0) return LA_ERR_HEAD_DIM;                                     // flash_api.cpp:854-856
+    if (a->num_heads_k != a->num_heads || a->head_dim_v != a->head_dim) return LA_ERR_UNSUPPORTED;
+    int bm = 0, bn = 0;
+    const int trc = la_get_tile_sizes(a->head_dim, 2, &bm, &bn);
+    if (trc != LA_OK) return trc;
+    if (a->block_m != bm || a->block_n != bn) return LA_ERR_TILE_MISMATCH;
+    if ((a->read_list == nullptr) != (a->write_list == nullptr)) return LA_ERR_LISTS;
+    // 16-byte vector access on every row: row/head/batch strides multiples of 8 elements, base aligned
+    const int64_t strides[] = {a->q_batch_stride, a->q_row_stride, a->q_head_stride, a->k_batch_stride,
+                               a->k_row_stride,   a->k_head_stride, a->v_batch_stride, a->v_row_stride,
+                               a->v_head_stride,  a->o_batch_stride, a->o_row_stride,  a->o_head_stride};
+    for (int64_t s : strides)
+        if (s % 8 != 0 || s < 0) return LA_ERR_STRIDE;                                   // flash_api.cpp:726-728 (+alignment)
+    if (!aligned16(a->q) || !aligned16(a->k) || !aligned16(a->v) || !aligned16(a->o)) return LA_ERR_STRIDE;
+
+    if (a->seqlen_k == 0) {
+        // flash_api.cpp:1241-1245: empty K -> out = 0, lse = +inf. Done with memset-class kernels by the
+        // caller-visible contract; the Python layer handles it (no kernel here).
+        return LA_ERR_SHAPE;
+    }
+
+    la::FwdParams p{};
+    p.q = static_cast<const uint16_t*>(a->q);
+    p.k = static_cast<const uint16_t*>(a->k);
+    p.v = static_cast<const uint16_t*>(a->v);
+    p.o = static_cast<uint16_t*>(a->o);
+    p.lse = a->lse;
+    p.q_batch_stride = a->q_batch_stride; p.q_row_stride = a->q_row_stride; p.q_head_stride = a->q_head_stride;
+    p.k_batch_stride = a->k_batch_stride; p.k_row_stride = a->k_row_stride; p.k_head_stride = a->k_head_stride;
+    p.v_batch_stride = a->v_batch_stride; p.v_row_stride = a->v_row_stride; p.v_head_stride = a->v_head_stride;
+    p.o_batch_stride = a->o_batch_stride; p.o_row_stride = a->o_row_stride; p.o_head_stride = a->o_head_stride;
+    p.batch = a->batch; p.seqlen_q = a->seqlen_q; p.seqlen_k = a->seqlen_k; p.num_heads = a->num_heads;
+    p.q_tiles = (a->seqlen_q + bm - 1) / bm;
+    p.k_tiles = (a->seqlen_k + bn - 1) / bn;
+    p.scale_log2 = static_cast<float>(static_cast<double>(a->softmax_scale) * 1.4426950408889634);  // flash_api.cpp:125-126
+    p.thr = a->thr;                                                                      // flash_api.cpp:930
+    p.read_list = a->read_list;
+    p.write_list = a->write_list;
+    p.must_do_list = a->must_do_list;
+    p.must_do_is_1d = a->must_do_is_1d;
+
+    if (la::fwd_lds_bytes(p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
+    if (static_cast<int64_t>(p.batch) * p.num_heads * p.q_tiles > 0x7fffffffLL) return LA_ERR_SHAPE;
+
+    const hipError_t err = la::launch_fwd_bf16_d128(p, a->read_list != nullptr, stream);   // is_skipable, flash_api.cpp:931
+    if (err != hipSuccess) {
+        g_last_hip_error = static_cast<int>(err);
+        return LA_ERR_LAUNCH;
+    }
+    return LA_OK;
+}
+
+int la_skip_list_stats(const int32_t* list, int32_t n_batch, int32_t num_heads, int32_t q_tiles, int32_t k_tiles,
+                       int64_t* out_counts, void* stream_) {
+    if (!list || !out_counts) return LA_ERR_NULL_ARG;
+    if (n_batch <= 0 || num_heads <= 0 || q_tiles <= 0 || k_tiles <= 0) return LA_ERR_SHAPE;
+    const int64_t rows = static_cast<int64_t>(n_batch) * num_heads * q_tiles;
+    if (rows > 0x7fffffffLL) return LA_ERR_SHAPE;
+    const hipError_t err = la::launch_skip_list_stats(list, static_cast<int>(rows), k_tiles, out_counts,
+                                                      static_cast<hipStream_t>(stream_));
+    if (err != hipSuccess) { g_last_hip_error = static_cast<int>(err); return LA_ERR_LAUNCH; }
+    return LA_OK;
+}
+
+int la_combine(const void* o_partial, int32_t partial_is_bf16, const float* lse_partial, void* o, float* lse,
+               int32_t num_splits, int32_t batch, int32_t seqlen_q, int32_t num_heads, int32_t head_dim_v,
+               void* stream_) {
+    if (!o_partial || !lse_partial || !o) return LA_ERR_NULL_ARG;
+    if (num_splits <= 0 || batch <= 0 || seqlen_q <= 0 || num_heads <= 0 || head_dim_v <= 0) return LA_ERR_SHAPE;
+    if (head_dim_v % 8 != 0) return LA_ERR_HEAD_DIM;
+    if (!aligned16(o_partial) || !aligned16(o)) return LA_ERR_STRIDE;
+    const hipError_t err = la::launch_combine(o_partial, partial_is_bf16 != 0, lse_partial, static_cast<uint16_t*>(o), lse,
+                                              num_splits, batch, seqlen_q, num_heads, head_dim_v,
+                                              static_cast<hipStream_t>(stream_));
+    if (err != hipSuccess) { g_last_hip_error = static_cast<int>(err); return LA_ERR_LAUNCH; }
+    return LA_OK;
+}
+
+}  // extern "C"

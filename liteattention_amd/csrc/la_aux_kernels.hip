@@ -1,0 +1,117 @@
+// la_aux_kernels.hip — small HBM-bound helpers around the forward kernel.
+//
+//  * skip_list_stats: number of listed tiles of a skip list, computed on the device. Replaces
+//    LiteAttention.calc_percentage (/root/reference/hopper/lite_attention.py:61-85), whose
+//    arithmetic is wrong; same input, corrected statistic.
+//  * combine: LSE-weighted merge of partial outputs of K/V splits — the device counterpart of
+//    attention_combine_ref (/root/reference/hopper/tests/test_flash_attn.py:1178-1187) and of the
+//    reference's (compiled-out) FlashAttnFwdCombine kernel
+//    (/root/reference/hopper/_internal/cpp/flash_fwd_combine_kernel.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "la_kernel_params.h"
+
+namespace la {
+
+__global__ void __launch_bounds__(256) skip_list_stats_kernel(const int32_t* __restrict__ list, int rows, int k_tiles,
+                                                               unsigned long long* out) {
+    // one wave per row; lanes stride over the ranges of the row
+    const int lane = threadIdx.x & 63;
+    const int wave_in_grid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    unsigned long long acc = 0;
+    for (int r = wave_in_grid; r < rows; r += n_waves) {
+        const int32_t* row = list + static_cast<int64_t>(r) * (k_tiles + 1);
+        int len = row[0];
+        if (len < 2) len = 2;   // the reader always walks the first range (mainloop...:93-101)
+        if (len > k_tiles) len = k_tiles;
+        for (int i = 1 + 2 * lane; i + 1 <= len; i += 128) {
+            const int d = row[i] - row[i + 1] + 1;
+            acc += d > 0 ? d : 0;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0 && acc) atomicAdd(out, acc);
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[1] = static_cast<unsigned long long>(rows);
+}
+
+hipError_t launch_skip_list_stats(const int32_t* list, int rows, int k_tiles, int64_t* out, hipStream_t stream) {
+    hipError_t err = hipMemsetAsync(out, 0, 2 * sizeof(int64_t), stream);
+    if (err != hipSuccess) return err;
+    int blocks = (rows + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(skip_list_stats_kernel, dim3(blocks), dim3(256), 0, stream, list, rows, k_tiles,
+                       reinterpret_cast<unsigned long long*>(out));
+    return hipGetLastError();
+}
+
+// One thread = 8 consecutive d of one (b, s, h) row. Memory-bound; 16-byte accesses.
+template <bool PARTIAL_BF16>
+__global__ void __launch_bounds__(256) combine_kernel(const void* __restrict__ o_partial,
+                                                       const float* __restrict__ lse_partial,
+                                                       uint16_t* __restrict__ o, float* __restrict__ lse_out,
+                                                       int num_splits, int batch, int seqlen_q, int num_heads,
+                                                       int dv) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    const int chunks = dv / 8;
+    const int64_t total = static_cast<int64_t>(batch) * seqlen_q * num_heads * chunks;
+    const int64_t split_elems = static_cast<int64_t>(batch) * seqlen_q * num_heads * dv;
+    const int64_t split_rows = static_cast<int64_t>(batch) * num_heads * seqlen_q;
+    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+         idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int ch = static_cast<int>(idx % chunks);
+        const int64_t row = idx / chunks;   // (b*S + s)*H + h
+        const int hh = static_cast<int>(row % num_heads);
+        const int64_t bs = row / num_heads;
+        const int s = static_cast<int>(bs % seqlen_q);
+        const int b = static_cast<int>(bs / seqlen_q);
+        const int64_t lse_idx = (static_cast<int64_t>(b) * num_heads + hh) * seqlen_q + s;
+        float m = -INFINITY;
+        for (int sp = 0; sp < num_splits; ++sp) m = fmaxf(m, lse_partial[sp * split_rows + lse_idx]);
+        float denom = 0.f;
+        f32x8 acc = {0, 0, 0, 0, 0, 0, 0, 0};
+        const float m_safe = (m == -INFINITY) ? 0.f : m;
+        for (int sp = 0; sp < num_splits; ++sp) {
+            const float l = lse_partial[sp * split_rows + lse_idx];
+            const float w = (l == -INFINITY) ? 0.f : __expf(l - m_safe);
+            denom += w;
+            const int64_t off = sp * split_elems + row * dv + ch * 8;
+            f32x8 x;
+            if (PARTIAL_BF16) {
+                const bf16x8 t = *reinterpret_cast<const bf16x8*>(static_cast<const uint16_t*>(o_partial) + off);
+                x = __builtin_convertvector(t, f32x8);
+            } else {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(static_cast<const float*>(o_partial) + off);
+                const f32x4 c = *reinterpret_cast<const f32x4*>(static_cast<const float*>(o_partial) + off + 4);
+                x = __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            acc += x * w;
+        }
+        const float inv = denom > 0.f ? 1.f / denom : 0.f;
+        acc *= inv;
+        *reinterpret_cast<bf16x8*>(o + row * dv + ch * 8) = __builtin_convertvector(acc, bf16x8);
+        if (lse_out != nullptr && ch == 0) lse_out[lse_idx] = denom > 0.f ? m_safe + __logf(denom) : -INFINITY;
+    }
+}
+
+hipError_t launch_combine(const void* o_partial, bool partial_is_bf16, const float* lse_partial, uint16_t* o,
+                          float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v,
+                          hipStream_t stream) {
+    const int64_t total = static_cast<int64_t>(batch) * seqlen_q * num_heads * (head_dim_v / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    if (partial_is_bf16)
+        hipLaunchKernelGGL(combine_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, o_partial,
+                           lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v);
+    else
+        hipLaunchKernelGGL(combine_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, o_partial,
+                           lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v);
+    return hipGetLastError();
+}
+
+}  // namespace la

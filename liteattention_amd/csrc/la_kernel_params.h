@@ -1,0 +1,37 @@
+// la_kernel_params.h — device-side parameter block (the slimmed-down Flash_fwd_params,
+// /root/reference/hopper/_internal/cpp/flash.h:48-185) filled by la_api.hip from la_fwd_args.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace la {
+
+struct FwdParams {
+    const uint16_t* q;
+    const uint16_t* k;
+    const uint16_t* v;
+    uint16_t* o;
+    float* lse;
+    int64_t q_batch_stride, q_row_stride, q_head_stride;   // elements
+    int64_t k_batch_stride, k_row_stride, k_head_stride;
+    int64_t v_batch_stride, v_row_stride, v_head_stride;
+    int64_t o_batch_stride, o_row_stride, o_head_stride;
+    int batch, seqlen_q, seqlen_k, num_heads;
+    int q_tiles, k_tiles;
+    int seq_cap;            // int32 slots reserved in LDS for the expanded tile sequence
+    float scale_log2;       // softmax_scale * log2(e)   (flash_api.cpp:125-126)
+    float thr;
+    const int* read_list;
+    int* write_list;
+    const int* must_do_list;
+    int must_do_is_1d;
+};
+
+size_t fwd_lds_bytes(int k_tiles, int* seq_cap_out);
+hipError_t launch_fwd_bf16_d128(const FwdParams& p, bool skipable, hipStream_t stream);
+hipError_t launch_skip_list_stats(const int32_t* list, int rows, int k_tiles, int64_t* out, hipStream_t stream);
+hipError_t launch_combine(const void* o_partial, bool partial_is_bf16, const float* lse_partial, uint16_t* o,
+                          float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v,
+                          hipStream_t stream);
+
+}  // namespace la

@@ -1,0 +1,31 @@
+// la_tiles.h — the ONE table of (kBlockM, kBlockN) used by the HIP kernels, the C-ABI
+// (la_get_tile_sizes) and, through it, the Python host code (LiteAttention.get_MN).
+//
+// Replaces tile_size_fwd_sm90 (/root/reference/hopper/_internal/cpp/tile_size.h:10-62) and its
+// hand-copied Python twin (/root/reference/hopper/lite_attention.py:87-111). The reference keeps two
+// copies that must agree; here Python asks the library.
+//
+// CDNA4 derivation: one wave owns 32 query rows (one 32x32 MFMA column block), a
+// workgroup is 4 waves -> kBlockM = 128 (same q granularity as the reference at d=128). kBlockN = 64
+// keys: K 16 KiB + V 16 KiB per stage, double-buffered = 64 KiB of LDS, so two workgroups share a
+// CU's 160 KiB and each SIMD holds two waves from different workgroups (softmax VALU of one
+// overlaps MFMA of the other).
+#pragma once
+
+namespace la {
+
+struct TileShape {
+    int block_m;
+    int block_n;
+};
+
+// element_size: 2 = bf16/fp16, 1 = fp8. Returns {0,0} when no kernel is instantiated.
+constexpr TileShape tile_shape(int head_dim, int element_size) {
+    if (element_size == 2) {
+        if (head_dim == 128) return {128, 64};
+        if (head_dim == 64) return {128, 64};
+    }
+    return {0, 0};
+}
+
+}  // namespace la

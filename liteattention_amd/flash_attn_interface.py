@@ -1,0 +1,348 @@
+"""Functional operator surface of the QK-Skip attention forward on MI355X.
+
+Mirrors /root/reference/hopper/_internal/flash_attn_interface.py for the LiteAttention path:
+
+* ``flash_attn_func``          same signature as the reference (:547-568), forward only
+* ``FlashAttnFunc``            autograd.Function shell (:274-342); backward raises, as the reference's
+                               default build compiles the backward out (hopper/setup.py:47)
+* ``_flash_attn_forward``      same positional contract (:20-112): calls ``torch.ops.lite_attention.fwd``
+* ``torch.ops.lite_attention.fwd``  registered here with the reference's schema
+                               (hopper/_internal/cpp/flash_api.cpp:1723-1762) under the CUDA (= HIP on
+                               ROCm) dispatch key; its body is ``mha_fwd`` below, the host half of
+                               flash_api.cpp:667-1249, which validates like the reference, allocates
+                               ``out``/``softmax_lse`` and calls the C-ABI ``la_fwd``.
+
+There is no CPU implementation and no eager fallback: CPU tensors fail in the dispatcher, a
+missing HIP library fails at import of the native binding.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _cabi
+
+__all__ = ["flash_attn_func", "FlashAttnFunc", "flash_attn_combine", "get_tile_sizes", "skip_list_stats"]
+
+_FWD_SCHEMA = (
+    "fwd("
+    "Tensor q,"
+    "Tensor k,"
+    "Tensor v,"
+    "Tensor(k_new!)? k_new = None,"
+    "Tensor(v_new!)? v_new = None,"
+    "Tensor? q_v = None,"
+    "Tensor(out!)? out = None,"
+    "Tensor? cu_seqlens_q = None,"
+    "Tensor? cu_seqlens_k = None,"
+    "Tensor? cu_seqlens_k_new = None,"
+    "Tensor? seqused_q = None,"
+    "Tensor? seqused_k = None,"
+    "int? max_seqlen_q = None,"
+    "int? max_seqlen_k = None,"
+    "Tensor? page_table = None,"
+    "Tensor? kv_batch_idx = None,"
+    "Tensor? leftpad_k = None,"
+    "Tensor? rotary_cos = None,"
+    "Tensor? rotary_sin = None,"
+    "Tensor? seqlens_rotary = None,"
+    "Tensor? q_descale = None,"
+    "Tensor? k_descale = None,"
+    "Tensor? v_descale = None,"
+    "float? softmax_scale = None,"
+    "bool is_causal = False,"
+    "int window_size_left = -1,"
+    "int window_size_right = -1,"
+    "int attention_chunk = 0,"
+    "float softcap = 0.0,"
+    "bool is_rotary_interleaved = False,"
+    "Tensor? scheduler_metadata = None,"
+    "int num_splits = 0,"
+    "bool? pack_gqa = None,"
+    "int sm_margin = 0,"
+    "Tensor? attn_read_list = None,"
+    "Tensor? attn_must_do_list = None,"
+    "Tensor? attn_write_list = None,"
+    "float thr = -3.0) -> (Tensor(out!), Tensor, Tensor, Tensor)"
+)
+
+
+def get_tile_sizes(head_dim: int, element_size: int) -> Tuple[int, int]:
+    """(kBlockM, kBlockN) of the gfx950 kernel — the single source for skip-list geometry."""
+    return _cabi.get_tile_sizes(head_dim, element_size)
+
+
+def _check_list(t: Optional[torch.Tensor], name: str, q: torch.Tensor) -> Optional[int]:
+    """flash_api.cpp:919-963: int32, 4-D, contiguous (same messages)."""
+    if t is None:
+        return None
+    if t.dtype != torch.int32:
+        raise RuntimeError(f"{name} must be int32 tensor")
+    if t.dim() != 4:
+        raise RuntimeError(f"{name} must be 4D tensor with shape [batch, heads, q_blocks, k_blocks]")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if t.device != q.device:
+        raise RuntimeError(f"{name} must be on the same device as q")
+    return t.data_ptr()
+
+
+def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=None, cu_seqlens_k=None,
+            cu_seqlens_k_new=None, seqused_q=None, seqused_k=None, max_seqlen_q=None, max_seqlen_k=None,
+            page_table=None, kv_batch_idx=None, leftpad_k=None, rotary_cos=None, rotary_sin=None,
+            seqlens_rotary=None, q_descale=None, k_descale=None, v_descale=None, softmax_scale=None,
+            is_causal=False, window_size_left=-1, window_size_right=-1, attention_chunk=0, softcap=0.0,
+            is_rotary_interleaved=False, scheduler_metadata=None, num_splits=0, pack_gqa=None, sm_margin=0,
+            attn_read_list=None, attn_must_do_list=None, attn_write_list=None, thr=-3.0,
+            _must_do_is_1d: bool = False):
+    """Host half of the op (flash_api.cpp:667-1249) for the non-causal, fixed-length, MHA subset that
+    ``LiteAttention.__call__`` reaches. Returns ``(out, softmax_lse, out_accum, softmax_lse_accum)``."""
+    if not q.is_cuda:
+        raise RuntimeError("lite_attention::fwd has no CPU implementation (HIP device tensors required)")
+    if q.dtype not in (torch.bfloat16,):
+        if q.dtype in (torch.float16, torch.float8_e4m3fn):
+            raise NotImplementedError(f"dtype {q.dtype} is not instantiated in this build (bf16 only)")
+        raise RuntimeError("FlashAttention only supports fp16, bf16, and fp8_e4m3 type")          # :715
+    if k.dtype != q.dtype or v.dtype != q.dtype:
+        raise RuntimeError("query and key must have the same dtype")                              # :718-719
+    for name, val in (("k_new", k_new), ("v_new", v_new), ("q_v", q_v), ("cu_seqlens_q", cu_seqlens_q),
+                      ("cu_seqlens_k", cu_seqlens_k), ("cu_seqlens_k_new", cu_seqlens_k_new),
+                      ("seqused_q", seqused_q), ("seqused_k", seqused_k), ("page_table", page_table),
+                      ("kv_batch_idx", kv_batch_idx), ("leftpad_k", leftpad_k), ("rotary_cos", rotary_cos),
+                      ("rotary_sin", rotary_sin), ("seqlens_rotary", seqlens_rotary),
+                      ("scheduler_metadata", scheduler_metadata), ("q_descale", q_descale),
+                      ("k_descale", k_descale), ("v_descale", v_descale)):
+        if val is not None:
+            raise NotImplementedError(f"{name} is outside the QK-Skip hot path (compiled out of the reference's "
+                                      "default LiteAttention build, hopper/setup.py:47-63)")
+    if is_causal or window_size_left >= 0 or window_size_right >= 0 or attention_chunk != 0:
+        raise NotImplementedError("causal / local / chunked attention is outside the QK-Skip hot path "
+                                  "(the reference's skip walk is non-causal only, mainloop:1757-1827)")
+    if softcap != 0.0:
+        raise NotImplementedError("softcap is compiled out (hopper/setup.py:52)")
+    if num_splits not in (0, 1):
+        raise NotImplementedError("split-KV is compiled out (hopper/setup.py:48)")
+    if pack_gqa:
+        raise NotImplementedError("pack_gqa is compiled out (hopper/setup.py:53)")
+    if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
+        raise RuntimeError("q, k, v must be 4D tensors (batch, seqlen, nheads, headdim)")
+    if q.stride(-1) != 1 or k.stride(-1) != 1 or v.stride(-1) != 1:
+        raise RuntimeError("Input tensor must have contiguous last dimension")                   # :726-728
+    B, Sq, H, D = q.shape
+    Bk, Sk, Hk, Dk = k.shape
+    Dv = v.shape[-1]
+    if (Bk, Dk) != (B, D) or tuple(v.shape[:3]) != (B, Sk, Hk):
+        raise RuntimeError("k/v shape mismatch: expected k (batch, seqlen_k, nheads_k, headdim), v (batch, seqlen_k, nheads_k, headdim_v)")
+    if H % Hk != 0:
+        raise RuntimeError("Number of heads in key/value must divide number of heads in query")  # :777
+    if D % 8 != 0:
+        raise RuntimeError("head_size should be a multiple of 8")                                # :854-856
+    if Hk != H:
+        raise NotImplementedError("GQA/MQA (nheads_k != nheads) is outside the QK-Skip hot path in this build")
+    if Dv != D:
+        raise NotImplementedError("head_dim_v != head_dim is outside the QK-Skip hot path in this build")
+    if softmax_scale is None:
+        softmax_scale = D ** -0.5
+
+    if out is None:
+        out = torch.empty((B, Sq, H, Dv), dtype=torch.bfloat16, device=q.device)                 # :872-886
+    else:
+        if out.dtype != torch.bfloat16 or tuple(out.shape) != (B, Sq, H, Dv) or out.stride(-1) != 1:
+            raise RuntimeError("out must be bf16 of shape (batch, seqlen_q, nheads, headdim_v) with contiguous last dimension")
+    softmax_lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)                  # :887-892
+    empty = torch.empty(0, dtype=torch.float32, device=q.device)
+
+    if Sk == 0:                                                                                   # :1241-1245
+        out.zero_()
+        softmax_lse.fill_(float("inf"))
+        return out, softmax_lse, empty, empty
+
+    read_ptr = _check_list(attn_read_list, "attn_read_list", q)
+    write_ptr = _check_list(attn_write_list, "attn_write_list", q)
+    if _must_do_is_1d and attn_must_do_list is not None:
+        if attn_must_do_list.dtype != torch.int32 or attn_must_do_list.dim() != 1 or not attn_must_do_list.is_contiguous():
+            raise RuntimeError("1-D attn_must_do_list must be a contiguous int32 vector")
+        must_ptr = attn_must_do_list.data_ptr()
+    else:
+        must_ptr = _check_list(attn_must_do_list, "attn_must_do_list", q)
+
+    block_m, block_n = get_tile_sizes(D, q.element_size())
+    q_tiles, k_tiles = -(-Sq // block_m), -(-Sk // block_n)
+    for name, t in (("attn_read_list", attn_read_list), ("attn_write_list", attn_write_list),
+                    ("attn_must_do_list", None if _must_do_is_1d else attn_must_do_list)):
+        if t is not None and (t.shape[0] < B or tuple(t.shape[1:]) != (H, q_tiles, k_tiles + 1)):
+            raise RuntimeError(f"{name} must have shape [>=batch, heads, q_blocks, k_blocks + 1] = "
+                               f"[>={B}, {H}, {q_tiles}, {k_tiles + 1}] for tile sizes ({block_m}, {block_n}); "
+                               f"got {tuple(t.shape)}")
+    if _must_do_is_1d and attn_must_do_list is not None and attn_must_do_list.numel() < 3:
+        raise RuntimeError("1-D attn_must_do_list needs at least [len, start, end]")
+
+    a = _cabi.LaFwdArgs()
+    a.struct_size = ctypes.sizeof(_cabi.LaFwdArgs)
+    a.dtype = _cabi.LA_DTYPE_BF16
+    a.q, a.k, a.v, a.o, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), softmax_lse.data_ptr()
+    a.q_batch_stride, a.q_row_stride, a.q_head_stride = q.stride(0), q.stride(1), q.stride(2)
+    a.k_batch_stride, a.k_row_stride, a.k_head_stride = k.stride(0), k.stride(1), k.stride(2)
+    a.v_batch_stride, a.v_row_stride, a.v_head_stride = v.stride(0), v.stride(1), v.stride(2)
+    a.o_batch_stride, a.o_row_stride, a.o_head_stride = out.stride(0), out.stride(1), out.stride(2)
+    a.batch, a.seqlen_q, a.seqlen_k = B, Sq, Sk
+    a.num_heads, a.num_heads_k, a.head_dim, a.head_dim_v = H, Hk, D, Dv
+    a.softmax_scale = float(softmax_scale)
+    a.read_list, a.write_list, a.must_do_list = read_ptr, write_ptr, must_ptr
+    a.must_do_is_1d = 1 if _must_do_is_1d else 0
+    a.thr = float(thr)
+    a.block_m, a.block_n = block_m, block_n
+    with torch.cuda.device(q.device):                                                             # CUDAGuard :885
+        stream = torch.cuda.current_stream(q.device).cuda_stream                                  # :1219
+        rc = _cabi.load().la_fwd(ctypes.byref(a), ctypes.c_void_p(stream))
+    if rc != _cabi.LA_OK:
+        msg = _cabi.status_string(rc)
+        if rc == _cabi.LA_ERR_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        if rc == _cabi.LA_ERR_LAUNCH:
+            msg += f" (hipError {_cabi.load().la_last_hip_error()})"
+        raise RuntimeError(f"lite_attention::fwd: {msg}")
+    return out, softmax_lse, empty, empty
+
+
+# ---- op registration: torch.ops.lite_attention.fwd (flash_api.cpp:1722-1763, 1819-1824) ----------
+_op_lib = None
+
+
+def _register_op():
+    global _op_lib
+    if _op_lib is not None:
+        return
+    lib = torch.library.Library("lite_attention", "DEF")
+    lib.define(_FWD_SCHEMA)
+
+    def _fwd_impl(*args, **kwargs):
+        return mha_fwd(*args, **kwargs)
+
+    lib.impl("fwd", _fwd_impl, "CUDA")
+    _op_lib = lib
+
+
+_register_op()
+
+
+def maybe_contiguous(x):
+    return x.contiguous() if x is not None and x.stride(-1) != 1 else x
+
+
+def _flash_attn_forward(q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k_new,
+                        seqused_q, seqused_k, max_seqlen_q, max_seqlen_k, page_table, kv_batch_idx,
+                        leftpad_k, rotary_cos, rotary_sin, seqlens_rotary, q_descale, k_descale, v_descale,
+                        softmax_scale, causal, window_size=(-1, -1), attention_chunk=0, softcap=0.0,
+                        rotary_interleaved=True, scheduler_metadata=None, num_splits=1, pack_gqa=None,
+                        sm_margin=0, attn_read_list=None, attn_must_do_list=None, attn_write_list=None,
+                        thr=-3.0):
+    """Same contract as the reference's _flash_attn_forward (:20-112)."""
+    q, k, v = [maybe_contiguous(x) for x in (q, k, v)]
+    if attn_must_do_list is not None and attn_must_do_list.dim() == 1:
+        # 1-D broadcast must-do row: extension of the C-ABI (avoids the per-call 4-D repeat,
+        # lite_attention.py:239-241). Not expressible in the reference schema -> direct call.
+        out, softmax_lse, *rest = mha_fwd(
+            q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k_new, seqused_q, seqused_k,
+            max_seqlen_q, max_seqlen_k, page_table, kv_batch_idx, leftpad_k, rotary_cos, rotary_sin,
+            seqlens_rotary, q_descale, k_descale, v_descale, softmax_scale, causal, window_size[0],
+            window_size[1], attention_chunk, softcap, rotary_interleaved, scheduler_metadata, num_splits,
+            pack_gqa, sm_margin, attn_read_list, attn_must_do_list, attn_write_list, thr, _must_do_is_1d=True)
+        return (out, softmax_lse, *rest)
+    out, softmax_lse, *rest = torch.ops.lite_attention.fwd(
+        q, k, v, k_new, v_new, qv, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens_k_new, seqused_q, seqused_k,
+        max_seqlen_q, max_seqlen_k, page_table, kv_batch_idx, leftpad_k, rotary_cos, rotary_sin,
+        seqlens_rotary, q_descale, k_descale, v_descale, softmax_scale, causal, window_size[0],
+        window_size[1], attention_chunk, softcap, rotary_interleaved, scheduler_metadata, num_splits,
+        pack_gqa, sm_margin, attn_read_list, attn_must_do_list, attn_write_list, thr=thr)
+    return (out, softmax_lse, *rest)
+
+
+class FlashAttnFunc(torch.autograd.Function):
+    """Forward-only counterpart of the reference's FlashAttnFunc (:274-342)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, softmax_scale, causal, qv=None, q_descale=None, k_descale=None, v_descale=None,
+                window_size=(-1, -1), attention_chunk=0, softcap=0.0, num_splits=1, pack_gqa=None,
+                deterministic=False, sm_margin=0, attn_read_list=None, attn_must_do_list=None,
+                attn_write_list=None, thr=-3.0, return_softmax_lse=False):
+        if softmax_scale is None:
+            softmax_scale = (q.shape[-1] + (qv.shape[-1] if qv is not None else 0)) ** (-0.5)   # :300-301
+        out, softmax_lse, *rest = _flash_attn_forward(
+            q, k, v, None, None, qv, None, None, None, None, None, None, None, None, None, None, None,
+            None, None, None, q_descale, k_descale, v_descale, softmax_scale, causal=causal,
+            window_size=window_size, attention_chunk=attention_chunk, softcap=softcap, num_splits=num_splits,
+            pack_gqa=pack_gqa, sm_margin=sm_margin, attn_read_list=attn_read_list,
+            attn_must_do_list=attn_must_do_list, attn_write_list=attn_write_list, thr=thr)
+        ctx.mark_non_differentiable(softmax_lse)
+        return (out, softmax_lse) if return_softmax_lse else out
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        raise NotImplementedError("lite_attention backward is not built (the reference's default build "
+                                  "sets FLASH_ATTENTION_DISABLE_BACKWARD, hopper/setup.py:47)")
+
+
+def flash_attn_func(q, k, v, softmax_scale=None, causal=False, qv=None, q_descale=None, k_descale=None,
+                    v_descale=None, window_size=(-1, -1), attention_chunk=0, softcap=0.0, num_splits=1,
+                    pack_gqa=None, deterministic=False, sm_margin=0, attn_read_list=None,
+                    attn_must_do_list=None, attn_write_list=None, thr=-3.0, return_softmax_lse=False):
+    """Same signature and return convention as the reference's flash_attn_func (:547-635).
+
+    q: (batch, seqlen, nheads, headdim); k, v: (batch, seqlen_k, nheads, headdim). Returns ``out``
+    (batch, seqlen, nheads, headdim) or ``(out, softmax_lse)`` with softmax_lse (batch, nheads, seqlen)
+    fp32. With ``attn_read_list``/``attn_write_list`` the K-tile loop walks the read list and the skip
+    decisions of this call are serialised into the write list (QK-Skip)."""
+    return FlashAttnFunc.apply(q, k, v, softmax_scale, causal, qv, q_descale, k_descale, v_descale, window_size,
+                               attention_chunk, softcap, num_splits, pack_gqa, deterministic, sm_margin,
+                               attn_read_list, attn_must_do_list, attn_write_list, thr, return_softmax_lse)
+
+
+def flash_attn_combine(out_partial: torch.Tensor, lse_partial: torch.Tensor, out: Optional[torch.Tensor] = None,
+                       return_lse: bool = True):
+    """LSE-weighted merge of per-split partial results (sequence-parallel K/V splits).
+
+    out_partial: (num_splits, batch, seqlen, nheads, headdim) fp32 or bf16; lse_partial:
+    (num_splits, batch, nheads, seqlen) fp32 (the layout ``flash_attn_func`` returns). Counterpart of
+    the reference's flash_attn_combine (hopper/_internal/flash_attn_interface.py, fwd_combine op)."""
+    if not out_partial.is_cuda:
+        raise RuntimeError("flash_attn_combine has no CPU implementation")
+    if out_partial.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("out_partial must be fp32 or bf16")
+    if lse_partial.dtype != torch.float32:
+        raise RuntimeError("lse_partial must be fp32")
+    out_partial = out_partial.contiguous()
+    lse_partial = lse_partial.contiguous()
+    ns, B, S, H, Dv = out_partial.shape
+    if tuple(lse_partial.shape) != (ns, B, H, S):
+        raise RuntimeError("lse_partial must have shape (num_splits, batch, nheads, seqlen)")
+    if out is None:
+        out = torch.empty((B, S, H, Dv), dtype=torch.bfloat16, device=out_partial.device)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=out_partial.device) if return_lse else None
+    with torch.cuda.device(out_partial.device):
+        stream = torch.cuda.current_stream(out_partial.device).cuda_stream
+        rc = _cabi.load().la_combine(out_partial.data_ptr(), int(out_partial.dtype == torch.bfloat16),
+                                     lse_partial.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None,
+                                     ns, B, S, H, Dv, ctypes.c_void_p(stream))
+    if rc != _cabi.LA_OK:
+        raise RuntimeError(f"la_combine: {_cabi.status_string(rc)}")
+    return (out, lse) if return_lse else out
+
+
+def skip_list_stats(skip_list: torch.Tensor, batch: Optional[int] = None) -> torch.Tensor:
+    """Device-side count of listed tiles: returns int64[2] = (listed tiles, rows). No host sync."""
+    if skip_list.dtype != torch.int32 or skip_list.dim() != 4 or not skip_list.is_contiguous():
+        raise RuntimeError("skip list must be a contiguous int32 tensor [batch, heads, q_blocks, k_blocks + 1]")
+    if not skip_list.is_cuda:
+        raise RuntimeError("skip_list_stats has no CPU implementation")
+    nb = skip_list.shape[0] if batch is None else batch
+    out = torch.empty(2, dtype=torch.int64, device=skip_list.device)
+    with torch.cuda.device(skip_list.device):
+        stream = torch.cuda.current_stream(skip_list.device).cuda_stream
+        rc = _cabi.load().la_skip_list_stats(skip_list.data_ptr(), nb, skip_list.shape[1], skip_list.shape[2],
+                                             skip_list.shape[3] - 1, out.data_ptr(), ctypes.c_void_p(stream))
+    if rc != _cabi.LA_OK:
+        raise RuntimeError(f"la_skip_list_stats: {_cabi.status_string(rc)}")
+    return out

@@ -1,0 +1,220 @@
+"""LiteAttention for MI355X: the per-layer owner of the ping-pong skip lists.
+
+API-compatible with /root/reference/hopper/lite_attention.py (class, method, argument and attribute
+names; defaults; list layout ``_skip_list[2, maxB, H, Qt, Kt+1]``; ``_phase``; ``threshold``), so
+``from lite_attention import LiteAttention`` code runs unchanged. The attention itself is
+``flash_attn_func`` -> ``torch.ops.lite_attention.fwd`` -> C-ABI ``la_fwd`` -> the gfx950 HIP kernel;
+list construction lives in ``skip_lists.py``.
+
+Behavioural differences, all fixes of reference defects:
+  B-1  ``enable_skipping=False`` runs the dense kernel (reference: AttributeError, lite_attention.py:262-266)
+  B-2  K-tile count from ``key.shape[1]`` (reference: from the query length, :121-122)
+  B-3  ``calc_percentage`` is the true listed fraction (reference returns about -1, :61-85)
+  B-4  ``must_skip_list`` in README format, caller's list untouched, nothing printed (:126-145)
+  B-6  must-do list handed to the kernel as one cached row (reference: 4-D repeat + H2D per call, :239-241)
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple, Union
+
+import torch
+
+from . import skip_lists as _sl
+from .flash_attn_interface import flash_attn_func, get_tile_sizes
+
+Tensor = torch.Tensor
+
+
+def _verbose() -> bool:
+    return os.getenv("LITE_ATTENTION_VERBOSE", "FALSE") != "FALSE"
+
+
+class LiteAttention:
+    """QK-Skip attention with internally managed read/write skip lists.
+
+    Args mirror the reference (lite_attention.py:36): ``enable_skipping=True``, ``threshold=-10.0``
+    (log2 domain, must be negative unless env LITE_ATTENTION_DEBUG is set), ``max_batch_size=4``.
+    One instance per attention layer; not thread-safe (README.md:162-172)."""
+
+    def __init__(self, enable_skipping: bool = True, threshold: float = -10.0, max_batch_size: int = 4):
+        self._skip_list: Optional[Tensor] = None   # [2, max_batch, H, Qt, Kt+1] int32
+        self._phase = 0                            # index of the buffer the NEXT call reads
+        self._shape_key = None                     # what the lists were built for
+        self._must_do_rows = {}                    # tuple(must_do_list) -> device row
+        self._last_percentage = 0.0
+        self.enable_skipping = enable_skipping
+        self.max_batch_size = max_batch_size
+        self.set_threshold(threshold)
+
+    # ---- reference-compatible static helpers -------------------------------------------------
+    @staticmethod
+    def ceil_div(x, y):
+        return _sl.cdiv(x, y)
+
+    @staticmethod
+    def get_MN(head_dim, element_size, v_colmajor=False):
+        """(kTileM, kTileN) of the kernel, from ``la_get_tile_sizes`` (one table shared with the HIP code;
+        the reference hand-copies it, lite_attention.py:87-111 vs tile_size.h:10-62)."""
+        if v_colmajor:
+            raise NotImplementedError("column-major V (fp8 layout of the reference) is not built")
+        return get_tile_sizes(head_dim, element_size)
+
+    @staticmethod
+    def calc_percentage(read_list: Tensor) -> float:
+        """Fraction of tiles that are listed, i.e. NOT skipped (what lite_attention.py:61-85 intended)."""
+        return _sl.listed_fraction(read_list)
+
+    @staticmethod
+    def init_skip_list(batch, seq_len, heads, head_dim, v_colmajor, dtype, device, must_skip_list=None,
+                       seq_len_k=None) -> Tensor:
+        """``[2, batch, heads, q_tiles, k_tiles+1]`` int32, rows ``[2, k_tiles-1, 0, ...]`` (:113-153).
+        ``seq_len_k`` (extension) defaults to ``seq_len``."""
+        if v_colmajor:
+            raise NotImplementedError("column-major V (fp8 layout of the reference) is not built")
+        _, bn, qt, kt = _sl.tile_geometry(seq_len, seq_len if seq_len_k is None else seq_len_k, head_dim,
+                                          dtype.itemsize)
+        row = None if must_skip_list is None else _sl.must_skip_row(must_skip_list, bn, kt)
+        return _sl.new_skip_lists(batch, heads, qt, kt, device, row)
+
+    @staticmethod
+    def _expand_must_do_list(must_do_list, list_shape, query, value):
+        """4-D ``[maxB, H, Qt, Kt+1]`` expansion kept for API parity (:214-242); ``__call__`` does not use it."""
+        _, bn = get_tile_sizes(query.shape[-1], query.dtype.itemsize)
+        row = _sl.must_do_row(must_do_list, bn, list_shape[3], query.device)
+        return row.repeat(*list_shape[:3], 1).contiguous()
+
+    # ---- list management ----------------------------------------------------------------------
+    def _init_skip_list(self, query: Tensor, value: Tensor, must_skip_list: list = None) -> Tensor:
+        assert query.shape[0] <= self.max_batch_size, "batch size must be less than or equal to max_batch_size (modify max_batch_size in LiteAttention constructor)"
+        return self.init_skip_list(self.max_batch_size, query.shape[1], query.shape[2], query.shape[3], False,
+                                   query.dtype, query.device, must_skip_list, seq_len_k=value.shape[1])
+
+    def _get_read_write_lists(self, query: Tensor, value: Tensor, must_skip_list: list = None
+                              ) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+        """(read, write) views for this call; (re)builds the lists when any of seq lengths / heads /
+        head_dim / dtype / device changed (:179-200) and flips the ping-pong phase (:203-210)."""
+        if not self.enable_skipping:
+            return None, None
+        key = (query.shape[1], value.shape[1], query.shape[2], query.shape[3], query.dtype, query.device)
+        if self._skip_list is None or key != self._shape_key:
+            self._skip_list = self._init_skip_list(query, value, must_skip_list)
+            self._shape_key = key
+            self._phase = 0
+            self._must_do_rows = {}
+            if _verbose():
+                print("[Warning]: reinitialized skip list during the forward pass")
+        rd = self._phase
+        self._phase = 1 - rd
+        return self._skip_list[rd], self._skip_list[1 - rd]
+
+    def _must_do_device_row(self, must_do_list, query: Tensor, width: int) -> Tensor:
+        key = (0, 0) if must_do_list is None else tuple(must_do_list)   # [0,0] = empty must-do (:267)
+        row = self._must_do_rows.get(key)
+        if row is None:
+            _, bn = get_tile_sizes(query.shape[-1], query.dtype.itemsize)
+            row = _sl.must_do_row(key, bn, width, query.device)
+            self._must_do_rows[key] = row
+        return row
+
+    # ---- the attention call -------------------------------------------------------------------
+    def __call__(self, query: Tensor, key: Tensor, value: Tensor, scale: Optional[float] = None,
+                 return_softmax_lse: bool = False, must_do_list: list = None, must_skip_list: list = None
+                 ) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+        """One attention call of a denoising step (:244-291).
+
+        query (B, S, H, D) bf16; key/value (B, Sk, H, D). Returns out (B, S, H, D) — the reference
+        docstring's (B, S, H*D) is wrong (Appendix B-5) — or ``(out, lse)`` with lse (B, H, S) fp32.
+        ``must_do_list``: token ranges ``[start0, end0, ...]`` (descending) never dropped;
+        ``must_skip_list``: token ranges dropped from the start, applied when the lists are (re)built."""
+        read_list, write_list = self._get_read_write_lists(query, key, must_skip_list)
+        must_do = None
+        if read_list is not None:
+            must_do = self._must_do_device_row(must_do_list, query, read_list.shape[3])
+        output = flash_attn_func(q=query, k=key, v=value, softmax_scale=scale, attn_read_list=read_list,
+                                 attn_must_do_list=must_do, attn_write_list=write_list, thr=self.threshold,
+                                 return_softmax_lse=return_softmax_lse)
+        if read_list is not None and _verbose():
+            self._last_percentage = self.calc_percentage(read_list[: query.shape[0]])
+            print(f"[Info]: Percentage of tiles skipped: {1.0 - self._last_percentage:.2%}")
+        return output
+
+    # ---- state control ------------------------------------------------------------------------
+    def reset_skip_state(self):
+        """Forget the lists; the next call starts from "all tiles listed" (:293-304)."""
+        self._skip_list = None
+        self._phase = 0
+        self._shape_key = None
+        self._must_do_rows = {}
+        self._last_percentage = 0.0
+
+    def set_threshold(self, threshold: float):
+        """Threshold must be negative unless env LITE_ATTENTION_DEBUG != "FALSE" (:306-313)."""
+        if threshold >= 0 and os.getenv("LITE_ATTENTION_DEBUG", "FALSE") == "FALSE":
+            raise ValueError("threshold must be negative when debug mode is not enabled")
+        self.threshold = threshold
+
+    def enable_skip_optimization(self, enable: bool = True):
+        self.enable_skipping = enable
+
+    # ---- additions: statistics and checkpoint/resume -------------------------
+    def current_read_list(self) -> Optional[Tensor]:
+        """The list the next call will read (= what the last call wrote)."""
+        return None if self._skip_list is None else self._skip_list[self._phase]
+
+    def get_skip_fraction(self, batch: Optional[int] = None) -> float:
+        """Fraction of tiles the next call skips (device reduction; synchronises)."""
+        rl = self.current_read_list()
+        if rl is None:
+            return 0.0
+        return 1.0 - self.calc_percentage(rl[: (rl.shape[0] if batch is None else batch)])
+
+    def state_dict(self) -> dict:
+        key = self._shape_key
+        return {
+            "skip_list": None if self._skip_list is None else self._skip_list.detach().cpu().clone(),
+            "phase": self._phase, "threshold": self.threshold, "enable_skipping": self.enable_skipping,
+            "max_batch_size": self.max_batch_size,
+            "shape_key": None if key is None else (*key[:4], str(key[4]).replace("torch.", "")),
+        }
+
+    def load_state_dict(self, state: dict, device=None):
+        self.threshold = state["threshold"]
+        self.enable_skipping = state["enable_skipping"]
+        self.max_batch_size = state["max_batch_size"]
+        self.reset_skip_state()
+        if state["skip_list"] is None:
+            return
+        dev = torch.device(device) if device is not None else state["skip_list"].device
+        self._skip_list = state["skip_list"].to(dev).contiguous()
+        self._phase = state["phase"]
+        sq, sk, h, d, dt = state["shape_key"]
+        self._shape_key = (sq, sk, h, d, getattr(torch, dt), dev)
+
+
+class SeqParallelLiteAttention:
+    """``num_nodes`` independent skip states, one per K/V split, selected by ``split_idx`` (:322-345).
+    The (local Q x split j) tile pattern differs per j, hence one state each. Transport of K/V and the
+    LSE merge of the partial results stay with the caller; ``flash_attn_combine`` does the merge."""
+
+    def __init__(self, num_nodes: int, enable_skipping: bool = True, threshold: float = -10.0, max_batch_size: int = 4):
+        self.num_nodes = num_nodes
+        self.lite_attention = [LiteAttention(enable_skipping, threshold, max_batch_size) for _ in range(num_nodes)]
+        self.set_threshold(threshold)
+
+    def __call__(self, query: Tensor, key: Tensor, value: Tensor, split_idx: int, scale: Optional[float] = None,
+                 return_softmax_lse: bool = False) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+        assert split_idx < self.num_nodes, "split_idx must be less than num_nodes"
+        return self.lite_attention[split_idx](query, key, value, scale, return_softmax_lse)
+
+    def reset_skip_state(self):
+        for la in self.lite_attention:
+            la.reset_skip_state()
+
+    def set_threshold(self, threshold: float):
+        for la in self.lite_attention:
+            la.set_threshold(threshold)
+
+    def enable_skip_optimization(self, enable: bool = True):
+        for la in self.lite_attention:
+            la.enable_skip_optimization(enable)
