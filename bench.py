@@ -1,0 +1,270 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the QK-Skip attention hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N=1 default)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric: "self-attn TFLOPS + ms/step @ seq=75k d=128 bf16, sparsity 0->77%"):
+one self-attention call of Wan2.1-14B's video shape — B=1, S=75600, H=40, D=128, bf16 — through
+``LiteAttention.__call__`` with an IMPOSED 42 % sparse read list (SURVEY.md §8d "imposed sparsity":
+every q-tile keeps the first walked tile plus a contiguous band of (1-s)*Kt key tiles centred on its
+diagonal; thr=-inf so the list is a fixed point and every step does identical work). A "step" is one such
+call. With N GPUs the 40 heads are sharded (40/N per rank, one skip state per rank, no data-path
+collective inside the attention) and the step ends with ONE RCCL all-gather of the bf16 output shard
+("scaling": "strong" — total work is fixed).
+
+`value` = executed TFLOP/s of the whole job = FLOPs of the LISTED tiles (4*rows*cols*D per tile, summed
+over all ranks) / step time; skipped tiles are never counted as work. The same JSON line carries the
+1-GPU sparsity sweep (0/21/42/57/77 %: ms, executed and dense-equivalent TFLOP/s, t(s)/t(0)), the MFMA
+roofline of the forward kernel (HIP-event kernel time) and the CPU baseline (the oracle port timed on the
+host cores on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+SPARSITIES = (0.0, 0.21, 0.42, 0.57, 0.77)
+HEADLINE_SPARSITY = 0.42
+
+
+def banded_rows(q_tiles: int, k_tiles: int, block_m: int, block_n: int, sparsity: float) -> torch.Tensor:
+    """[q_tiles, 5] int32 list-row heads for the imposed-sparsity pattern (<= 2 ranges)."""
+    keep = max(1, round((1.0 - sparsity) * k_tiles))
+    rows = torch.zeros(q_tiles, 5, dtype=torch.int32)
+    for m in range(q_tiles):
+        if keep >= k_tiles:
+            rows[m, :3] = torch.tensor([2, k_tiles - 1, 0])
+            continue
+        centre = min(k_tiles - 1, (m * block_m + block_m // 2) // block_n)
+        band = keep - 1                                   # + the always-walked first tile k_tiles-1
+        lo = max(0, min(centre - band // 2, k_tiles - 1 - band))
+        hi = lo + band - 1
+        if band <= 0:
+            rows[m, :3] = torch.tensor([2, k_tiles - 1, k_tiles - 1])
+        elif hi >= k_tiles - 2:                           # band touches the first tile: one range
+            rows[m, :3] = torch.tensor([2, k_tiles - 1, lo])
+        else:
+            rows[m] = torch.tensor([4, k_tiles - 1, k_tiles - 1, hi, lo])
+    return rows
+
+
+def listed_tiles_of_rows(rows: torch.Tensor) -> int:
+    n = 0
+    for r in rows.tolist():
+        n += r[1] - r[2] + 1
+        if r[0] == 4:
+            n += r[3] - r[4] + 1
+    return n
+
+
+def impose_lists(att, rows: torch.Tensor):
+    """Overwrite BOTH ping-pong buffers of `att` with the same rows (fixed point under thr=-inf)."""
+    sl = att._skip_list
+    sl.zero_()
+    sl[..., :5] = rows.to(sl.device)[None, None, None]
+
+
+def executed_flops(rows: torch.Tensor, heads: int, batch: int, S: int, Sk: int, bm: int, bn: int, D: int) -> float:
+    """sum over listed tiles of 4*rows*cols*D with ragged edge tiles counted at their real size."""
+    q_tiles, k_tiles = rows.shape[0], -(-Sk // bn)
+    total = 0.0
+    last_cols = Sk - (k_tiles - 1) * bn
+    for m, r in enumerate(rows.tolist()):
+        nrows = min(bm, S - m * bm)
+        ranges = [(r[1], r[2])] + ([(r[3], r[4])] if r[0] == 4 else [])
+        cols = 0
+        for s, e in ranges:
+            cols += (s - e + 1) * bn
+            if s == k_tiles - 1:
+                cols -= bn - last_cols
+        total += 4.0 * nrows * cols * D
+    return total * heads * batch
+
+
+def cpu_baseline(S, D, bm, bn, rows, target_seconds=15.0):
+    """Time the oracle port (oracle/qkskip_oracle.c, OpenMP) on a bounded sample of the SAME workload:
+    one head, the first `n` q-tiles with their 42 % lists against all S keys."""
+    from oracle import oracle as orc
+    threads = os.cpu_count() or 1
+    g = torch.Generator().manual_seed(1)
+    k = torch.randn(1, S, 1, D, generator=g).bfloat16()
+    v = torch.randn(1, S, 1, D, generator=g).bfloat16()
+    k_tiles = -(-S // bn)
+
+    def run(n_qt):
+        q = torch.randn(1, n_qt * bm, 1, D, generator=g).bfloat16()
+        lists = torch.zeros(2, 1, 1, n_qt, k_tiles + 1, dtype=torch.int32)
+        lists[0, 0, 0, :, :5] = rows[:n_qt]
+        t0 = time.perf_counter()
+        _, _, tiles = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=lists[0], write_list=lists[1],
+                                     thr=float("-inf"))
+        dt = time.perf_counter() - t0
+        return dt, tiles * 4.0 * bm * bn * D
+
+    dt, fl = run(threads)                       # probe: one q-tile per thread
+    rate = fl / dt
+    n_qt = int(max(threads, min(rows.shape[0], target_seconds * rate / (fl / threads))))
+    n_qt = (n_qt // threads) * threads
+    dt, fl = run(n_qt)
+    return {"value": round(fl / dt / 1e12, 5), "unit": "TFLOP/s", "cores": threads, "kind": "port",
+            "sample": f"1 head x {n_qt} q-tiles ({n_qt * bm} query rows) x all {S} keys at the 42% list, "
+                      f"{fl / 1e9:.1f} GFLOP in {dt:.1f} s (oracle/qkskip_oracle.c, OpenMP)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--seqlen", type=int, default=75600)
+    ap.add_argument("--heads", type=int, default=40)
+    ap.add_argument("--no-sweep", action="store_true", help="skip the 1-GPU sparsity sweep")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import liteattention_amd as L
+    from liteattention_amd.parallel import HeadShardedLiteAttention
+
+    B, S, H, D = 1, args.seqlen, args.heads, 128
+    assert H % world == 0, "heads must divide over ranks"
+    Hl = H // world
+    bm, bn = L.get_tile_sizes(D, 2)
+    q_tiles, k_tiles = -(-S // bm), -(-S // bn)
+
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    q, k, v = [torch.randn(B, S, Hl, D, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
+               for _ in range(3)]
+
+    att = HeadShardedLiteAttention(num_heads=H, threshold=-10.0, max_batch_size=B,
+                                   process_group=None if world == 1 else dist.group.WORLD)
+    att.local.threshold = float("-inf")     # imposed lists are a fixed point: identical work every step
+
+    def set_sparsity(s):
+        rows = banded_rows(q_tiles, k_tiles, bm, bn, s)
+        if att.local._skip_list is None:
+            att.local._get_read_write_lists(q, k)          # allocate for this shape
+            att.local._phase = 0
+        impose_lists(att.local, rows)
+        return rows
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(steps, warmup):
+        for _ in range(warmup):
+            att(q, k, v)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            att(q, k, v, _kernel_events=ev[i])
+        barrier()
+        dt = time.perf_counter() - t0
+        kern_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt / steps, kern_ms / 1e3
+
+    # ---- headline: 42 % imposed sparsity
+    rows = set_sparsity(HEADLINE_SPARSITY)
+    flops_rank = executed_flops(rows, Hl, B, S, S, bm, bn, D)
+    step_s, kern_s = timed(args.steps, args.warmup)
+    flops_job = flops_rank * world
+    listed_frac = listed_tiles_of_rows(rows) / (q_tiles * k_tiles)
+
+    result = {
+        "metric": "self-attn TFLOPS + ms/step @ seq=75k d=128 bf16, sparsity 0->77%; 1/2/4/8 GPU",
+        "value": round(flops_job / step_s / 1e12, 2),
+        "unit": "TFLOP/s (executed: FLOPs of listed tiles only)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(step_s * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"QK-Skip self-attention fwd, B={B} S={S} H={H} D={D} bf16, imposed "
+                               f"{HEADLINE_SPARSITY:.0%} sparsity (banded lists, thr=-inf), tiles {bm}x{bn}",
+                   "sparsity": round(1 - listed_frac, 4),
+                   "parallelism": f"heads sharded {world}x{Hl}" + (" + 1 RCCL all-gather of O per step" if world > 1 else ""),
+                   "dense_equiv_tflops": round(4.0 * B * H * S * S * D / step_s / 1e12, 2)},
+        "roofline": {"bound": "mfma", "achieved": round(flops_rank / kern_s / 1e12, 2),
+                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(flops_rank / kern_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "traffic": None,
+                     "kernel": "la_fwd_bf16_d128_kernel<4,true>", "kernel_ms": round(kern_s * 1e3, 3),
+                     "algorithmic_tflop_per_launch": round(flops_rank / 1e12, 3)},
+    }
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if os.path.exists(pmc):
+        try:
+            with open(pmc) as f:
+                p = json.load(f)
+            result["roofline"]["traffic"] = p.get("hbm_bytes_per_launch")
+            result["roofline"]["traffic_source"] = p.get("source")
+        except Exception:
+            pass
+
+    # ---- 1-GPU sparsity sweep (the reference's sparsity-vs-runtime curve, README.md:81-87)
+    if world == 1 and not args.no_sweep:
+        sweep = []
+        for s in SPARSITIES:
+            r = set_sparsity(s)
+            fl = executed_flops(r, Hl, B, S, S, bm, bn, D)
+            st, ks = timed(max(5, args.steps // 2), 2)
+            sweep.append({"sparsity": round(1 - listed_tiles_of_rows(r) / (q_tiles * k_tiles), 4),
+                          "ms": round(st * 1e3, 3), "kernel_ms": round(ks * 1e3, 3),
+                          "executed_tflops": round(fl / st / 1e12, 1),
+                          "dense_equiv_tflops": round(4.0 * B * H * S * S * D / st / 1e12, 1)})
+        t0 = sweep[0]["ms"]
+        ref_curve = {0.0: 1.0, 0.21: 0.824, 0.42: 0.601, 0.57: 0.443, 0.77: 0.235}
+        for e, s in zip(sweep, SPARSITIES):
+            e["t_over_t0"] = round(e["ms"] / t0, 3)
+            e["reference_t_over_t0"] = ref_curve[s]
+        result["sweep"] = sweep
+
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline(S, D, bm, bn, banded_rows(q_tiles, k_tiles, bm, bn, HEADLINE_SPARSITY))
+        except Exception as e:  # the baseline is a reported number, never the measured path
+            result["cpu_baseline"] = {"value": None, "unit": "TFLOP/s", "cores": os.cpu_count(), "kind": "port",
+                                      "sample": f"failed: {e!r}"}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -10,7 +10,8 @@ import os
 from typing import Tuple
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libliteattention_amd.so")
+# LITEATTENTION_AMD_LIB overrides the in-tree location (deployment / tests of the failure path)
+LIB_PATH = os.environ.get("LITEATTENTION_AMD_LIB") or os.path.join(_PKG_DIR, "libliteattention_amd.so")
 
 LA_ABI_VERSION = 1
 LA_DTYPE_BF16, LA_DTYPE_FP16, LA_DTYPE_FP8_E4M3 = 0, 1, 2
@@ -62,6 +63,10 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; this library NEEDs the same SONAME. Whichever is
+    # loaded first serves both, and a process must have exactly one HIP runtime (with the system one
+    # loaded first, torch's device init reports hipErrorNoDevice). So: torch first, always.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise NativeLibraryError(
             f"{LIB_PATH} is missing: build it with `python -m liteattention_amd.build` "

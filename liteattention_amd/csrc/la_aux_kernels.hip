@@ -39,6 +39,7 @@ __global__ void __launch_bounds__(256) skip_list_stats_kernel(const int32_t* __r
 hipError_t launch_skip_list_stats(const int32_t* list, int rows, int k_tiles, int64_t* out, hipStream_t stream) {
     hipError_t err = hipMemsetAsync(out, 0, 2 * sizeof(int64_t), stream);
     if (err != hipSuccess) return err;
+    (void)hipGetLastError();
     int blocks = (rows + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
@@ -105,6 +106,7 @@ hipError_t launch_combine(const void* o_partial, bool partial_is_bf16, const flo
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
+    (void)hipGetLastError();
     if (partial_is_bf16)
         hipLaunchKernelGGL(combine_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, o_partial,
                            lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v);

@@ -397,6 +397,7 @@ hipError_t launch_fwd_bf16_d128(const FwdParams& p, bool skipable, hipStream_t s
     FwdParams pp = p;
     const size_t lds = fwd_lds_bytes(p.k_tiles, &pp.seq_cap);
     hipError_t err;
+    (void)hipGetLastError();   // drop any stale sticky error of this thread: only OUR launch is reported
     if (skipable) {
         auto kfn = la_fwd_bf16_d128_kernel<4, true>;
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -86,7 +86,6 @@ class LiteAttention:
 
     # ---- list management ----------------------------------------------------------------------
     def _init_skip_list(self, query: Tensor, value: Tensor, must_skip_list: list = None) -> Tensor:
-        assert query.shape[0] <= self.max_batch_size, "batch size must be less than or equal to max_batch_size (modify max_batch_size in LiteAttention constructor)"
         return self.init_skip_list(self.max_batch_size, query.shape[1], query.shape[2], query.shape[3], False,
                                    query.dtype, query.device, must_skip_list, seq_len_k=value.shape[1])
 
@@ -96,6 +95,8 @@ class LiteAttention:
         head_dim / dtype / device changed (:179-200) and flips the ping-pong phase (:203-210)."""
         if not self.enable_skipping:
             return None, None
+        # checked on EVERY call (the reference only checks at (re)init, :158, and would index past the lists)
+        assert query.shape[0] <= self.max_batch_size, "batch size must be less than or equal to max_batch_size (modify max_batch_size in LiteAttention constructor)"
         key = (query.shape[1], value.shape[1], query.shape[2], query.shape[3], query.dtype, query.device)
         if self._skip_list is None or key != self._shape_key:
             self._skip_list = self._init_skip_list(query, value, must_skip_list)

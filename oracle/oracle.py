@@ -53,6 +53,7 @@ class _Args(ctypes.Structure):
         ("p_round", ctypes.c_int32), ("mask_any_tail", ctypes.c_int32),
         ("nthreads", ctypes.c_int32),
         ("tiles_done", ctypes.c_void_p),
+        ("margins", ctypes.c_void_p),
     ]
 
 
@@ -86,11 +87,13 @@ def qkskip_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, block_m: in
                read_list: Optional[torch.Tensor] = None, write_list: Optional[torch.Tensor] = None,
                must_do_list: Optional[torch.Tensor] = None, thr: float = -3.0,
                softmax_scale: Optional[float] = None, p_round: bool = True,
-               mask_any_tail: bool = True, nthreads: int = 0
+               mask_any_tail: bool = True, nthreads: int = 0, margins: Optional[torch.Tensor] = None
                ) -> Tuple[torch.Tensor, torch.Tensor, int]:
     """Tiled CPU forward. q,k,v: (B,S,H,D) of any float dtype (values are taken as they are,
     i.e. bf16 tensors give bf16-representable fp32 operands). Lists are CPU int32 tensors of shape
     [>=B, H, Qt, Kt+1]; ``write_list`` is filled in place. ``must_do_list`` may be 1-D ([Kt+1]).
+    ``margins`` (optional fp32 [B,H,Qt,Kt]) receives, per computed non-first tile, the quantity compared
+    with ``thr`` (skip <=> margin <= thr); NaN elsewhere.
     Returns (o fp32 (B,Sq,H,Dv), lse fp32 (B,H,Sq), number of K tiles computed)."""
     lib = load_lib()
     qf, kf, vf = _f32c(q), _f32c(k), _f32c(v)
@@ -130,6 +133,10 @@ def qkskip_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, block_m: in
     a.mask_any_tail = int(mask_any_tail)
     a.nthreads = nthreads
     a.tiles_done = ctypes.addressof(tiles)
+    if margins is not None:
+        assert margins.dtype == torch.float32 and margins.is_contiguous() and tuple(margins.shape) == (B, H, Qt, Kt)
+        margins.fill_(float("nan"))
+        a.margins = margins.data_ptr()
     rc = lib.la_oracle_fwd(ctypes.byref(a))
     if rc != 0:
         raise RuntimeError(f"la_oracle_fwd failed: {rc}")

@@ -1,0 +1,115 @@
+"""CPU: the C-ABI shared library loads, exports every symbol include/*.h declares, and its argument
+struct matches the ctypes mirror. No compute is launched (no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from liteattention_amd import _cabi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "lite_attention_amd.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|char\s*\*|const char\*)\s+\**\s*(la_\w+)\s*\(", src, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_declares_expected_entry_points():
+    assert declared_functions() == sorted(_cabi.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _cabi.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    assert lib.la_abi_version() == _cabi.LA_ABI_VERSION
+
+
+def test_struct_layout_matches_header(tmp_path):
+    """Compile a C program against the header with gcc: sizeof/offsetof must equal the ctypes mirror
+    (also proves the header is plain C)."""
+    fields = [f[0] for f in _cabi.LaFwdArgs._fields_]
+    prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){",
+            'printf("%zu\\n", sizeof(la_fwd_args));']
+    prog += [f'printf("%zu\\n", offsetof(la_fwd_args, {f}));' for f in fields]
+    prog += ["return 0;}"]
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(prog))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-o", str(exe), str(c)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) == ctypes.sizeof(_cabi.LaFwdArgs)
+    for f, off in zip(fields, out[1:]):
+        assert getattr(_cabi.LaFwdArgs, f).offset == int(off), f
+
+
+def test_tile_sizes_and_status_strings():
+    assert _cabi.get_tile_sizes(128, 2) == (128, 64)
+    lib = _cabi.load()
+    m, n = ctypes.c_int(), ctypes.c_int()
+    assert lib.la_get_tile_sizes(48, 2, ctypes.byref(m), ctypes.byref(n)) == _cabi.LA_ERR_HEAD_DIM
+    assert lib.la_get_tile_sizes(128, 4, ctypes.byref(m), ctypes.byref(n)) == _cabi.LA_ERR_DTYPE
+    for code in range(0, -12, -1):
+        s = _cabi.status_string(code)
+        assert s and s != "unknown la_status", code
+    assert _cabi.status_string(-99) == "unknown la_status"
+
+
+def test_argument_validation_returns_codes_without_launching():
+    """Every check below fails before any HIP call, so it is safe without a GPU."""
+    lib = _cabi.load()
+    assert lib.la_fwd(None, None) == _cabi.LA_ERR_NULL_ARG
+    a = _cabi.LaFwdArgs()
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_STRUCT_SIZE
+    a.struct_size = ctypes.sizeof(_cabi.LaFwdArgs)
+    a.dtype = _cabi.LA_DTYPE_FP8_E4M3
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_DTYPE
+    a.dtype = _cabi.LA_DTYPE_BF16
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_NULL_ARG
+    a.q = a.k = a.v = a.o = 0x1000
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_SHAPE
+    a.batch, a.seqlen_q, a.seqlen_k, a.num_heads, a.num_heads_k, a.head_dim, a.head_dim_v = 1, 256, 256, 4, 3, 128, 128
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_SHAPE           # heads_k must divide heads
+    a.num_heads_k = 2
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_UNSUPPORTED     # GQA outside the hot path
+    a.num_heads_k = 4
+    a.head_dim = a.head_dim_v = 100
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_HEAD_DIM        # % 8 (flash_api.cpp:854)
+    a.head_dim = a.head_dim_v = 96
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_HEAD_DIM        # not instantiated
+    a.head_dim = a.head_dim_v = 128
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_TILE_MISMATCH
+    a.block_m, a.block_n = 128, 64
+    a.read_list = 0x2000
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_LISTS
+    a.write_list = 0x3000
+    a.q_row_stride = 4 * 128 + 4
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_STRIDE
+    assert lib.la_skip_list_stats(None, 1, 1, 1, 1, None, None) == _cabi.LA_ERR_NULL_ARG
+    assert lib.la_combine(None, 0, None, None, None, 1, 1, 1, 1, 128, None) == _cabi.LA_ERR_NULL_ARG
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """The product must not fall back to anything when the HIP extension is absent: import raises."""
+    code = "import sys; sys.path.insert(0, %r)\nimport liteattention_amd\n" % ROOT
+    env = dict(os.environ, LITEATTENTION_AMD_LIB=str(tmp_path / "nope.so"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert out.returncode != 0
+    assert "NativeLibraryError" in out.stderr and "no CPU/eager fallback" in out.stderr
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "liteattention_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("# oracle", "").lower() or "oracle hopper" in text.lower() or \
+                    all("import" not in line and "include" not in line for line in text.splitlines() if "oracle" in line.lower()), f

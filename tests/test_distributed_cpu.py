@@ -1,0 +1,62 @@
+"""CPU, world_size 2, gloo: the head-sharding + all-gather path of liteattention_amd.parallel.
+The device op cannot run here (no CPU fallback in the product), so the attention is replaced through the
+documented test seam by the eager oracle; what is under test is partitioning, state locality and the collective."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from liteattention_amd.parallel import HeadShardedLiteAttention, head_range
+        from oracle import oracle as orc
+
+        calls = []
+
+        def stand_in(q, k, v, scale=None, **kw):
+            calls.append(q.shape)
+            return orc.attention_dense_ref(q, k, v, softmax_scale=scale)[0]
+
+        H = 6
+        g = torch.Generator().manual_seed(0)           # same full tensors on every rank
+        q, k, v = [torch.randn(2, 96, H, 32, generator=g) for _ in range(3)]
+        att = HeadShardedLiteAttention(num_heads=H, max_batch_size=2, process_group=dist.group.WORLD,
+                                       attention_fn=stand_in)
+        assert (att.h0, att.h1) == head_range(H, world, rank) == (rank * 3, rank * 3 + 3)
+        gathered = att(att.shard(q), att.shard(k), att.shard(v))
+        assert gathered.shape == (world, 2, 96, 3, 32) and calls == [(2, 96, 3, 32)]
+        full = HeadShardedLiteAttention.to_bshd(gathered)
+        ref = orc.attention_dense_ref(q, k, v)[0]
+        assert torch.allclose(full, ref, atol=1e-6), (full - ref).abs().max()
+        local = att(att.shard(q), att.shard(k), att.shard(v), gather=False)
+        assert torch.equal(local, ref[:, :, att.h0:att.h1])
+        with pytest.raises(AssertionError):
+            att(q, k, v)                               # full tensors are not a local shard
+        with pytest.raises(ValueError):
+            head_range(5, 2, 0)
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_head_sharded_all_gather_world2(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]

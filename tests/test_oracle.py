@@ -1,0 +1,170 @@
+"""CPU: pins the oracle (oracle/) against the reference's golden vectors and known-answer tests."""
+import math
+
+import pytest
+import torch
+
+from helpers import DENSE_CASES, load_dense_case, ref_tolerance, structured_qkv
+from oracle import oracle as orc
+
+
+@pytest.mark.parametrize("name", DENSE_CASES)
+def test_dense_eager_oracle_matches_reference_outputs(name):
+    """attention_dense_ref restates attention_ref (test_util.py:226-348): same numbers as the reference run."""
+    c = load_dense_case(name)
+    out, lse = orc.attention_dense_ref(c["q"], c["k"], c["v"])
+    assert (out - c["out_ref"]).abs().max().item() <= 1e-6
+    assert (lse - c["lse_ref"]).abs().max().item() <= 2e-5
+    # the same-dtype reordered variant reproduces the reference's error bound input (out_pt)
+    qd, kd, vd = [x.to(c["dtype"]) for x in (c["q"], c["k"], c["v"])]
+    out_pt, _ = orc.attention_dense_ref(qd, kd, vd, upcast=False, reorder_ops=True)
+    assert abs((out_pt.float() - c["out_ref"]).abs().max().item() - c["pt_maxerr"]) <= 1e-6
+
+
+@pytest.mark.parametrize("name", DENSE_CASES)
+@pytest.mark.parametrize("tiles", [(128, 64), (128, 176)])
+def test_tiled_oracle_dense_matches_reference_outputs(name, tiles):
+    """The tiled C walk with every tile listed equals the reference's eager result (fp32 P: round-off only;
+    bf16 P: inside the reference's own tolerance rule, test_flash_attn.py:296)."""
+    c = load_dense_case(name)
+    bm, bn = tiles
+    o32, lse32, n_tiles = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=bm, block_n=bn, p_round=False)
+    B, Sq = c["q"].shape[:2]
+    Sk, H = c["k"].shape[1], c["q"].shape[2]
+    assert n_tiles == B * H * math.ceil(Sq / bm) * math.ceil(Sk / bn)
+    assert (o32 - c["out_ref"]).abs().max().item() <= 5e-6
+    assert (lse32 - c["lse_ref"]).abs().max().item() <= 2e-5
+    if c["dtype"] == torch.bfloat16:
+        o16, lse16, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=bm, block_n=bn, p_round=True)
+        assert (o16 - c["out_ref"]).abs().max().item() <= ref_tolerance(c["out_ref"], c["pt_maxerr"])
+        assert torch.equal(lse16, lse32)   # row sums use the un-rounded P (softmax.h:271)
+
+
+def _qkv(B=2, S=1000, H=3, D=128, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(B, S, H, D, generator=g).bfloat16() for _ in range(3)]
+
+
+@pytest.mark.parametrize("tiles", [(128, 64), (128, 176)])
+def test_known_answers_of_reference_script(tiles):
+    """K1-K4 of /root/reference/test_lite_attention.py:11-93 on the oracle."""
+    bm, bn = tiles
+    q, k, v = _qkv()
+    B, S, H, _ = q.shape
+    Qt, Kt = math.ceil(S / bm), math.ceil(S / bn)
+    # K1: thr=+inf -> every write row has list[0] <= 2 (exactly [2, Kt-1, Kt-2])
+    sl = orc.init_skip_list_ref(B, Qt, Kt, H)
+    orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=sl[0], write_list=sl[1], thr=float("inf"))
+    assert (sl[1][..., 0] <= 2).all()
+    assert (sl[1][..., 1] == Kt - 1).all() and (sl[1][..., 2] == Kt - 2).all()
+    # K2: thr=+inf, must_do_list=[S-1, 0] -> write == read
+    sl = orc.init_skip_list_ref(B, Qt, Kt, H)
+    md = orc.expand_must_do_ref([S - 1, 0], bn, Kt + 1)
+    orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=sl[0], write_list=sl[1], must_do_list=md, thr=float("inf"))
+    assert torch.equal(sl[0], sl[1])
+    # same with the reference's 4-D expanded must-do tensor
+    sl = orc.init_skip_list_ref(B, Qt, Kt, H)
+    md4 = md.repeat(B, H, Qt, 1).contiguous()
+    orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=sl[0], write_list=sl[1], must_do_list=md4, thr=float("inf"))
+    assert torch.equal(sl[0], sl[1])
+    # K3: thr=-inf -> write == read == init
+    sl = orc.init_skip_list_ref(B, Qt, Kt, H)
+    orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=sl[0], write_list=sl[1], thr=float("-inf"))
+    assert torch.equal(sl[0], sl[1])
+    # K4: thr=0, one call: LSE vs logsumexp, max-abs diff < 0.1 (in fact round-off)
+    sl = orc.init_skip_list_ref(B, Qt, Kt, H)
+    _, lse, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=sl[0], write_list=sl[1], thr=0.0)
+    _, lse_ref = orc.attention_dense_ref(q, k, v)
+    assert (lse - lse_ref).abs().max().item() < 1e-4
+
+
+def test_writer_semantics_examples_from_survey():
+    """SURVEY.md Appendix A.3 consequences, on the pure-Python writer."""
+    Kt = 10
+    row = [2, 9, 0]
+    flags = lambda flagged: [False] + [(n in flagged) for n in range(8, -1, -1)]
+    assert orc.simulate_writer(row, flags({7, 6})) == [4, 9, 7, 5, 0]          # first flagged tile of a run stays
+    assert orc.simulate_writer(row, flags({5})) == [4, 9, 5, 4, 0]             # isolated flagged tile is never dropped...
+    assert orc.walk_tiles([4, 9, 5, 4, 0]) == list(range(9, -1, -1))           # ...the two ranges still cover it
+    assert orc.simulate_writer(row, flags(set(range(9)))) == [2, 9, 8]         # all flagged -> two tiles survive
+    assert orc.simulate_writer(row, flags(set())) == [2, 9, 0]                 # nothing flagged -> unchanged
+    # must-do [start=6 inclusive, end=2 exclusive] keeps tiles 6..3; tile 2, first flagged of the run, stays as inclusive end
+    md = [2, 6, 2]
+    assert orc.simulate_writer(row, flags(set(range(9))), md) == [4, 9, 8, 6, 2]
+    # a range's first tile can be dropped when flagged; lists are a fixed point when flags repeat
+    r2 = [4, 9, 7, 5, 0]
+    f2 = [False, False, False] + [True, False, False, False, False, False]      # tile 5 flagged, 4..0 not
+    assert orc.simulate_writer(r2, f2) == [4, 9, 7, 4, 0]
+
+
+def test_c_writer_equals_python_writer_over_steps():
+    """C oracle walk/writer vs the pure-Python restatement, on lists produced by a multi-step run with
+    structured inputs (real sparsity), including a must-do range."""
+    bm, bn = 128, 64
+    B, S, H, D = 1, 1536, 2, 128
+    q, k, v = structured_qkv(B, S, H, D, seed=5)
+    Qt, Kt = S // bm, S // bn
+    sl = orc.init_skip_list_ref(B, Qt, Kt, H)
+    md = orc.expand_must_do_ref([700, 400], bn, Kt + 1)
+    margins = torch.empty(B, H, Qt, Kt)
+    prev_listed = Qt * Kt * H
+    thr = -4.0
+    for step in range(4):
+        rd, wr = sl[step % 2], sl[(step + 1) % 2]
+        orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=rd, write_list=wr, must_do_list=md, thr=thr,
+                       margins=margins)
+        for h in range(H):
+            for m in range(Qt):
+                row = rd[0, h, m].tolist()
+                tiles = orc.walk_tiles(row)
+                flags = [False] + [bool(margins[0, h, m, n] <= thr) for n in tiles[1:]]
+                exp = orc.simulate_writer(row, flags, md.tolist())
+                got = wr[0, h, m].tolist()
+                assert got[: got[0] + 1] == exp
+                new_tiles = orc.walk_tiles(got)
+                assert set(new_tiles) <= set(tiles)            # monotone: dropped tiles never come back
+                assert new_tiles[0] == Kt - 1                   # the masked first tile is never dropped
+                for n in range(400 // bn + 1, 700 // bn + 1 + 1):   # must-do tiles (start incl., end excl.) stay
+                    if n in tiles and n <= -(-700 // bn) and n > 400 // bn:
+                        assert n in new_tiles
+        listed = orc.listed_tiles(wr)
+        assert listed <= prev_listed
+        prev_listed = listed
+    assert prev_listed < Qt * Kt * H * 0.9, "structured inputs should produce real sparsity"
+
+
+def test_sparse_output_error_is_bounded_by_threshold():
+    """Skipping tiles flagged at threshold thr changes O by O(2^thr): sanity of the error bound."""
+    bm, bn = 128, 64
+    B, S, H, D = 1, 1024, 1, 128
+    q, k, v = structured_qkv(B, S, H, D, seed=9)
+    Qt, Kt = S // bm, S // bn
+    o_dense, _, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn)
+    sl = orc.init_skip_list_ref(B, Qt, Kt, H)
+    thr = -8.0
+    orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=sl[0], write_list=sl[1], thr=thr)
+    o_sparse, _, n_tiles = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=sl[1], write_list=sl[0], thr=thr)
+    assert n_tiles < Qt * Kt
+    # dropped mass per row <= (#dropped keys) * 2^thr relative to the max term
+    assert (o_sparse - o_dense).abs().max().item() < S * 2.0 ** thr * v.float().abs().max().item()
+
+
+def test_empty_key_sequence():
+    """flash_api.cpp:1241-1245: seqlen_k == 0 -> O = 0, LSE = +inf."""
+    q = torch.randn(1, 5, 1, 128)
+    k = torch.zeros(1, 0, 1, 128)
+    o, lse, _ = orc.qkskip_fwd(q, k, k, block_m=128, block_n=64)
+    assert (o == 0).all() and torch.isinf(lse).all() and (lse > 0).all()
+
+
+def test_combine_ref_matches_single_pass():
+    q, k, v = _qkv(B=1, S=512, H=2)
+    o_full, lse_full = orc.attention_dense_ref(q.float(), k.float(), v.float())
+    parts_o, parts_l = [], []
+    for s in range(0, 512, 128):
+        o, l = orc.attention_dense_ref(q.float(), k[:, s:s + 128].float(), v[:, s:s + 128].float())
+        parts_o.append(o)
+        parts_l.append(l.transpose(1, 2))      # (B,S,H) as in test_flash_attn.py:1178-1187
+    o, lse = orc.attention_combine_ref(torch.stack(parts_o), torch.stack(parts_l))
+    assert (o - o_full).abs().max().item() < 1e-5
+    assert (lse.transpose(1, 2) - lse_full).abs().max().item() < 1e-5
