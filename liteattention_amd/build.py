@@ -35,21 +35,32 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into one shared library. Returns its path."""
+def build(force: bool = False, verbose: bool = False, defines=(), out: str = None) -> str:
+    """Compile every HIP source for gfx950 into one shared library. Returns its path.
+    ``defines``/``out`` build an A/B variant (e.g. defines=["LA_NO_SETPRIO"], out="/path/lib_b.so") that
+    LITEATTENTION_AMD_LIB can select; the default build has neither."""
+    if out is not None:
+        return _compile(out, defines, verbose)
     if not force and not is_stale():
         return LIB_PATH
+    return _compile(LIB_PATH, (), verbose)
+
+
+def _compile(lib_path: str, defines, verbose: bool) -> str:
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-I", INCLUDE, "-I", CSRC]
+    cmd += [f"-D{d}" for d in defines]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    tmp = LIB_PATH + ".tmp"
+    tmp = lib_path + ".tmp"
     cmd += ["-o", tmp]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    os.replace(tmp, LIB_PATH)
-    return LIB_PATH
+    os.replace(tmp, lib_path)
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    outs = [a[6:] for a in sys.argv[1:] if a.startswith("--out=")]
+    print(build(force="--force" in sys.argv, verbose=True, defines=defs, out=outs[0] if outs else None))
