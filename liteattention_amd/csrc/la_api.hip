@@ -6,6 +6,7 @@
 // layer turns codes into the reference's exception types.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/lite_attention_amd.h"
 #include "la_kernel_params.h"
@@ -72,6 +73,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
                                a->v_head_stride,  a->o_batch_stride, a->o_row_stride,  a->o_head_stride};
     for (int64_t s : strides)
         if (s % 8 != 0 || s < 0) return LA_ERR_STRIDE;                                   // flash_api.cpp:726-728 (+alignment)
+    if (a->k_row_stride > 0x3fffffff || a->v_row_stride > 0x3fffffff) return LA_ERR_STRIDE;   // byte strides kept in int32
     if (!aligned16(a->q) || !aligned16(a->k) || !aligned16(a->v) || !aligned16(a->o)) return LA_ERR_STRIDE;
 
     if (a->seqlen_k == 0) {
@@ -103,7 +105,11 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     if (la::fwd_lds_bytes(p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
     if (static_cast<int64_t>(p.batch) * p.num_heads * p.q_tiles > 0x7fffffffLL) return LA_ERR_SHAPE;
 
-    const hipError_t err = la::launch_fwd_bf16_d128(p, a->read_list != nullptr, stream);   // is_skipable, flash_api.cpp:931
+    // LA_FWD_KERNEL=v1 selects the register-staged kernel (A/B and fallback); default is the pipelined v2.
+    static const bool use_v1 = [] { const char* e = getenv("LA_FWD_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
+    const bool skipable = a->read_list != nullptr;                                      // is_skipable, flash_api.cpp:931
+    const hipError_t err = use_v1 ? la::launch_fwd_bf16_d128(p, skipable, stream)
+                                  : la::launch_fwd_bf16_d128_v2(p, skipable, stream);
     if (err != hipSuccess) {
         g_last_hip_error = static_cast<int>(err);
         return LA_ERR_LAUNCH;

@@ -1,0 +1,354 @@
+// la_fwd_kernel_v2.hip — software-pipelined QK-Skip attention forward (gfx950, bf16, head_dim 128).
+//
+// Same algorithm, tiles (128 x 64), LDS layout and MFMA mapping as la_fwd_kernel.hip (see its header for
+// the reference lines replaced). What changes is the schedule, driven by the round-1 rocprof evidence
+// (profiles/r01a: MFMA busy 37 %, waves 32 % parked on s_waitcnt/barrier, 27 % issue-stalled):
+//
+//   * K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction). The DMA
+//     image is lane-linear, so the XOR swizzles move to the per-lane SOURCE address. No staging VGPRs
+//     (-32), no ds_write pass, no vmcnt wait in front of it.
+//   * the freed registers hold a second S^T accumulator: QK^T of tile i+1 is issued BEFORE the softmax of
+//     tile i, so a wave's own exp2/max/cvt VALU work runs in the shadow of its own MFMAs (MFMA and VALU
+//     are separate pipes) instead of only in the shadow of the co-resident workgroup's. K therefore runs
+//     one tile ahead of V in LDS (same 64 KiB: K ring and V ring of two tiles each, one barrier per tile).
+//   * the O rescale is skipped — exactly, not approximately — when no row of the wave raised its running
+//     max in this tile (alpha == 1.0f for all 64 lanes): multiplying by 1.0f is the identity in IEEE
+//     arithmetic, so results are bit-identical to the always-rescale schedule.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "la_fwd_common.h"
+
+namespace la {
+
+namespace {
+
+constexpr int D = 128;
+constexpr int BN = 64;
+constexpr int ROW_BYTES = D * 2;                 // 256
+constexpr int TILE_BYTES = BN * ROW_BYTES;       // 16 KiB
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One 1-KiB LDS-DMA piece: every lane moves 16 bytes from its own global address to
+// (wave-uniform LDS base) + lane*16.
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)lds_dst, 16, 0, 0);
+}
+
+}  // namespace
+
+template <bool SKIPABLE>
+__global__ void __launch_bounds__(256, 2)
+la_fwd_bf16_d128_v2_kernel(const FwdParams p) {
+    constexpr int BM = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const k_lds = smem;                        // [2][TILE_BYTES]
+    unsigned char* const v_lds = smem + 2 * TILE_BYTES;       // [2][TILE_BYTES]
+    int* const meta = reinterpret_cast<int*>(smem + 4 * TILE_BYTES);
+    int* const seq = meta + 4;
+    unsigned* const doflags = reinterpret_cast<unsigned*>(seq + p.seq_cap);
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int hh = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int vid = xcd_work_id();
+    const int m_block = vid % p.q_tiles;
+    const int bh = vid / p.q_tiles;
+    const int h = bh % p.num_heads;
+    const int b = bh / p.num_heads;
+    const int k_tiles = p.k_tiles;
+    const int64_t list_off = (static_cast<int64_t>(bh) * p.q_tiles + m_block) * (k_tiles + 1);
+
+    if (SKIPABLE) {
+        for (int i = tid; i < (k_tiles + 31) / 32; i += 256) doflags[i] = 0u;
+        if (wave == 0) {
+            const int n = expand_read_list(p.read_list + list_off, seq, k_tiles, lane);
+            if (lane == 0) meta[0] = n;
+        }
+    }
+
+    // ---- Q fragments (B operand of S^T = K Q^T): query row l31, d = 16*ks + 8*hh + [0,8)
+    const int q_row = m_block * BM + wave * 32 + l31;
+    bf16x8 qf[8];
+    {
+        const uint16_t* qp = p.q + b * p.q_batch_stride + static_cast<int64_t>(q_row) * p.q_row_stride +
+                             h * p.q_head_stride + hh * 8;
+        const bool ok = q_row < p.seqlen_q;   // rows past seqlen_q are ZERO rows (TMA OOB fill in the reference)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            u32x4 t = {0u, 0u, 0u, 0u};
+            if (ok) t = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+            qf[ks] = __builtin_bit_cast(bf16x8, t);
+        }
+    }
+
+    // ---- LDS-DMA addressing. Wave w, piece j (0..3) fills LDS bytes [(4w+j)*1024, +1024) of a tile =
+    // rows 4(4w+j) .. +3; lane: row r = 4(4w+j) + (lane>>4), LDS chunk position c' = lane&15.
+    // The byte image must equal the register-staged kernel's:  K chunk c of row r at c' = c ^ (r&15),
+    // V chunk c at c' = c ^ ((r&3)<<2)  ->  source chunk c = c' ^ swizzle(r).
+    const unsigned char* const kg = reinterpret_cast<const unsigned char*>(p.k + b * p.k_batch_stride + h * p.k_head_stride);
+    const unsigned char* const vg = reinterpret_cast<const unsigned char*>(p.v + b * p.v_batch_stride + h * p.v_head_stride);
+    const int k_rs = static_cast<int>(p.k_row_stride * 2), v_rs = static_cast<int>(p.v_row_stride * 2);   // bytes (< 2^31, checked on the host)
+    const int rip = lane >> 4;                 // row inside a 4-row piece
+    const int cpos = lane & 15;                // 16-byte chunk position inside the LDS row
+    // per-lane byte offsets relative to the piece's first row. K: (cpos ^ ((4j+rip)&15)) = (cpos^rip) ^ 4j
+    const int k_lane = rip * k_rs + ((cpos ^ rip) << 4);     // piece j: xor (j << 6) into the low byte part
+    const int v_lane = rip * v_rs + ((cpos ^ (rip << 2)) << 4);
+    const int last_row = p.seqlen_k - 1;
+    auto dma_tile = [&](int n, int kbuf, bool do_k, int vbuf, bool do_v) {
+        const int row_w = n * BN + 16 * wave;                               // wave-uniform first row of this wave's slice
+        if (__builtin_expect(row_w + 15 <= last_row, 1)) {
+            const unsigned char* kb_ = kg + static_cast<int64_t>(row_w) * k_rs;   // scalar bases
+            const unsigned char* vb_ = vg + static_cast<int64_t>(row_w) * v_rs;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (do_k) dma16(kb_ + j * 4 * k_rs + (k_lane ^ (j << 6)), k_lds + kbuf * TILE_BYTES + (4 * wave + j) * 1024);
+                if (do_v) dma16(vb_ + j * 4 * v_rs + v_lane, v_lds + vbuf * TILE_BYTES + (4 * wave + j) * 1024);
+            }
+        } else {
+            asm volatile("; ragged K/V tail" ::: "memory");                  // keep this a real (rare) branch
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * j + rip;
+                const int grow = min(row_w + r, last_row);                    // rows past seqlen_k: clamp (masked, P = 0)
+                if (do_k) dma16(kg + static_cast<int64_t>(grow) * k_rs + ((cpos ^ (r & 15)) << 4),
+                                k_lds + kbuf * TILE_BYTES + (4 * wave + j) * 1024);
+                if (do_v) dma16(vg + static_cast<int64_t>(grow) * v_rs + ((cpos ^ ((r & 3) << 2)) << 4),
+                                v_lds + vbuf * TILE_BYTES + (4 * wave + j) * 1024);
+            }
+        }
+    };
+
+    __syncthreads();   // seq / meta / doflags visible
+    const int n_tiles = SKIPABLE ? meta[0] : k_tiles;
+    auto tile_at = [&](int i) -> int {
+        const int ii = min(i, n_tiles - 1);
+        return SKIPABLE ? __builtin_amdgcn_readfirstlane(seq[ii]) : (k_tiles - 1 - ii);
+    };
+
+    // prologue: K(0) -> kbuf0, V(0) -> vbuf0, K(1) -> kbuf1
+    dma_tile(tile_at(0), 0, true, 0, true);
+    dma_tile(tile_at(1), 1, true, 0, false);
+    __syncthreads();
+
+    // ---- per-lane LDS read offsets (same as la_fwd_kernel.hip)
+    const int k_rd_row = l31 * ROW_BYTES;
+    const int k_rd_sw = l31 & 15;
+    const int a16 = lane & 15;
+    const int v_key0 = 4 * hh + (a16 >> 2);
+    int v_rd[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+        v_rd[db] = v_key0 * ROW_BYTES + (((db ^ (a16 >> 2)) << 6) | (((lane >> 4) & 1) << 5) | ((a16 & 3) << 3));
+
+    const float c = p.scale_log2;
+    const float thr = p.thr;
+    const int tail_valid = p.seqlen_k - (k_tiles - 1) * BN;   // valid keys in tile k_tiles-1 (1..64)
+    unsigned domask = 1u;                                     // wave-uniform "do" bits of 32 consecutive positions; position 0 is never flagged
+    float l_run = 0.f;
+    f32x16 o_acc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[db][r] = 0.f;
+
+    // S^T[key][q] for one 64-key tile from K buffer `kbuf`
+    auto qk_tile = [&](int kbuf, f32x16 (&s)[2]) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            const unsigned char* kt = k_lds + kbuf * TILE_BYTES + kb * 32 * ROW_BYTES + k_rd_row;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + (((2 * ks + hh) ^ k_rd_sw) << 4));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+            }
+        }
+    };
+
+    // Row max of a score tile + running-max update + skip vote for list position `pos`.
+    // Returns alpha = exp2((m_prev - m_new) * c). `valid` = the tile really is part of the walk.
+    float m_run = -INFINITY;
+    auto stats = [&](f32x16 (&s)[2], int pos, bool valid) -> float {
+        float m_loc = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m_loc = fmaxf(m_loc, s[kb][r]);
+        m_loc = half_swap_max(m_loc);
+        if (!valid) m_loc = -INFINITY;                       // clamped duplicate past the end of the walk: no effect
+        const float m_prev = m_run;
+        m_run = fmaxf(m_prev, m_loc);
+        if (SKIPABLE) {
+            // do_qk |= ((m_loc - m_prev) * c) > thr   (softmax.h:194); wave vote -> one scalar bit per position
+            const bool do_any = __any(((m_loc - m_prev) * c) > thr) && valid;
+            domask |= (do_any ? 1u : 0u) << (pos & 31);
+            if ((pos & 31) == 31 && valid) {
+                if (lane == 0) atomicOr(&doflags[pos >> 5], domask);
+                domask = 0u;
+            }
+        }
+        return fast_exp2((m_prev - m_run) * c);              // first tile: exp2(-inf) = 0
+    };
+    // Seqlen-k mask (mask.h:44-78). As in the reference it is applied to the FIRST walked tile only
+    // (mainloop...:1626): every well-formed list starts with tile k_tiles-1 — init_skip_list, the writer
+    // (position 0 is never dropped) and must_skip_row all guarantee it — and only that tile can be ragged.
+    auto mask_tail = [&](f32x16 (&s)[2], int n) {
+        if (__builtin_expect(n == k_tiles - 1 && tail_valid < BN, 0)) {
+            asm volatile("; seqlen-k mask" ::: "memory");    // a real, rare branch (not 32 selects per tile)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= tail_valid) s[kb][r] = -INFINITY;
+                }
+        }
+    };
+
+    // One pipeline step. On entry: s_cur = raw (masked) scores of tile i, m_run already includes tile i,
+    // `alpha` is tile i's rescale factor and O has already been multiplied by it; V(i) is in vbuf[i&1],
+    // K(i+1) in kbuf[(i+1)&1].
+    float alpha = 0.f;
+    auto step = [&](int i, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2]) {
+        const int cur = i & 1;
+        const bool has_next = (i + 1) < n_tiles;
+        const int n_next = tile_at(i + 1);
+        // stage K(i+2) -> kbuf[cur] (K(i) was consumed by the previous step), V(i+1) -> vbuf[cur^1]
+        dma_tile(tile_at(i + 2), cur, true, 0, false);
+        dma_tile(n_next, 0, false, cur ^ 1, true);
+
+        // ---- phase 1: QK^T of tile i+1 (MFMA)  ||  P = exp2(S*c - m*c), row sum, bf16 P of tile i (VALU)
+        qk_tile(cur ^ 1, s_nxt);
+        const float m_scaled = m_run * c;
+        float psum = 0.f;
+        bf16x8 pf[4];   // B operand of O^T += V^T P^T: k-step kk = accumulator regs 8*(kk&1).. of block kk>>1
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = fast_exp2(__builtin_fmaf(s_cur[kb][r], c, -m_scaled));
+                s_cur[kb][r] = pv;
+                psum += pv;
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f32x8 t;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = s_cur[kb][8 * half + e];
+                pf[2 * kb + half] = __builtin_convertvector(t, bf16x8);
+            }
+        }
+        l_run = l_run * alpha + psum;
+
+        // ---- phase 2: O^T += V^T P^T of tile i (MFMA)  ||  row max / running max / vote of tile i+1 (VALU)
+        const unsigned char* vt = v_lds + cur * TILE_BYTES;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    LDS_PTR(s16x4, vt + v_rd[db] + kk * 16 * ROW_BYTES));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    LDS_PTR(s16x4, vt + v_rd[db] + kk * 16 * ROW_BYTES + 8 * ROW_BYTES));
+                const s16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf[kk],
+                                                                    o_acc[db], 0, 0, 0);
+            }
+        }
+        alpha = stats(s_nxt, i + 1, has_next);
+
+        // ---- O^T *= alpha(i+1), after PV(i). Identity (bit-exact) when alpha == 1 on every lane.
+        if (!__all(alpha == 1.0f)) {
+            float a_in = alpha;
+            asm volatile("; rescale O" : "+v"(a_in));           // value defined inside the branch: the multiplies cannot be speculated
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o_acc[db][r] *= a_in;
+        }
+        __syncthreads();   // all waves done with K(i+1)/V(i) of this step; this step's DMA has landed
+    };
+
+    f32x16 s_a[2], s_b[2];
+    {
+        const int n0 = tile_at(0);
+        qk_tile(0, s_a);
+        mask_tail(s_a, n0);
+        domask = 0u;
+        (void)stats(s_a, 0, true);
+        domask |= 1u;                                        // the first walked tile is never flagged (softmax.h:153)
+        alpha = 0.f;                                         // O = 0, l = 0
+    }
+    __syncthreads();   // every wave has read K(0) before step 0 re-fills kbuf0 with K(2)
+    int i = 0;
+    for (; i + 1 < n_tiles; i += 2) {
+        step(i, s_a, s_b);
+        step(i + 1, s_b, s_a);
+    }
+    if (i < n_tiles) step(i, s_a, s_b);
+    if (SKIPABLE) {
+        if ((n_tiles & 31) != 0 && lane == 0) atomicOr(&doflags[(n_tiles - 1) >> 5], domask);
+        __syncthreads();
+    }
+
+    // ---- finalize (softmax.h:275-296) and store (epilogue_fwd.hpp:214-403)
+    const float l_tot = half_swap_sum(l_run);
+    const bool bad = (l_tot == 0.f) || (l_tot != l_tot);
+    const float inv = bad ? 0.f : 1.f / l_tot;
+    if (q_row < p.seqlen_q) {
+        uint16_t* op = p.o + b * p.o_batch_stride + static_cast<int64_t>(q_row) * p.o_row_stride + h * p.o_head_stride;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                f32x4 x = {o_acc[db][4 * t] * inv, o_acc[db][4 * t + 1] * inv, o_acc[db][4 * t + 2] * inv,
+                           o_acc[db][4 * t + 3] * inv};
+                *reinterpret_cast<bf16x4*>(op + 32 * db + 8 * t + 4 * hh) = __builtin_convertvector(x, bf16x4);
+            }
+        }
+        if (p.lse != nullptr && hh == 0) {
+            p.lse[static_cast<int64_t>(bh) * p.seqlen_q + q_row] =
+                bad ? -INFINITY : m_run * (c * 0.69314718055994530942f) + __logf(l_tot);
+        }
+    }
+
+    if (SKIPABLE) {
+        if (tid == 0 && p.write_list != nullptr) {
+            const int* md = p.must_do_list ? (p.must_do_is_1d ? p.must_do_list : p.must_do_list + list_off) : nullptr;
+            write_skip_list(p.read_list + list_off, p.write_list + list_off, md, doflags, k_tiles);
+        }
+    }
+}
+
+hipError_t launch_fwd_bf16_d128_v2(const FwdParams& p, bool skipable, hipStream_t stream) {
+    const int total = p.batch * p.num_heads * p.q_tiles;
+    FwdParams pp = p;
+    const size_t lds = fwd_lds_bytes(p.k_tiles, &pp.seq_cap);
+    hipError_t err;
+    (void)hipGetLastError();
+    if (skipable) {
+        auto kfn = la_fwd_bf16_d128_v2_kernel<true>;
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds));
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(kfn, dim3(total), dim3(256), lds, stream, pp);
+    } else {
+        auto kfn = la_fwd_bf16_d128_v2_kernel<false>;
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds));
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(kfn, dim3(total), dim3(256), lds, stream, pp);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace la
