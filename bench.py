@@ -114,12 +114,19 @@ def cpu_baseline(S, D, bm, bn, rows, target_seconds=15.0):
         return dt, tiles * 4.0 * bm * bn * D
 
     dt, fl = run(threads)                       # probe: one q-tile per thread
-    rate = fl / dt
-    n_qt = int(max(threads, min(rows.shape[0], target_seconds * rate / (fl / threads))))
-    n_qt = (n_qt // threads) * threads
-    dt, fl = run(n_qt)
+    n_qt = threads
+    for _ in range(3):                          # grow the sample until it is a 10-30 s measurement
+        if dt >= 10.0 or n_qt >= rows.shape[0]:
+            break
+        n_qt = int(min(rows.shape[0], max(n_qt + threads, n_qt * min(8.0, target_seconds / max(dt, 1e-3)))))
+        n_qt = max(threads, (n_qt // threads) * threads)
+        dt, fl = run(n_qt)
+    reps = 1
+    while dt < 10.0 and reps < 8:               # many-core hosts finish one head quickly: repeat the sample
+        d2, f2 = run(n_qt)
+        dt, fl, reps = dt + d2, fl + f2, reps + 1
     return {"value": round(fl / dt / 1e12, 5), "unit": "TFLOP/s", "cores": threads, "kind": "port",
-            "sample": f"1 head x {n_qt} q-tiles ({n_qt * bm} query rows) x all {S} keys at the 42% list, "
+            "sample": f"{reps} x [1 head x {n_qt} q-tiles ({n_qt * bm} query rows) x all {S} keys at the 42% list], "
                       f"{fl / 1e9:.1f} GFLOP in {dt:.1f} s (oracle/qkskip_oracle.c, OpenMP)"}
 
 
@@ -222,7 +229,7 @@ def main():
                      "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(flops_rank / kern_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                      "traffic": None,
-                     "kernel": "la_fwd_bf16_d128_kernel<4,true>", "kernel_ms": round(kern_s * 1e3, 3),
+                     "kernel": "la_fwd_bf16_d128_v2_kernel<true>", "kernel_ms": round(kern_s * 1e3, 3),
                      "algorithmic_tflop_per_launch": round(flops_rank / 1e12, 3)},
     }
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
