@@ -12,6 +12,10 @@ _cabi.load()   # fail loudly, at import, when libliteattention_amd.so is absent 
 from .flash_attn_interface import (flash_attn_combine, flash_attn_func, get_tile_sizes,  # noqa: E402
                                    skip_list_stats)
 from .lite_attention import LiteAttention, SeqParallelLiteAttention  # noqa: E402
+from .compat import (blockmask_to_skip_lists, fa2_flash_attn_func, flash_attn_varlen_func,  # noqa: E402
+                     flash_blocksparse_attn_func)
+from .calibration import calibrate_threshold  # noqa: E402
 
 __all__ = ["LiteAttention", "SeqParallelLiteAttention", "flash_attn_func", "flash_attn_combine",
-           "get_tile_sizes", "skip_list_stats", "__version__"]
+           "get_tile_sizes", "skip_list_stats", "fa2_flash_attn_func", "flash_attn_varlen_func",
+           "flash_blocksparse_attn_func", "blockmask_to_skip_lists", "calibrate_threshold", "__version__"]
