@@ -45,72 +45,88 @@ struct ListReader {
     __device__ bool has_more() const { return idx <= len; }
 };
 
-__device__ __noinline__ void write_skip_list(const int* __restrict__ read_row, int* __restrict__ write_row,
-                                             const int* __restrict__ must_do_row, const unsigned* doflags,
-                                             int k_tiles) {
-    ListReader rd, md;
-    rd.init(read_row);
+// Runs on ONE lane in the epilogue, entirely from LDS: the walked tile sequence `seq`, the range-end markers
+// `endflags` (bit p set = position p is the last tile of its read-list range) and the vote bits `doflags` (bit p
+// set = some row of the q-tile voted "do" for position p). No global loads of the read list: real lists hold
+// hundreds of ranges per row and two dependent global loads per range cost more than the tiles they describe.
+__device__ __noinline__ void write_skip_list(const int* seq, const unsigned* endflags, const unsigned* doflags,
+                                             int n_tiles, int* __restrict__ write_row,
+                                             const int* __restrict__ must_do_row, int k_tiles) {
+    ListReader md;
     const bool has_md = must_do_row != nullptr;
     if (has_md) md.init(must_do_row);
     int w = 1;
     bool is_skipping = true;
-    auto transition = [&](bool skip, int n, bool use_md) {
-        if (use_md && skip) {
+    for (int pos = 0; pos < n_tiles; ++pos) {
+        const int n = seq[pos];
+        // fwd_step's raw flag; the first walked tile is recorded with skip = false and no must-do (:1804-1805)
+        const bool raw_skip = pos != 0 && !((doflags[pos >> 5] >> (pos & 31)) & 1u);
+        bool skip = raw_skip;
+        if (has_md && skip) {                                            // record_transition :154-162
             if (md.end > n && md.has_more()) { md.advance(); md.load(); }
             const bool must_do = n <= md.start && n > md.end;
             skip = skip && !must_do;
         }
-        if (skip != is_skipping) {
+        if (skip != is_skipping) {                                       // :163-168
             if (w <= k_tiles) write_row[w] = n;
             ++w;
             is_skipping = skip;
         }
-    };
-    int pos = 0;
-    int n = min(max(rd.start, 0), k_tiles - 1);
-    bool skip = false;
-    transition(false, n, false);
-    --n; ++pos;
-    for (;;) {
-        const int end = min(max(rd.end, 0), k_tiles - 1);
-        for (; n >= end && pos < k_tiles; --n, ++pos) {
-            skip = !((doflags[pos >> 5] >> (pos & 31)) & 1u);
-            transition(skip, n, has_md);
+        if ((endflags[pos >> 5] >> (pos & 31)) & 1u) {                   // record_range_end :173-181 (raw flag)
+            is_skipping = true;
+            if (!raw_skip) { if (w <= k_tiles) write_row[w] = n; ++w; }
         }
-        // record_range_end (:173-181)
-        is_skipping = true;
-        if (!skip) { if (w <= k_tiles) write_row[w] = end; ++w; }
-        rd.advance();
-        if (!rd.has_more()) break;
-        rd.load();
-        n = min(max(rd.start, 0), k_tiles - 1);
     }
-    write_row[0] = min(w - 1, k_tiles);
+    write_row[0] = min(w - 1, k_tiles);                                  // finalize :185-191
 }
 
-
-// XCD-aware (bijective) block -> virtual work id: blocks b%8 share an XCD/L2, so each XCD gets a contiguous
-// run of q-tiles of the same head (they stream the same K/V tiles in the same order).
+// XCD-aware (bijective) block -> virtual work id. Blocks b%8 share an XCD/L2 (observed dispatch rule; used for
+// speed only). Work is dealt to the XCDs in CHUNKS of 64 consecutive q-tiles of one head: 64 = the workgroups
+// co-resident on one XCD (32 CUs x 2), so the co-resident set streams the same K/V tiles in the same order and
+// K/V is read from HBM about once per chunk. Chunks go round-robin over the XCDs (chunk j -> XCD j%8), so every
+// XCD sees every head: with real skip lists heads differ in sparsity, and one contiguous slab of heads per XCD
+// (the first version of this map) left the kernel waiting for the XCD that drew the densest heads.
 __device__ __forceinline__ int xcd_work_id() {
+    constexpr int C = 64;
     const int bid = blockIdx.x, nwg = gridDim.x;
+    const int full = (nwg / (8 * C)) * (8 * C);
+    if (bid >= full) return bid;                       // ragged tail: identity (still a bijection)
     const int xcd = bid & 7, idx = bid >> 3;
-    const int q8 = nwg >> 3, r8 = nwg & 7;
-    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    return ((idx / C) * 8 + xcd) * C + (idx % C);
 }
 
-// Expand one read-list row into the LDS tile sequence (one wave). Returns the number of tiles (lane-uniform).
-// The first range is walked even when len == 0 (mainloop...:93-101). Indices are clamped to [0, k_tiles).
-__device__ __forceinline__ int expand_read_list(const int* __restrict__ row, int* seq, int k_tiles, int lane) {
-    const int len = row[0];
-    int idx = 1, pos = 0;
-    do {
-        const int start = min(max(row[idx], 0), k_tiles - 1);
-        const int end = min(max(row[idx + 1], 0), k_tiles - 1);
-        const int cnt = min(start - end + 1, k_tiles - pos);
-        for (int j = lane; j < cnt; j += 64) seq[pos + j] = start - j;
-        pos += max(cnt, 0);
-        idx += 2;
-    } while (idx <= len);
+// Expand one read-list row into the LDS tile sequence (one wave, 64 ranges per pass). Returns the number of
+// tiles (wave-uniform). Real lists hold hundreds of short ranges per row, so the ranges are handled in parallel:
+// lane r takes range 64*pass + r, an exclusive wave scan of the range sizes gives its first position, then every
+// lane writes its own tiles. The first range is walked even when len == 0 (mainloop...:93-101); indices are
+// clamped to [0, k_tiles) and the total to k_tiles (memory safety on malformed lists). `endflags` (zeroed by the
+// caller) gets one bit per range end.
+__device__ __forceinline__ int expand_read_list(const int* __restrict__ row, int* seq, unsigned* endflags, int k_tiles,
+                                                int lane) {
+    const int len = max(row[0], 2);
+    const int n_ranges = min(len >> 1, (k_tiles + 1) >> 1);
+    int pos = 0;
+    for (int base = 0; base < n_ranges; base += 64) {
+        const int r = base + lane;
+        int start = 0, cnt = 0;
+        if (r < n_ranges) {
+            start = min(max(row[1 + 2 * r], 0), k_tiles - 1);
+            const int end = min(max(row[2 + 2 * r], 0), k_tiles - 1);
+            cnt = max(start - end + 1, 0);
+        }
+        int incl = cnt;                                       // inclusive scan over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        const int first = pos + incl - cnt;
+        const int room = max(k_tiles - first, 0);
+        cnt = min(cnt, room);
+        for (int j = 0; j < cnt; ++j) seq[first + j] = start - j;
+        if (cnt > 0) atomicOr(&endflags[(first + cnt - 1) >> 5], 1u << ((first + cnt - 1) & 31));
+        pos = min(pos + __shfl(incl, 63), k_tiles);
+    }
     return pos;
 }
 

@@ -52,6 +52,7 @@ la_fwd_bf16_d128_kernel(const FwdParams p) {
     int* const meta = reinterpret_cast<int*>(smem + 4 * TILE_BYTES);  // [4]: n_tiles
     int* const seq = meta + 4;                                // [k_tiles] tile index per position
     unsigned* const doflags = reinterpret_cast<unsigned*>(seq + p.seq_cap);  // [(k_tiles+31)/32]
+    unsigned* const endflags = doflags + (p.k_tiles + 31) / 32;               // [(k_tiles+31)/32]
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -78,20 +79,11 @@ la_fwd_bf16_d128_kernel(const FwdParams p) {
 
     // ---- expand the read list into the LDS tile sequence (wave 0), clear the vote bits
     if (SKIPABLE) {
-        for (int i = tid; i < (k_tiles + 31) / 32; i += NT) doflags[i] = 0u;
+        for (int i = tid; i < 2 * ((k_tiles + 31) / 32); i += NT) doflags[i] = 0u;   // doflags + endflags
+        __syncthreads();
         if (wave == 0) {
-            const int* row = p.read_list + list_off;
-            const int len = row[0];
-            int idx = 1, pos = 0;
-            do {  // the first range is walked even when len == 0 (mainloop...:93-101)
-                int start = min(max(row[idx], 0), k_tiles - 1);
-                int end = min(max(row[idx + 1], 0), k_tiles - 1);
-                int cnt = min(start - end + 1, k_tiles - pos);
-                for (int j = lane; j < cnt; j += 64) seq[pos + j] = start - j;
-                pos += max(cnt, 0);
-                idx += 2;
-            } while (idx <= len);
-            if (lane == 0) meta[0] = pos;
+            const int n = expand_read_list(p.read_list + list_off, seq, endflags, k_tiles, lane);
+            if (lane == 0) meta[0] = n;
         }
     }
 
@@ -298,7 +290,7 @@ la_fwd_bf16_d128_kernel(const FwdParams p) {
     if (SKIPABLE) {
         if (tid == 0 && p.write_list != nullptr) {
             const int* md = p.must_do_list ? (p.must_do_is_1d ? p.must_do_list : p.must_do_list + list_off) : nullptr;
-            write_skip_list(p.read_list + list_off, p.write_list + list_off, md, doflags, k_tiles);
+            write_skip_list(seq, endflags, doflags, n_tiles, p.write_list + list_off, md, k_tiles);
         }
     }
 }
@@ -309,7 +301,7 @@ la_fwd_bf16_d128_kernel(const FwdParams p) {
 size_t fwd_lds_bytes(int k_tiles, int* seq_cap_out) {
     const int seq_cap = (k_tiles + 3) & ~3;
     if (seq_cap_out) *seq_cap_out = seq_cap;
-    return 4 * 16384 + 16 + static_cast<size_t>(seq_cap) * 4 + static_cast<size_t>((k_tiles + 31) / 32) * 4 + 16;
+    return 4 * 16384 + 16 + static_cast<size_t>(seq_cap) * 4 + 2 * static_cast<size_t>((k_tiles + 31) / 32) * 4 + 16;
 }
 
 hipError_t launch_fwd_bf16_d128(const FwdParams& p, bool skipable, hipStream_t stream) {

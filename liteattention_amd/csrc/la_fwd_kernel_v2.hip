@@ -49,6 +49,7 @@ la_fwd_bf16_d128_v2_kernel(const FwdParams p) {
     int* const meta = reinterpret_cast<int*>(smem + 4 * TILE_BYTES);
     int* const seq = meta + 4;
     unsigned* const doflags = reinterpret_cast<unsigned*>(seq + p.seq_cap);
+    unsigned* const endflags = doflags + (p.k_tiles + 31) / 32;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -65,9 +66,10 @@ la_fwd_bf16_d128_v2_kernel(const FwdParams p) {
     const int64_t list_off = (static_cast<int64_t>(bh) * p.q_tiles + m_block) * (k_tiles + 1);
 
     if (SKIPABLE) {
-        for (int i = tid; i < (k_tiles + 31) / 32; i += 256) doflags[i] = 0u;
+        for (int i = tid; i < 2 * ((k_tiles + 31) / 32); i += 256) doflags[i] = 0u;   // doflags + endflags
+        __syncthreads();
         if (wave == 0) {
-            const int n = expand_read_list(p.read_list + list_off, seq, k_tiles, lane);
+            const int n = expand_read_list(p.read_list + list_off, seq, endflags, k_tiles, lane);
             if (lane == 0) meta[0] = n;
         }
     }
@@ -324,7 +326,7 @@ la_fwd_bf16_d128_v2_kernel(const FwdParams p) {
     if (SKIPABLE) {
         if (tid == 0 && p.write_list != nullptr) {
             const int* md = p.must_do_list ? (p.must_do_is_1d ? p.must_do_list : p.must_do_list + list_off) : nullptr;
-            write_skip_list(p.read_list + list_off, p.write_list + list_off, md, doflags, k_tiles);
+            write_skip_list(seq, endflags, doflags, n_tiles, p.write_list + list_off, md, k_tiles);
         }
     }
 }
