@@ -108,8 +108,11 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     // LA_FWD_KERNEL=v1 selects the register-staged kernel (A/B and fallback); default is the pipelined v2.
     static const bool use_v1 = [] { const char* e = getenv("LA_FWD_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
     const bool skipable = a->read_list != nullptr;                                      // is_skipable, flash_api.cpp:931
-    const hipError_t err = use_v1 ? la::launch_fwd_bf16_d128(p, skipable, stream)
-                                  : la::launch_fwd_bf16_d128_v2(p, skipable, stream);
+    static const bool use_w8 = [] { const char* e = getenv("LA_FWD_KERNEL"); return e && e[0] == 'w' && e[1] == '8'; }();
+    const bool w8_fits = la::fwd_w8_lds_bytes(p.k_tiles, nullptr) <= 160 * 1024;
+    const hipError_t err = (use_w8 && w8_fits) ? la::launch_fwd_bf16_d128_w8(p, skipable, stream)
+                           : use_v1            ? la::launch_fwd_bf16_d128(p, skipable, stream)
+                                               : la::launch_fwd_bf16_d128_v2(p, skipable, stream);
     if (err != hipSuccess) {
         g_last_hip_error = static_cast<int>(err);
         return LA_ERR_LAUNCH;

@@ -80,14 +80,69 @@ __device__ __noinline__ void write_skip_list(const int* seq, const unsigned* end
     write_row[0] = min(w - 1, k_tiles);                                  // finalize :185-191
 }
 
+// Wave-parallel form of write_skip_list (same inputs, run by all 64 lanes of ONE wave). Lane l takes position
+// base + l: with skip(p) the must-do-adjusted flag and raw(p) the raw one, the serial writer emits
+//     n(p)   if skip(p) != (p is the first position of its range ? true : skip(p-1))       (record_transition)
+//     n(p)   if p is the last position of its range and !raw(p)                             (record_range_end)
+// in that order; entry slots come from a wave prefix sum. The must-do reader of the reference is stateful (it
+// advances at most one range per flagged tile, mainloop...:156-159), but for lists of at most ONE range - the
+// default [0,0] and the single-range case - membership reduces to `n <= start && n > end` whatever the reader
+// state; longer must-do lists take the serial path, which reproduces the state machine literally.
+__device__ __forceinline__ void write_skip_list_wave(const int* seq, const unsigned* endflags, const unsigned* doflags,
+                                                     int n_tiles, int* __restrict__ write_row,
+                                                     const int* __restrict__ must_do_row, int k_tiles, int lane) {
+    int md_start = 0, md_end = 0;
+    if (must_do_row != nullptr) {
+        if (must_do_row[0] > 2) {                                         // multi-range must-do: literal state machine
+            if (lane == 0) write_skip_list(seq, endflags, doflags, n_tiles, write_row, must_do_row, k_tiles);
+            return;
+        }
+        md_start = must_do_row[1];
+        md_end = must_do_row[2];
+    }
+    int w = 1;                  // next free entry slot (wave-uniform)
+    int carry_skip = 1;         // "is_skipping" entering the chunk: true at the very start (:125)
+    for (int base = 0; base < n_tiles; base += 64) {
+        const int pos = base + lane;
+        const bool live = pos < n_tiles;
+        int n = 0;
+        bool raw = false, is_end = false;
+        if (live) {
+            n = seq[pos];
+            raw = pos != 0 && !((doflags[pos >> 5] >> (pos & 31)) & 1u);
+            is_end = (endflags[pos >> 5] >> (pos & 31)) & 1u;
+        }
+        const bool skip = raw && !(n <= md_start && n > md_end);
+        // state left behind by this position: forced to "skipping" after a range end
+        const int after = (is_end || skip) ? 1 : 0;
+        int before = __shfl_up(after, 1);
+        if (lane == 0) before = carry_skip;
+        const int e1 = live && (static_cast<int>(skip) != before);
+        const int e2 = live && is_end && !raw;
+        const int cnt = e1 + e2;
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        int slot = w + incl - cnt;
+        if (e1) { if (slot <= k_tiles) write_row[slot] = n; ++slot; }
+        if (e2) { if (slot <= k_tiles) write_row[slot] = n; }
+        w += __shfl(incl, 63);
+        carry_skip = __shfl(after, 63);
+    }
+    if (lane == 0) write_row[0] = min(w - 1, k_tiles);
+}
+
 // XCD-aware (bijective) block -> virtual work id. Blocks b%8 share an XCD/L2 (observed dispatch rule; used for
 // speed only). Work is dealt to the XCDs in CHUNKS of 64 consecutive q-tiles of one head: 64 = the workgroups
 // co-resident on one XCD (32 CUs x 2), so the co-resident set streams the same K/V tiles in the same order and
 // K/V is read from HBM about once per chunk. Chunks go round-robin over the XCDs (chunk j -> XCD j%8), so every
 // XCD sees every head: with real skip lists heads differ in sparsity, and one contiguous slab of heads per XCD
 // (the first version of this map) left the kernel waiting for the XCD that drew the densest heads.
+template <int C = 64>
 __device__ __forceinline__ int xcd_work_id() {
-    constexpr int C = 64;
     const int bid = blockIdx.x, nwg = gridDim.x;
     const int full = (nwg / (8 * C)) * (8 * C);
     if (bid >= full) return bid;                       // ragged tail: identity (still a bijection)

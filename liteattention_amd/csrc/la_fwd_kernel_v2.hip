@@ -324,9 +324,11 @@ la_fwd_bf16_d128_v2_kernel(const FwdParams p) {
     }
 
     if (SKIPABLE) {
-        if (tid == 0 && p.write_list != nullptr) {
+        if (wave == 0 && p.write_list != nullptr) {
             const int* md = p.must_do_list ? (p.must_do_is_1d ? p.must_do_list : p.must_do_list + list_off) : nullptr;
-            write_skip_list(seq, endflags, doflags, n_tiles, p.write_list + list_off, md, k_tiles);
+#ifndef LA_ABL_NOWRITER
+            write_skip_list_wave(seq, endflags, doflags, n_tiles, p.write_list + list_off, md, k_tiles, lane);
+#endif
         }
     }
 }

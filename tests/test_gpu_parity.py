@@ -176,7 +176,7 @@ def _compare_lists(orc, rd_cpu, wr_gpu_cpu, wr_orc, margins, thr, B):
 
 
 @pytest.mark.parametrize("thr", [-2.0, -6.0])
-@pytest.mark.parametrize("use_must_do", [False, True])
+@pytest.mark.parametrize("use_must_do", [False, True, "two_ranges"])
 def test_multi_step_lists_match_oracle(thr, use_must_do):
     """5 denoising-like steps with slowly varying structured inputs. At every step the oracle gets the
     SAME read list as the kernel; write lists must be identical, outputs within the oracle tolerance."""
@@ -184,7 +184,8 @@ def test_multi_step_lists_match_oracle(thr, use_must_do):
     B, S, H = 2, 1536, 2
     Qt, Kt = S // BM, S // BN
     att = L.LiteAttention(threshold=thr, max_batch_size=B)
-    must_do = [700, 400] if use_must_do else None
+    # one range -> wave-parallel writer; two ranges -> the literal (stateful) must-do reader path
+    must_do = [1300, 1100, 700, 400] if use_must_do == "two_ranges" else ([700, 400] if use_must_do else None)
     md_row = orc.expand_must_do_ref(must_do if use_must_do else [0, 0], BN, Kt + 1)
     margins = torch.empty(B, H, Qt, Kt)
     total_border = 0
