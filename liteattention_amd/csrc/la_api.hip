@@ -30,7 +30,7 @@ const char* la_status_string(int status) {
         case LA_ERR_NULL_ARG: return "required pointer is NULL";
         case LA_ERR_STRUCT_SIZE: return "la_fwd_args.struct_size mismatch (ABI version skew)";
         case LA_ERR_DTYPE: return "FlashAttention only supports fp16, bf16, and fp8_e4m3 type; this build instantiates bf16";
-        case LA_ERR_HEAD_DIM: return "head_size not instantiated in this build (bf16: 128)";
+        case LA_ERR_HEAD_DIM: return "head_size not instantiated in this build (bf16: 64, 128)";
         case LA_ERR_SHAPE: return "invalid shape (sizes must be positive; number of heads in key/value must divide number of heads in query)";
         case LA_ERR_STRIDE: return "Input tensor must have contiguous last dimension and 16-byte aligned rows";
         case LA_ERR_TILE_MISMATCH: return "block_m/block_n do not match la_get_tile_sizes(): skip lists would be mis-indexed";
@@ -102,17 +102,18 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     p.must_do_list = a->must_do_list;
     p.must_do_is_1d = a->must_do_is_1d;
 
-    if (la::fwd_lds_bytes(p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
+    if (la::fwd_lds_bytes_v2(a->head_dim, p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
     if (static_cast<int64_t>(p.batch) * p.num_heads * p.q_tiles > 0x7fffffffLL) return LA_ERR_SHAPE;
 
     // LA_FWD_KERNEL=v1 selects the register-staged kernel (A/B and fallback); default is the pipelined v2.
     static const bool use_v1 = [] { const char* e = getenv("LA_FWD_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
     const bool skipable = a->read_list != nullptr;                                      // is_skipable, flash_api.cpp:931
     static const bool use_w8 = [] { const char* e = getenv("LA_FWD_KERNEL"); return e && e[0] == 'w' && e[1] == '8'; }();
+    const bool d128 = a->head_dim == 128;                                               // v1 / w8 are head_dim-128 only
     const bool w8_fits = la::fwd_w8_lds_bytes(p.k_tiles, nullptr) <= 160 * 1024;
-    const hipError_t err = (use_w8 && w8_fits) ? la::launch_fwd_bf16_d128_w8(p, skipable, stream)
-                           : use_v1            ? la::launch_fwd_bf16_d128(p, skipable, stream)
-                                               : la::launch_fwd_bf16_d128_v2(p, skipable, stream);
+    const hipError_t err = (use_w8 && d128 && w8_fits) ? la::launch_fwd_bf16_d128_w8(p, skipable, stream)
+                           : (use_v1 && d128)          ? la::launch_fwd_bf16_d128(p, skipable, stream)
+                                                       : la::launch_fwd_bf16_v2(p, a->head_dim, skipable, stream);
     if (err != hipSuccess) {
         g_last_hip_error = static_cast<int>(err);
         return LA_ERR_LAUNCH;

@@ -1,4 +1,4 @@
-// la_fwd_kernel_v2.hip — software-pipelined QK-Skip attention forward (gfx950, bf16, head_dim 128).
+// la_fwd_kernel_v2.hip — software-pipelined QK-Skip attention forward (gfx950, bf16, head_dim 128 and 64).
 //
 // Same algorithm, tiles (128 x 64), LDS layout and MFMA mapping as la_fwd_kernel.hip (see its header for
 // the reference lines replaced). What changes is the schedule, driven by the round-1 rocprof evidence
@@ -23,10 +23,17 @@ namespace la {
 
 namespace {
 
-constexpr int D = 128;
-constexpr int BN = 64;
-constexpr int ROW_BYTES = D * 2;                 // 256
-constexpr int TILE_BYTES = BN * ROW_BYTES;       // 16 KiB
+constexpr int BN = 64;                           // keys per tile
+
+// LDS swizzles (in 16-byte chunks of a row of 2*D bytes), chosen per head_dim so that the fragment reads are
+// bank-conflict free:
+//   K, read with ds_read_b128 by 16-lane groups of distinct rows:  D=128: chunk ^ (row & 15)   (16 chunks/row)
+//                                                                  D=64 : chunk ^ ((row>>1) & 7) (8 chunks/row,
+//                                                                         two rows per 256-byte bank row)
+//   V, read with ds_read_b64_tr_b16 by 32-lane groups covering 4 keys x 64 bytes: the 64-byte segment index is
+//      XOR-ed with  D=128: key & 3  (4 segments/row),  D=64: (key>>1) & 1  (2 segments/row).
+template <int D> __device__ __forceinline__ constexpr int k_swz(int row) { return D == 128 ? (row & 15) : ((row >> 1) & 7); }
+template <int D> __device__ __forceinline__ constexpr int v_swz(int row) { return D == 128 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2); }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -39,10 +46,17 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
 
 }  // namespace
 
-template <bool SKIPABLE>
+template <int D, bool SKIPABLE>
 __global__ void __launch_bounds__(256, 2)
-la_fwd_bf16_d128_v2_kernel(const FwdParams p) {
+la_fwd_bf16_v2_kernel(const FwdParams p) {
     constexpr int BM = 128;
+    constexpr int ROW_BYTES = D * 2;                 // 256 / 128
+    constexpr int TILE_BYTES = BN * ROW_BYTES;       // 16 / 8 KiB
+    constexpr int KS = D / 16;                       // k-steps of QK^T
+    constexpr int DB = D / 32;                       // 32-wide d blocks of O^T
+    constexpr int CPR = ROW_BYTES / 16;              // 16-byte chunks per row
+    constexpr int RPP = 1024 / ROW_BYTES;            // rows per 1-KiB DMA piece
+    constexpr int PPW = TILE_BYTES / 1024 / 4;       // DMA pieces per wave per tile (each wave stages 16 rows)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const k_lds = smem;                        // [2][TILE_BYTES]
     unsigned char* const v_lds = smem + 2 * TILE_BYTES;       // [2][TILE_BYTES]
@@ -76,31 +90,32 @@ la_fwd_bf16_d128_v2_kernel(const FwdParams p) {
 
     // ---- Q fragments (B operand of S^T = K Q^T): query row l31, d = 16*ks + 8*hh + [0,8)
     const int q_row = m_block * BM + wave * 32 + l31;
-    bf16x8 qf[8];
+    bf16x8 qf[KS];
     {
         const uint16_t* qp = p.q + b * p.q_batch_stride + static_cast<int64_t>(q_row) * p.q_row_stride +
                              h * p.q_head_stride + hh * 8;
         const bool ok = q_row < p.seqlen_q;   // rows past seqlen_q are ZERO rows (TMA OOB fill in the reference)
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             u32x4 t = {0u, 0u, 0u, 0u};
             if (ok) t = *reinterpret_cast<const u32x4*>(qp + ks * 16);
             qf[ks] = __builtin_bit_cast(bf16x8, t);
         }
     }
 
-    // ---- LDS-DMA addressing. Wave w, piece j (0..3) fills LDS bytes [(4w+j)*1024, +1024) of a tile =
-    // rows 4(4w+j) .. +3; lane: row r = 4(4w+j) + (lane>>4), LDS chunk position c' = lane&15.
-    // The byte image must equal the register-staged kernel's:  K chunk c of row r at c' = c ^ (r&15),
-    // V chunk c at c' = c ^ ((r&3)<<2)  ->  source chunk c = c' ^ swizzle(r).
+    // ---- LDS-DMA addressing. A tile is TILE_BYTES/1024 pieces of 1 KiB (RPP rows each); wave w stages rows
+    // 16w .. 16w+15 = pieces PPW*w .. PPW*w+PPW-1. Lane: row rip = lane / CPR inside the piece, LDS chunk
+    // position cpos = lane % CPR. The DMA image is lane-linear, so the swizzles go on the SOURCE address:
+    // LDS position c' of row r holds data chunk c' ^ swz(r).
     const unsigned char* const kg = reinterpret_cast<const unsigned char*>(p.k + b * p.k_batch_stride + h * p.k_head_stride);
     const unsigned char* const vg = reinterpret_cast<const unsigned char*>(p.v + b * p.v_batch_stride + h * p.v_head_stride);
     const int k_rs = static_cast<int>(p.k_row_stride * 2), v_rs = static_cast<int>(p.v_row_stride * 2);   // bytes (< 2^31, checked on the host)
-    const int rip = lane >> 4;                 // row inside a 4-row piece
-    const int cpos = lane & 15;                // 16-byte chunk position inside the LDS row
-    // per-lane byte offsets relative to the piece's first row. K: (cpos ^ ((4j+rip)&15)) = (cpos^rip) ^ 4j
-    const int k_lane = rip * k_rs + ((cpos ^ rip) << 4);     // piece j: xor (j << 6) into the low byte part
-    const int v_lane = rip * v_rs + ((cpos ^ (rip << 2)) << 4);
+    const int rip = lane / CPR;
+    const int cpos = lane % CPR;
+    // K: swz(RPP*j + rip) = swz(rip) ^ 4j for both head dims (RPP*j only touches bits the swizzle maps to 4j),
+    // so piece j XORs (4j << 4) into the byte offset; V: swz(RPP*j + rip) = swz(rip).
+    const int k_lane = rip * k_rs + ((cpos ^ k_swz<D>(rip)) << 4);
+    const int v_lane = rip * v_rs + ((cpos ^ v_swz<D>(rip)) << 4);
     const int last_row = p.seqlen_k - 1;
     auto dma_tile = [&](int n, int kbuf, bool do_k, int vbuf, bool do_v) {
         const int row_w = n * BN + 16 * wave;                               // wave-uniform first row of this wave's slice
@@ -108,20 +123,20 @@ la_fwd_bf16_d128_v2_kernel(const FwdParams p) {
             const unsigned char* kb_ = kg + static_cast<int64_t>(row_w) * k_rs;   // scalar bases
             const unsigned char* vb_ = vg + static_cast<int64_t>(row_w) * v_rs;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (do_k) dma16(kb_ + j * 4 * k_rs + (k_lane ^ (j << 6)), k_lds + kbuf * TILE_BYTES + (4 * wave + j) * 1024);
-                if (do_v) dma16(vb_ + j * 4 * v_rs + v_lane, v_lds + vbuf * TILE_BYTES + (4 * wave + j) * 1024);
+            for (int j = 0; j < PPW; ++j) {
+                if (do_k) dma16(kb_ + j * RPP * k_rs + (k_lane ^ (j << 6)), k_lds + kbuf * TILE_BYTES + (PPW * wave + j) * 1024);
+                if (do_v) dma16(vb_ + j * RPP * v_rs + v_lane, v_lds + vbuf * TILE_BYTES + (PPW * wave + j) * 1024);
             }
         } else {
             asm volatile("; ragged K/V tail" ::: "memory");                  // keep this a real (rare) branch
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 4 * j + rip;
+            for (int j = 0; j < PPW; ++j) {
+                const int r = RPP * j + rip;
                 const int grow = min(row_w + r, last_row);                    // rows past seqlen_k: clamp (masked, P = 0)
-                if (do_k) dma16(kg + static_cast<int64_t>(grow) * k_rs + ((cpos ^ (r & 15)) << 4),
-                                k_lds + kbuf * TILE_BYTES + (4 * wave + j) * 1024);
-                if (do_v) dma16(vg + static_cast<int64_t>(grow) * v_rs + ((cpos ^ ((r & 3) << 2)) << 4),
-                                v_lds + vbuf * TILE_BYTES + (4 * wave + j) * 1024);
+                if (do_k) dma16(kg + static_cast<int64_t>(grow) * k_rs + ((cpos ^ k_swz<D>(r)) << 4),
+                                k_lds + kbuf * TILE_BYTES + (PPW * wave + j) * 1024);
+                if (do_v) dma16(vg + static_cast<int64_t>(grow) * v_rs + ((cpos ^ v_swz<D>(r)) << 4),
+                                v_lds + vbuf * TILE_BYTES + (PPW * wave + j) * 1024);
             }
         }
     };
@@ -138,24 +153,29 @@ la_fwd_bf16_d128_v2_kernel(const FwdParams p) {
     dma_tile(tile_at(1), 1, true, 0, false);
     __syncthreads();
 
-    // ---- per-lane LDS read offsets (same as la_fwd_kernel.hip)
+    // ---- per-lane LDS read offsets
+    // K A-operand: row = 32*kb + l31, chunk = 2*ks + hh   ->  row*ROW_BYTES + ((chunk ^ k_swz(row)) << 4)
     const int k_rd_row = l31 * ROW_BYTES;
-    const int k_rd_sw = l31 & 15;
+    const int k_rd_sw = k_swz<D>(l31);
+    // V^T A-operand via ds_read_b64_tr_b16. 16-lane group g = lane>>4, a = lane&15:
+    //   key = 16*kk + 4*hh + (a>>2) (+8 for the second read), d = 32*db + 16*(g&1) + 4*(a&3)
+    //   16-byte chunk = 4*db + 2*(g&1) + ((a&3)>>1), swizzled with v_swz(key) (constant per lane), +8 bytes if a&1
     const int a16 = lane & 15;
     const int v_key0 = 4 * hh + (a16 >> 2);
-    int v_rd[4];
+    int v_rd[DB];
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
-        v_rd[db] = v_key0 * ROW_BYTES + (((db ^ (a16 >> 2)) << 6) | (((lane >> 4) & 1) << 5) | ((a16 & 3) << 3));
+    for (int db = 0; db < DB; ++db)
+        v_rd[db] = v_key0 * ROW_BYTES +
+                   (((4 * db + 2 * ((lane >> 4) & 1) + ((a16 & 3) >> 1)) ^ v_swz<D>(v_key0)) << 4) + 8 * (a16 & 1);
 
     const float c = p.scale_log2;
     const float thr = p.thr;
     const int tail_valid = p.seqlen_k - (k_tiles - 1) * BN;   // valid keys in tile k_tiles-1 (1..64)
     unsigned domask = 1u;                                     // wave-uniform "do" bits of 32 consecutive positions; position 0 is never flagged
     float l_run = 0.f;
-    f32x16 o_acc[4];
+    f32x16 o_acc[DB];
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o_acc[db][r] = 0.f;
 
@@ -167,7 +187,7 @@ la_fwd_bf16_d128_v2_kernel(const FwdParams p) {
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
             const unsigned char* kt = k_lds + kbuf * TILE_BYTES + kb * 32 * ROW_BYTES + k_rd_row;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + (((2 * ks + hh) ^ k_rd_sw) << 4));
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
             }
@@ -252,7 +272,7 @@ la_fwd_bf16_d128_v2_kernel(const FwdParams p) {
         // ---- phase 2: O^T += V^T P^T of tile i (MFMA)  ||  row max / running max / vote of tile i+1 (VALU)
         const unsigned char* vt = v_lds + cur * TILE_BYTES;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
+        for (int db = 0; db < DB; ++db) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -271,7 +291,7 @@ la_fwd_bf16_d128_v2_kernel(const FwdParams p) {
             float a_in = alpha;
             asm volatile("; rescale O" : "+v"(a_in));           // value defined inside the branch: the multiplies cannot be speculated
 #pragma unroll
-            for (int db = 0; db < 4; ++db)
+            for (int db = 0; db < DB; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o_acc[db][r] *= a_in;
         }
@@ -307,7 +327,7 @@ la_fwd_bf16_d128_v2_kernel(const FwdParams p) {
     if (q_row < p.seqlen_q) {
         uint16_t* op = p.o + b * p.o_batch_stride + static_cast<int64_t>(q_row) * p.o_row_stride + h * p.o_head_stride;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
+        for (int db = 0; db < DB; ++db) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -333,26 +353,31 @@ la_fwd_bf16_d128_v2_kernel(const FwdParams p) {
     }
 }
 
-hipError_t launch_fwd_bf16_d128_v2(const FwdParams& p, bool skipable, hipStream_t stream) {
+size_t fwd_lds_bytes_v2(int head_dim, int k_tiles, int* seq_cap_out) {
+    const int seq_cap = (k_tiles + 3) & ~3;
+    if (seq_cap_out) *seq_cap_out = seq_cap;
+    return 4 * static_cast<size_t>(BN) * head_dim * 2 + 16 + static_cast<size_t>(seq_cap) * 4 +
+           2 * static_cast<size_t>((k_tiles + 31) / 32) * 4 + 16;
+}
+
+template <int D, bool SKIPABLE>
+static hipError_t launch_v2(const FwdParams& p, hipStream_t stream) {
     const int total = p.batch * p.num_heads * p.q_tiles;
     FwdParams pp = p;
-    const size_t lds = fwd_lds_bytes(p.k_tiles, &pp.seq_cap);
-    hipError_t err;
-    (void)hipGetLastError();
-    if (skipable) {
-        auto kfn = la_fwd_bf16_d128_v2_kernel<true>;
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int>(lds));
-        if (err != hipSuccess) return err;
-        hipLaunchKernelGGL(kfn, dim3(total), dim3(256), lds, stream, pp);
-    } else {
-        auto kfn = la_fwd_bf16_d128_v2_kernel<false>;
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int>(lds));
-        if (err != hipSuccess) return err;
-        hipLaunchKernelGGL(kfn, dim3(total), dim3(256), lds, stream, pp);
-    }
+    const size_t lds = fwd_lds_bytes_v2(D, p.k_tiles, &pp.seq_cap);
+    (void)hipGetLastError();   // drop any stale sticky error of this thread: only OUR launch is reported
+    auto kfn = la_fwd_bf16_v2_kernel<D, SKIPABLE>;
+    const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(kfn, dim3(total), dim3(256), lds, stream, pp);
     return hipGetLastError();
+}
+
+hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, hipStream_t stream) {
+    if (head_dim == 128) return skipable ? launch_v2<128, true>(p, stream) : launch_v2<128, false>(p, stream);
+    if (head_dim == 64) return skipable ? launch_v2<64, true>(p, stream) : launch_v2<64, false>(p, stream);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace la

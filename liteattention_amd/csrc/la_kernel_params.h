@@ -29,7 +29,8 @@ struct FwdParams {
 
 size_t fwd_lds_bytes(int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_d128(const FwdParams& p, bool skipable, hipStream_t stream);      // v1: register-staged
-hipError_t launch_fwd_bf16_d128_v2(const FwdParams& p, bool skipable, hipStream_t stream);   // v2: LDS-DMA, pipelined
+size_t fwd_lds_bytes_v2(int head_dim, int k_tiles, int* seq_cap_out);
+hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, hipStream_t stream);   // v2: LDS-DMA, pipelined; head_dim 128 / 64
 size_t fwd_w8_lds_bytes(int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_d128_w8(const FwdParams& p, bool skipable, hipStream_t stream);   // 8 waves, 256 rows, two list tiles
 hipError_t launch_skip_list_stats(const int32_t* list, int rows, int k_tiles, int64_t* out, hipStream_t stream);

@@ -23,7 +23,7 @@ struct TileShape {
 constexpr TileShape tile_shape(int head_dim, int element_size) {
     if (element_size == 2) {
         if (head_dim == 128) return {128, 64};
-        if (head_dim == 64) return {128, 64};
+        if (head_dim == 64) return {128, 64};   // K/V tile 8 KiB each: same key granularity, half the LDS
     }
     return {0, 0};
 }

@@ -34,7 +34,7 @@ def _orc():
     return orc
 
 
-def _randn(B, S, H, D=128, seed=0, Sk=None):
+def _randn(B, S, H, D=128, seed=0, Sk=None):  # noqa: E302
     g = torch.Generator().manual_seed(seed)
     Sk = S if Sk is None else Sk
     q = torch.randn(B, S, H, D, generator=g).bfloat16()
@@ -422,3 +422,60 @@ def test_full_size_properties_c2():
     o2 = L.flash_attn_func(q, k, v2)
     osum = L.flash_attn_func(q, k, vsum)
     assert (osum.float() - (dense.float() + o2.float())).abs().max().item() <= 3e-2
+
+
+# ----------------------------------------------------------------------------------- head_dim 64
+@pytest.mark.parametrize("shape", [(1, 64, 1, 64), (2, 333, 3, 333), (1, 1000, 2, 1250), (1, 2048, 1, 2048)])
+def test_head_dim_64_dense_matches_oracle(shape):
+    """Second instantiation of the reference's default build (hopper/instantiations/flash_fwd_hdim64_bf16_sm90.cu);
+    (1,2048,1,64) is BASELINE.json configs[0]'s shape in bf16."""
+    import liteattention_amd as L
+    orc = _orc()
+    assert L.get_tile_sizes(64, 2) == (BM, BN)
+    B, Sq, H, Sk = shape
+    q, k, v = _randn(B, Sq, H, D=64, seed=Sq, Sk=Sk)
+    o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN)
+    out, lse = L.flash_attn_func(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
+    assert (out.float().cpu() - o_ref).abs().max().item() <= _oracle_tol(o_ref)
+    assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
+    o_eager, _ = orc.attention_dense_ref(q, k, v)
+    o_pt, _ = orc.attention_dense_ref(q, k, v, upcast=False, reorder_ops=True)
+    assert (out.float().cpu() - o_eager.float()).abs().max().item() <= \
+        orc.dense_tolerance(o_eager.float(), o_pt) + 2.0 ** -8 * o_eager.float().abs().max().item()
+
+
+def test_head_dim_64_skip_lists_match_oracle():
+    import liteattention_amd as L
+    orc = _orc()
+    B, S, H, thr = 1, 1536, 3, -3.0
+    Qt, Kt = S // BM, S // BN
+    att = L.LiteAttention(threshold=thr, max_batch_size=B)
+    md_row = orc.expand_must_do_ref([0, 0], BN, Kt + 1)
+    margins = torch.empty(B, H, Qt, Kt)
+    listed = []
+    for step in range(4):
+        q, k, v = structured_qkv(B, S, H, 64, seed=200, alpha=7.0)
+        g = torch.Generator().manual_seed(3000 + step)
+        q = (q.float() + 0.05 * torch.randn(q.shape, generator=g)).bfloat16()
+        rd_idx = att._phase if att._skip_list is not None else 0
+        out, lse = att(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
+        rd, wr = att._skip_list[rd_idx].cpu(), att._skip_list[1 - rd_idx].cpu()
+        wr_orc = torch.zeros_like(wr)
+        o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN, read_list=rd, write_list=wr_orc,
+                                           must_do_list=md_row, thr=thr, margins=margins)
+        assert (out.float().cpu() - o_ref).abs().max().item() <= _oracle_tol(o_ref)
+        assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
+        bad, _ = _compare_lists(orc, rd, wr, wr_orc, margins, thr, B)
+        assert bad == 0
+        listed.append(orc.listed_tiles(wr[:B]))
+    assert listed[-1] < 0.9 * B * H * Qt * Kt
+    # reference script checks at head_dim 64 (test_lite_attention.py:7 loops over head dims)
+    q, k, v = [x.cuda() for x in _randn(2, 5000, 8, D=64, seed=0)]
+    attn = L.LiteAttention()
+    attn.threshold = float("inf")
+    attn(q, k, v)
+    assert (attn._skip_list[1, ..., 0] <= 2).all()
+    attn = L.LiteAttention()
+    attn.threshold = float("-inf")
+    attn(q, k, v)
+    assert (attn._skip_list[1] == attn._skip_list[0]).all()
