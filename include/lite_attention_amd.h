@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LA_ABI_VERSION 1
+#define LA_ABI_VERSION 2
 
 typedef enum la_status {
     LA_OK = 0,
@@ -49,7 +49,8 @@ typedef enum la_status {
     LA_ERR_LISTS = -8,           /* read list without write list, or vice versa                   */
     LA_ERR_UNSUPPORTED = -9,     /* feature outside the hot path (causal, GQA, dv != d, ...)      */
     LA_ERR_LAUNCH = -10,         /* hipLaunchKernel failed; see la_last_hip_error()               */
-    LA_ERR_SEQLEN = -11          /* sequence too long for the per-workgroup list staging in LDS   */
+    LA_ERR_SEQLEN = -11,         /* sequence too long for the per-workgroup list staging in LDS   */
+    LA_ERR_WORKSPACE = -12       /* fp8: workspace missing or smaller than la_fwd_workspace_bytes() */
 } la_status;
 
 typedef enum la_dtype {
@@ -106,11 +107,19 @@ typedef struct la_fwd_args {
     float          thr;          /* QKSkipMaskArgs::thr flash.h:17 (log2 domain)                  */
 
     int32_t block_m, block_n;    /* echo of la_get_tile_sizes(); checked                          */
+
+    /* fp8 only: caller-owned scratch for the pre-transposed V tiles (the library allocates nothing).
+     * Size from la_fwd_workspace_bytes(); 16-byte aligned; contents are scratch, valid during the call. */
+    void*    workspace;
+    uint64_t workspace_bytes;
 } la_fwd_args;
 
 /* Tile sizes (kBlockM, kBlockN) of the kernel that la_fwd will run for (head_dim, element size).
  * Skip-list geometry depends on them, so host code must take them from here. */
 int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n);
+
+/* Bytes of `workspace` la_fwd needs for these arguments (0 for bf16). Negative la_status on bad arguments. */
+int64_t la_fwd_workspace_bytes(const la_fwd_args* args);
 
 /* The forward pass. `stream` is a hipStream_t. */
 int la_fwd(const la_fwd_args* args, void* stream);

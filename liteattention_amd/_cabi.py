@@ -13,16 +13,17 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # LITEATTENTION_AMD_LIB overrides the in-tree location (deployment / tests of the failure path)
 LIB_PATH = os.environ.get("LITEATTENTION_AMD_LIB") or os.path.join(_PKG_DIR, "libliteattention_amd.so")
 
-LA_ABI_VERSION = 1
+LA_ABI_VERSION = 2
 LA_DTYPE_BF16, LA_DTYPE_FP16, LA_DTYPE_FP8_E4M3 = 0, 1, 2
 
 LA_OK = 0
 LA_ERR_NULL_ARG, LA_ERR_STRUCT_SIZE, LA_ERR_DTYPE, LA_ERR_HEAD_DIM, LA_ERR_SHAPE = -1, -2, -3, -4, -5
 LA_ERR_STRIDE, LA_ERR_TILE_MISMATCH, LA_ERR_LISTS, LA_ERR_UNSUPPORTED, LA_ERR_LAUNCH, LA_ERR_SEQLEN = (
     -6, -7, -8, -9, -10, -11)
+LA_ERR_WORKSPACE = -12
 
 EXPORTED_SYMBOLS = (
-    "la_abi_version", "la_get_tile_sizes", "la_fwd", "la_skip_list_stats", "la_combine",
+    "la_abi_version", "la_get_tile_sizes", "la_fwd", "la_fwd_workspace_bytes", "la_skip_list_stats", "la_combine",
     "la_status_string", "la_last_hip_error",
 )
 
@@ -48,6 +49,7 @@ class LaFwdArgs(ctypes.Structure):
         ("read_list", ctypes.c_void_p), ("write_list", ctypes.c_void_p), ("must_do_list", ctypes.c_void_p),
         ("must_do_is_1d", ctypes.c_int32), ("thr", ctypes.c_float),
         ("block_m", ctypes.c_int32), ("block_n", ctypes.c_int32),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64),
     ]
 
 
@@ -83,6 +85,8 @@ def load() -> ctypes.CDLL:
     lib.la_get_tile_sizes.restype = ctypes.c_int
     lib.la_fwd.argtypes = [ctypes.POINTER(LaFwdArgs), ctypes.c_void_p]
     lib.la_fwd.restype = ctypes.c_int
+    lib.la_fwd_workspace_bytes.argtypes = [ctypes.POINTER(LaFwdArgs)]
+    lib.la_fwd_workspace_bytes.restype = ctypes.c_int64
     lib.la_skip_list_stats.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                        ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
     lib.la_skip_list_stats.restype = ctypes.c_int

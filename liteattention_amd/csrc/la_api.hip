@@ -38,32 +38,47 @@ const char* la_status_string(int status) {
         case LA_ERR_UNSUPPORTED: return "feature outside the QK-Skip hot path (GQA/MQA, head_dim_v != head_dim)";
         case LA_ERR_LAUNCH: return "HIP kernel launch failed (see la_last_hip_error)";
         case LA_ERR_SEQLEN: return "seqlen_k too long: expanded skip list does not fit in LDS";
+        case LA_ERR_WORKSPACE: return "fp8 needs a 16-byte aligned workspace of la_fwd_workspace_bytes() bytes";
         default: return "unknown la_status";
     }
 }
 
 int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n) {
     const la::TileShape t = la::tile_shape(head_dim, element_size);
-    if (t.block_m == 0) return element_size == 2 ? LA_ERR_HEAD_DIM : LA_ERR_DTYPE;
+    if (t.block_m == 0) return (element_size == 2 || element_size == 1) ? LA_ERR_HEAD_DIM : LA_ERR_DTYPE;
     if (block_m) *block_m = t.block_m;
     if (block_n) *block_n = t.block_n;
     return LA_OK;
+}
+
+int64_t la_fwd_workspace_bytes(const la_fwd_args* a) {
+    if (a == nullptr) return LA_ERR_NULL_ARG;
+    if (a->struct_size != sizeof(la_fwd_args)) return LA_ERR_STRUCT_SIZE;
+    if (a->dtype == LA_DTYPE_BF16) return 0;
+    if (a->dtype != LA_DTYPE_FP8_E4M3) return LA_ERR_DTYPE;
+    int bm = 0, bn = 0;
+    const int trc = la_get_tile_sizes(a->head_dim, 1, &bm, &bn);
+    if (trc != LA_OK) return trc;
+    if (a->batch <= 0 || a->num_heads <= 0 || a->seqlen_k < 0) return LA_ERR_SHAPE;
+    return static_cast<int64_t>(la::fp8_workspace_bytes(a->batch, a->num_heads, (a->seqlen_k + bn - 1) / bn));
 }
 
 int la_fwd(const la_fwd_args* a, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (a == nullptr) return LA_ERR_NULL_ARG;
     if (a->struct_size != sizeof(la_fwd_args)) return LA_ERR_STRUCT_SIZE;
-    if (a->dtype != LA_DTYPE_BF16) return LA_ERR_DTYPE;                                  // flash_api.cpp:715
+    if (a->dtype != LA_DTYPE_BF16 && a->dtype != LA_DTYPE_FP8_E4M3) return LA_ERR_DTYPE;   // flash_api.cpp:715
+    const bool fp8 = a->dtype == LA_DTYPE_FP8_E4M3;
+    const int esize = fp8 ? 1 : 2;
     if (!a->q || !a->k || !a->v || !a->o) return LA_ERR_NULL_ARG;
     if (a->batch <= 0 || a->seqlen_q <= 0 || a->seqlen_k < 0 || a->num_heads <= 0 || a->num_heads_k <= 0 ||
         a->head_dim <= 0 || a->head_dim_v <= 0)
         return LA_ERR_SHAPE;                                                             // flash_api.cpp:776-778
     if (a->num_heads % a->num_heads_k != 0) return LA_ERR_SHAPE;                          // flash_api.cpp:777
-    if (a->head_dim % 8 != 0) return LA_ERR_HEAD_DIM;                                     // flash_api.cpp:854-856
+    if (a->head_dim % (fp8 ? 16 : 8) != 0) return LA_ERR_HEAD_DIM;                         // flash_api.cpp:854-856
     if (a->num_heads_k != a->num_heads || a->head_dim_v != a->head_dim) return LA_ERR_UNSUPPORTED;
     int bm = 0, bn = 0;
-    const int trc = la_get_tile_sizes(a->head_dim, 2, &bm, &bn);
+    const int trc = la_get_tile_sizes(a->head_dim, esize, &bm, &bn);
     if (trc != LA_OK) return trc;
     if (a->block_m != bm || a->block_n != bn) return LA_ERR_TILE_MISMATCH;
     if ((a->read_list == nullptr) != (a->write_list == nullptr)) return LA_ERR_LISTS;
@@ -71,8 +86,11 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     const int64_t strides[] = {a->q_batch_stride, a->q_row_stride, a->q_head_stride, a->k_batch_stride,
                                a->k_row_stride,   a->k_head_stride, a->v_batch_stride, a->v_row_stride,
                                a->v_head_stride,  a->o_batch_stride, a->o_row_stride,  a->o_head_stride};
-    for (int64_t s : strides)
-        if (s % 8 != 0 || s < 0) return LA_ERR_STRIDE;                                   // flash_api.cpp:726-728 (+alignment)
+    for (int i = 0; i < 12; ++i) {                                                       // flash_api.cpp:726-728 (+alignment)
+        const int64_t s = strides[i];
+        const int gran = (fp8 && i < 9) ? 16 : 8;                                        // 16-byte rows: 16 fp8 / 8 bf16 elements
+        if (s % gran != 0 || s < 0) return LA_ERR_STRIDE;
+    }
     if (a->k_row_stride > 0x3fffffff || a->v_row_stride > 0x3fffffff) return LA_ERR_STRIDE;   // byte strides kept in int32
     if (!aligned16(a->q) || !aligned16(a->k) || !aligned16(a->v) || !aligned16(a->o)) return LA_ERR_STRIDE;
 
@@ -83,6 +101,10 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     }
 
     la::FwdParams p{};
+    if (fp8) {
+        const size_t need = la::fp8_workspace_bytes(a->batch, a->num_heads, (a->seqlen_k + bn - 1) / bn);
+        if (a->workspace == nullptr || a->workspace_bytes < need || !aligned16(a->workspace)) return LA_ERR_WORKSPACE;
+    }
     p.q = static_cast<const uint16_t*>(a->q);
     p.k = static_cast<const uint16_t*>(a->k);
     p.v = static_cast<const uint16_t*>(a->v);
@@ -101,10 +123,26 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     p.write_list = a->write_list;
     p.must_do_list = a->must_do_list;
     p.must_do_is_1d = a->must_do_is_1d;
+    p.q_descale = a->q_descale; p.k_descale = a->k_descale; p.v_descale = a->v_descale;
+    p.q_descale_batch_stride = a->q_descale_batch_stride; p.q_descale_head_stride = a->q_descale_head_stride;
+    p.k_descale_batch_stride = a->k_descale_batch_stride; p.k_descale_head_stride = a->k_descale_head_stride;
+    p.v_descale_batch_stride = a->v_descale_batch_stride; p.v_descale_head_stride = a->v_descale_head_stride;
 
     if (la::fwd_lds_bytes_v2(a->head_dim, p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
     if (static_cast<int64_t>(p.batch) * p.num_heads * p.q_tiles > 0x7fffffffLL) return LA_ERR_SHAPE;
 
+    if (fp8) {
+        if (la::fwd_lds_bytes_fp8(p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
+        // 1) V -> pre-transposed, pre-swizzled V^T tiles in the caller's workspace; 2) forward on (Q, K, V^T)
+        hipError_t e8 = la::launch_prep_v_fp8(a->v, a->v_batch_stride, a->v_row_stride, a->v_head_stride, a->workspace,
+                                              a->batch, a->seqlen_k, a->num_heads, p.k_tiles, stream);
+        if (e8 == hipSuccess) {
+            p.v = static_cast<const uint16_t*>(a->workspace);
+            e8 = la::launch_fwd_fp8_d128(p, a->read_list != nullptr, stream);
+        }
+        if (e8 != hipSuccess) { g_last_hip_error = static_cast<int>(e8); return LA_ERR_LAUNCH; }
+        return LA_OK;
+    }
     // LA_FWD_KERNEL=v1 selects the register-staged kernel (A/B and fallback); default is the pipelined v2.
     static const bool use_v1 = [] { const char* e = getenv("LA_FWD_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
     const bool skipable = a->read_list != nullptr;                                      // is_skipable, flash_api.cpp:931

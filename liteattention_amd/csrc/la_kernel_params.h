@@ -25,6 +25,13 @@ struct FwdParams {
     int* write_list;
     const int* must_do_list;
     int must_do_is_1d;
+    // fp8 only: per-(batch, head) descales, NULL = 1.0 (flash_api.cpp:1003-1022); strides in elements
+    const float* q_descale;
+    const float* k_descale;
+    const float* v_descale;
+    int64_t q_descale_batch_stride, q_descale_head_stride;
+    int64_t k_descale_batch_stride, k_descale_head_stride;
+    int64_t v_descale_batch_stride, v_descale_head_stride;
 };
 
 size_t fwd_lds_bytes(int k_tiles, int* seq_cap_out);
@@ -33,6 +40,11 @@ size_t fwd_lds_bytes_v2(int head_dim, int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, hipStream_t stream);   // v2: LDS-DMA, pipelined; head_dim 128 / 64
 size_t fwd_w8_lds_bytes(int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_d128_w8(const FwdParams& p, bool skipable, hipStream_t stream);   // 8 waves, 256 rows, two list tiles
+size_t fwd_lds_bytes_fp8(int k_tiles, int* seq_cap_out);
+size_t fp8_workspace_bytes(int batch, int num_heads, int k_tiles);
+hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_row_stride, int64_t v_head_stride,
+                             void* vt, int batch, int seqlen_k, int num_heads, int k_tiles, hipStream_t stream);
+hipError_t launch_fwd_fp8_d128(const FwdParams& p, bool skipable, hipStream_t stream);   // p.v = V^T workspace
 hipError_t launch_skip_list_stats(const int32_t* list, int rows, int k_tiles, int64_t* out, hipStream_t stream);
 hipError_t launch_combine(const void* o_partial, bool partial_is_bf16, const float* lse_partial, uint16_t* o,
                           float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v,

@@ -101,10 +101,11 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     ``LiteAttention.__call__`` reaches. Returns ``(out, softmax_lse, out_accum, softmax_lse_accum)``."""
     if not q.is_cuda:
         raise RuntimeError("lite_attention::fwd has no CPU implementation (HIP device tensors required)")
-    if q.dtype not in (torch.bfloat16,):
-        if q.dtype in (torch.float16, torch.float8_e4m3fn):
-            raise NotImplementedError(f"dtype {q.dtype} is not instantiated in this build (bf16 only)")
+    if q.dtype not in (torch.bfloat16, torch.float8_e4m3fn):
+        if q.dtype == torch.float16:
+            raise NotImplementedError("fp16 is not instantiated in this build (bf16 and fp8_e4m3 are)")
         raise RuntimeError("FlashAttention only supports fp16, bf16, and fp8_e4m3 type")          # :715
+    is_fp8 = q.dtype == torch.float8_e4m3fn
     if k.dtype != q.dtype or v.dtype != q.dtype:
         raise RuntimeError("query and key must have the same dtype")                              # :718-719
     for name, val in (("k_new", k_new), ("v_new", v_new), ("q_v", q_v), ("cu_seqlens_q", cu_seqlens_q),
@@ -112,8 +113,7 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
                       ("seqused_q", seqused_q), ("seqused_k", seqused_k), ("page_table", page_table),
                       ("kv_batch_idx", kv_batch_idx), ("leftpad_k", leftpad_k), ("rotary_cos", rotary_cos),
                       ("rotary_sin", rotary_sin), ("seqlens_rotary", seqlens_rotary),
-                      ("scheduler_metadata", scheduler_metadata), ("q_descale", q_descale),
-                      ("k_descale", k_descale), ("v_descale", v_descale)):
+                      ("scheduler_metadata", scheduler_metadata)):
         if val is not None:
             raise NotImplementedError(f"{name} is outside the QK-Skip hot path (compiled out of the reference's "
                                       "default LiteAttention build, hopper/setup.py:47-63)")
@@ -137,8 +137,18 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
         raise RuntimeError("k/v shape mismatch: expected k (batch, seqlen_k, nheads_k, headdim), v (batch, seqlen_k, nheads_k, headdim_v)")
     if H % Hk != 0:
         raise RuntimeError("Number of heads in key/value must divide number of heads in query")  # :777
-    if D % 8 != 0:
-        raise RuntimeError("head_size should be a multiple of 8")                                # :854-856
+    if D % (16 if is_fp8 else 8) != 0:
+        raise RuntimeError("head_size should be a multiple of " + ("16" if is_fp8 else "8"))     # :854-856
+    descales = []
+    for name, t in (("q_descale", q_descale), ("k_descale", k_descale), ("v_descale", v_descale)):
+        if t is None:
+            descales.append(None)
+            continue
+        if not is_fp8:
+            raise RuntimeError(f"{name} is only supported for fp8 inputs")
+        if t.dtype != torch.float32 or tuple(t.shape) != (B, Hk) or t.device != q.device:          # :1003-1022
+            raise RuntimeError(f"{name} must be a float32 tensor of shape (batch_size, nheads_k) on the input device")
+        descales.append(t)
     if Hk != H:
         raise NotImplementedError("GQA/MQA (nheads_k != nheads) is outside the QK-Skip hot path in this build")
     if Dv != D:
@@ -181,7 +191,12 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
 
     a = _cabi.LaFwdArgs()
     a.struct_size = ctypes.sizeof(_cabi.LaFwdArgs)
-    a.dtype = _cabi.LA_DTYPE_BF16
+    a.dtype = _cabi.LA_DTYPE_FP8_E4M3 if is_fp8 else _cabi.LA_DTYPE_BF16
+    for name, t in zip(("q", "k", "v"), descales):
+        if t is not None:
+            setattr(a, f"{name}_descale", t.data_ptr())
+            setattr(a, f"{name}_descale_batch_stride", t.stride(0))
+            setattr(a, f"{name}_descale_head_stride", t.stride(1))
     a.q, a.k, a.v, a.o, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), softmax_lse.data_ptr()
     a.q_batch_stride, a.q_row_stride, a.q_head_stride = q.stride(0), q.stride(1), q.stride(2)
     a.k_batch_stride, a.k_row_stride, a.k_head_stride = k.stride(0), k.stride(1), k.stride(2)
@@ -194,6 +209,15 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     a.must_do_is_1d = 1 if _must_do_is_1d else 0
     a.thr = float(thr)
     a.block_m, a.block_n = block_m, block_n
+    workspace = None
+    if is_fp8:
+        # scratch for the pre-transposed V tiles: caller-owned (the C side allocates nothing); freed after the
+        # launch by the caching allocator's stream-ordered reuse
+        need = _cabi.load().la_fwd_workspace_bytes(ctypes.byref(a))
+        if need < 0:
+            raise RuntimeError(f"lite_attention::fwd: {_cabi.status_string(int(need))}")
+        workspace = torch.empty(int(need), dtype=torch.uint8, device=q.device)
+        a.workspace, a.workspace_bytes = workspace.data_ptr(), int(need)
     with torch.cuda.device(q.device):                                                             # CUDAGuard :885
         stream = torch.cuda.current_stream(q.device).cuda_stream                                  # :1219
         rc = _cabi.load().la_fwd(ctypes.byref(a), ctypes.c_void_p(stream))

@@ -53,6 +53,7 @@ class _Args(ctypes.Structure):
         ("p_round", ctypes.c_int32), ("mask_any_tail", ctypes.c_int32),
         ("nthreads", ctypes.c_int32),
         ("tiles_done", ctypes.c_void_p),
+        ("q_descale", ctypes.c_void_p), ("k_descale", ctypes.c_void_p), ("v_descale", ctypes.c_void_p),
         ("margins", ctypes.c_void_p),
     ]
 
@@ -87,8 +88,9 @@ def qkskip_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, block_m: in
                read_list: Optional[torch.Tensor] = None, write_list: Optional[torch.Tensor] = None,
                must_do_list: Optional[torch.Tensor] = None, thr: float = -3.0,
                softmax_scale: Optional[float] = None, p_round: bool = True,
-               mask_any_tail: bool = True, nthreads: int = 0, margins: Optional[torch.Tensor] = None
-               ) -> Tuple[torch.Tensor, torch.Tensor, int]:
+               mask_any_tail: bool = True, nthreads: int = 0, margins: Optional[torch.Tensor] = None,
+               q_descale: Optional[torch.Tensor] = None, k_descale: Optional[torch.Tensor] = None,
+               v_descale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, int]:
     """Tiled CPU forward. q,k,v: (B,S,H,D) of any float dtype (values are taken as they are,
     i.e. bf16 tensors give bf16-representable fp32 operands). Lists are CPU int32 tensors of shape
     [>=B, H, Qt, Kt+1]; ``write_list`` is filled in place. ``must_do_list`` may be 1-D ([Kt+1]).
@@ -129,7 +131,14 @@ def qkskip_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, block_m: in
             a.must_do_is_1d = 0
             a.must_do_list = _chk(must_do_list, "must_do_list")
     a.thr = thr
-    a.p_round = int(p_round)
+    a.p_round = 2 if p_round == "fp8" else int(p_round)   # "fp8": e4m3 P with the 2^8 offset (reference Max_offset)
+    keep = []
+    for name, t in (("q_descale", q_descale), ("k_descale", k_descale), ("v_descale", v_descale)):
+        if t is not None:
+            t32 = t.detach().to("cpu", torch.float32).contiguous()
+            assert tuple(t32.shape) == (B, H), name
+            keep.append(t32)
+            setattr(a, name, t32.data_ptr())
     a.mask_any_tail = int(mask_any_tail)
     a.nthreads = nthreads
     a.tiles_done = ctypes.addressof(tiles)

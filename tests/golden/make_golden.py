@@ -142,6 +142,25 @@ def main():
             input_checksum=np.float64(q.double().sum().item() + 2 * k.double().sum().item() + 3 * v.double().sum().item()),
             meta=np.array([seed, B, Sq, Sk, H, D]), dtype=np.array(dt))
         print(name, "pt_maxerr", (out_pt.float() - out_ref).abs().max().item())
+    # G5-fp8: e4m3 inputs with per-(batch, head) descales (hopper/tests/test_flash_attn.py:204-219, 253)
+    for name, seed, B, Sq, Sk, H, D in [("fp8_b2_s333_h3_d128", 11, 2, 333, 333, 3, 128),
+                                        ("fp8_sq200_sk777_h2_d128", 12, 1, 200, 777, 2, 128)]:
+        q, k, v = dense_inputs(seed, B, Sq, Sk, H, D, torch.float8_e4m3fn)
+        g = torch.Generator().manual_seed(1000 + seed)
+        qd, kd, vd = [torch.rand(B, H, generator=g) * 2 for _ in range(3)]
+        out_ref, _ = test_util.attention_ref(q, k, v, None, None, q_descale=qd, k_descale=kd, v_descale=vd)
+        out_pt, _ = test_util.attention_ref(q, k, v, None, None, q_descale=qd, k_descale=kd, v_descale=vd,
+                                            upcast=False, reorder_ops=True, intermediate_dtype=torch.float8_e4m3fn)
+        scores = torch.einsum("bthd,bshd->bhts", q, k) * (qd * kd)[:, :, None, None] * (1.0 / D ** 0.5)
+        lse_ref = torch.logsumexp(scores, dim=-1)
+        np.savez_compressed(
+            os.path.join(HERE, f"dense_{name}.npz"),
+            out_ref=out_ref.numpy().astype(np.float32), lse_ref=lse_ref.numpy().astype(np.float32),
+            pt_maxerr=np.float32((out_pt.float() - out_ref).abs().max().item()),
+            input_checksum=np.float64(q.double().sum().item() + 2 * k.double().sum().item() + 3 * v.double().sum().item()),
+            meta=np.array([seed, B, Sq, Sk, H, D]), dtype=np.array("float8_e4m3fn"),
+            q_descale=qd.numpy(), k_descale=kd.numpy(), v_descale=vd.numpy())
+        print(name, "pt_maxerr", (out_pt.float() - out_ref).abs().max().item())
     print("wrote", sorted(os.listdir(HERE)))
 
 

@@ -8,6 +8,7 @@ import torch
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 DENSE_CASES = ["cfg0_fp32_s2048_d64", "bf16_b2_s333_h3_d128", "bf16_s512_h2_d128", "bf16_sq113_sk203_h2_d128"]
+FP8_CASES = ["fp8_b2_s333_h3_d128", "fp8_sq200_sk777_h2_d128"]
 
 
 def dense_inputs(seed, B, Sq, Sk, H, D, dtype):
@@ -26,8 +27,12 @@ def load_dense_case(name):
     q, k, v = dense_inputs(seed, B, Sq, Sk, H, D, dtype)
     chk = q.double().sum().item() + 2 * k.double().sum().item() + 3 * v.double().sum().item()
     assert abs(chk - float(z["input_checksum"])) < 1e-6, "torch CPU generator drifted: regenerate tests/golden"
-    return {"q": q, "k": k, "v": v, "dtype": dtype, "out_ref": torch.from_numpy(z["out_ref"]),
+    case = {"q": q, "k": k, "v": v, "dtype": dtype, "out_ref": torch.from_numpy(z["out_ref"]),
             "lse_ref": torch.from_numpy(z["lse_ref"]), "pt_maxerr": float(z["pt_maxerr"]), "D": D}
+    for name in ("q_descale", "k_descale", "v_descale"):
+        if name in z.files:
+            case[name] = torch.from_numpy(z[name])
+    return case
 
 
 def ref_tolerance(out_ref, pt_maxerr):

@@ -17,7 +17,7 @@ HEADER = os.path.join(ROOT, "include", "lite_attention_amd.h")
 def declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+)?(?:int|char\s*\*|const char\*)\s+\**\s*(la_\w+)\s*\(", src, flags=re.M)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int64_t|int|char\s*\*|const char\*)\s+\**\s*(la_\w+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 
@@ -51,12 +51,13 @@ def test_struct_layout_matches_header(tmp_path):
 
 
 def test_tile_sizes_and_status_strings():
-    assert _cabi.get_tile_sizes(128, 2) == (128, 64)
+    assert _cabi.get_tile_sizes(128, 2) == (128, 64) and _cabi.get_tile_sizes(64, 2) == (128, 64)
+    assert _cabi.get_tile_sizes(128, 1) == (128, 64)
     lib = _cabi.load()
     m, n = ctypes.c_int(), ctypes.c_int()
     assert lib.la_get_tile_sizes(48, 2, ctypes.byref(m), ctypes.byref(n)) == _cabi.LA_ERR_HEAD_DIM
     assert lib.la_get_tile_sizes(128, 4, ctypes.byref(m), ctypes.byref(n)) == _cabi.LA_ERR_DTYPE
-    for code in range(0, -12, -1):
+    for code in range(0, -13, -1):
         s = _cabi.status_string(code)
         assert s and s != "unknown la_status", code
     assert _cabi.status_string(-99) == "unknown la_status"
@@ -69,7 +70,7 @@ def test_argument_validation_returns_codes_without_launching():
     a = _cabi.LaFwdArgs()
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_STRUCT_SIZE
     a.struct_size = ctypes.sizeof(_cabi.LaFwdArgs)
-    a.dtype = _cabi.LA_DTYPE_FP8_E4M3
+    a.dtype = _cabi.LA_DTYPE_FP16
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_DTYPE
     a.dtype = _cabi.LA_DTYPE_BF16
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_NULL_ARG
@@ -92,6 +93,14 @@ def test_argument_validation_returns_codes_without_launching():
     a.write_list = 0x3000
     a.q_row_stride = 4 * 128 + 4
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_STRIDE
+    # fp8: workspace contract
+    a.q_row_stride = 4 * 128
+    a.dtype = _cabi.LA_DTYPE_FP8_E4M3
+    a.read_list = a.write_list = None
+    assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 1 * 4 * 4 * 8192     # B * H * Kt * 8 KiB
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_WORKSPACE
+    a.dtype = _cabi.LA_DTYPE_BF16
+    assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 0
     assert lib.la_skip_list_stats(None, 1, 1, 1, 1, None, None) == _cabi.LA_ERR_NULL_ARG
     assert lib.la_combine(None, 0, None, None, None, 1, 1, 1, 1, 128, None) == _cabi.LA_ERR_NULL_ARG
 
