@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_FP8_PEAK_TFLOPS = 5000.0      # dense fp8 peak (MX-scaled K=128 forms); the non-scaled fp8 MFMA used here runs at the bf16 rate
 SPARSITIES = (0.0, 0.21, 0.42, 0.57, 0.77)
 HEADLINE_SPARSITY = 0.42
 
@@ -139,6 +140,8 @@ def main():
     ap.add_argument("--heads", type=int, default=40)
     ap.add_argument("--no-sweep", action="store_true", help="skip the 1-GPU sparsity sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
+                    help="bf16 = headline (BASELINE.json configs[2,3]); fp8 = configs[4] (e4m3 Q/K/V, bf16 out)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,11 +167,13 @@ def main():
     B, S, H, D = 1, args.seqlen, args.heads, 128
     assert H % world == 0, "heads must divide over ranks"
     Hl = H // world
-    bm, bn = L.get_tile_sizes(D, 2)
+    fp8 = args.dtype == "fp8"
+    in_dtype = torch.float8_e4m3fn if fp8 else torch.bfloat16
+    bm, bn = L.get_tile_sizes(D, 1 if fp8 else 2)
     q_tiles, k_tiles = -(-S // bm), -(-S // bn)
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    q, k, v = [torch.randn(B, S, Hl, D, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    q, k, v = [torch.randn(B, S, Hl, D, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16).to(in_dtype)
                for _ in range(3)]
 
     att = HeadShardedLiteAttention(num_heads=H, threshold=-10.0, max_batch_size=B,
@@ -219,21 +224,22 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(step_s * 1e3, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"QK-Skip self-attention fwd, B={B} S={S} H={H} D={D} bf16, imposed "
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"QK-Skip self-attention fwd, B={B} S={S} H={H} D={D} {args.dtype}, imposed "
                                f"{HEADLINE_SPARSITY:.0%} sparsity (banded lists, thr=-inf), tiles {bm}x{bn}",
                    "sparsity": round(1 - listed_frac, 4),
                    "parallelism": f"heads sharded {world}x{Hl}" + (" + 1 RCCL all-gather of O per step" if world > 1 else ""),
                    "dense_equiv_tflops": round(4.0 * B * H * S * S * D / step_s / 1e12, 2)},
         "roofline": {"bound": "mfma", "achieved": round(flops_rank / kern_s / 1e12, 2),
-                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(flops_rank / kern_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "peak": MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(flops_rank / kern_s / 1e12 / (MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS), 4),
                      "traffic": None,
-                     "kernel": "la_fwd_bf16_d128_v2_kernel<true>", "kernel_ms": round(kern_s * 1e3, 3),
+                     "kernel": "la_prep_v_fp8_kernel + la_fwd_fp8_d128_kernel<true>" if fp8 else "la_fwd_bf16_v2_kernel<128,true>",
+                     "kernel_ms": round(kern_s * 1e3, 3),
                      "algorithmic_tflop_per_launch": round(flops_rank / 1e12, 3)},
     }
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and not fp8:
         try:
             with open(pmc) as f:
                 p = json.load(f)
@@ -260,7 +266,7 @@ def main():
             e["reference_t_over_t0"] = ref_curve[s]
         result["sweep"] = sweep
 
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and not fp8:
         try:
             result["cpu_baseline"] = cpu_baseline(S, D, bm, bn, banded_rows(q_tiles, k_tiles, bm, bn, HEADLINE_SPARSITY))
         except Exception as e:  # the baseline is a reported number, never the measured path
