@@ -115,10 +115,11 @@ def test_missing_library_fails_loudly(tmp_path):
 
 
 def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: no product source may import, include or load it."""
     pkg = os.path.join(ROOT, "liteattention_amd")
+    pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle|#include\s+.*oracle)|qkskip_oracle|libqkskip", re.M)
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in text.replace("# oracle", "").lower() or "oracle hopper" in text.lower() or \
-                    all("import" not in line and "include" not in line for line in text.splitlines() if "oracle" in line.lower()), f
+                assert not pat.search(text), f
