@@ -149,7 +149,9 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     static const bool use_w8 = [] { const char* e = getenv("LA_FWD_KERNEL"); return e && e[0] == 'w' && e[1] == '8'; }();
     const bool d128 = a->head_dim == 128;                                               // v1 / w8 are head_dim-128 only
     const bool w8_fits = la::fwd_w8_lds_bytes(p.k_tiles, nullptr) <= 160 * 1024;
-    const hipError_t err = (use_w8 && d128 && w8_fits) ? la::launch_fwd_bf16_d128_w8(p, skipable, stream)
+    static const bool use_asm = [] { const char* e = getenv("LA_FWD_KERNEL"); return e && e[0] == 'a' && e[1] == 's'; }();
+    const hipError_t err = (use_asm && d128)            ? la::launch_fwd_bf16_d128_asm(p, skipable, stream)
+                           : (use_w8 && d128 && w8_fits) ? la::launch_fwd_bf16_d128_w8(p, skipable, stream)
                            : (use_v1 && d128)          ? la::launch_fwd_bf16_d128(p, skipable, stream)
                                                        : la::launch_fwd_bf16_v2(p, a->head_dim, skipable, stream);
     if (err != hipSuccess) {
