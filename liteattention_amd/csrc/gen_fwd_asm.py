@@ -18,7 +18,11 @@ Schedule of one step (tile i in S_cur, K(i+1) / V(i) resident in LDS):
 Everything the block needs comes from an LDS parameter block written by the C++ prologue; results (O^T, m, l) go
 back through LDS (the K/V buffers are free after the last barrier). The block owns v0-v247, s30-s79, vcc, m0, scc.
 """
+import os
 import sys
+
+# Experiment switches (comma list in LA_ASM_OPT): ablations produce WRONG results and exist only to price a component.
+OPT = set(x for x in os.environ.get("LA_ASM_OPT", "").split(",") if x)
 
 # ---------------------------------------------------------------- register map (VGPR)
 O = [0, 16, 32, 48]                  # O^T accumulators, 4 d-blocks x 16
@@ -49,6 +53,17 @@ S_QBASE, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT = 58, 60, 61, 62, 63
 S_T64 = 64                           # 64-bit temp (s64:65)
 S_PARAM, S_HASNEXT, S_NEGC, S_T2, S_T3 = 66, 67, 68, 69, 70
 S_VB = 72                            # 64-bit V tile base temp (s72:73)
+S_SAFEROW, S_DMAW, S_RAG = 71, 77, 78   # max(seqlen_k-64, 0); LDS base of this wave's DMA pieces; ragged-tile flags of the step
+
+def opt_val(key, default):
+    for o in OPT:
+        if o.startswith(key + ":"):
+            return o[len(key) + 1:]
+    return default
+
+
+DMA_PLACE = opt_val("dma", "head")      # where the 8 LDS-DMA pieces of a step are issued
+ILV = "ilv" in OPT                      # alternate accumulators between consecutive MFMAs
 
 KV_TILE = 16384
 V_REGION = 32768
@@ -85,11 +100,14 @@ class Lgkm:
 
     def __init__(self):
         self.issued = []
+        self.fake = set()
 
     def issue(self, tag):
         self.issued.append(tag)
 
     def wait_for(self, tag):
+        if tag in self.fake:
+            return
         idx = max(i for i, t in enumerate(self.issued) if t == tag)
         after = len(self.issued) - 1 - idx
         emit(f"s_waitcnt lgkmcnt({after})")
@@ -110,6 +128,9 @@ def mfma(dst, a, b, c_init_zero=False):
 def k_read(lg, slot, kbuf_imm, j):
     """K(i+1) fragment j = 8*kb + ks from K buffer at byte immediate kbuf_imm."""
     kb, ks = j >> 3, j & 7
+    if "nokread" in OPT:
+        lg.issue(("k", j)); lg.issued.pop(); lg.fake.add(("k", j))
+        return
     emit(f"ds_read_b128 {vr(KF[slot], 4)}, {v(KADDR[ks])} offset:{kbuf_imm + kb * 8192}")
     lg.issue(("k", j))
 
@@ -117,6 +138,9 @@ def k_read(lg, slot, kbuf_imm, j):
 def v_read(lg, slot, vbuf_imm, m):
     """V^T fragment m = 4*db + kk: two transpose reads (keys +0 and +8)."""
     db, kk = m >> 2, m & 3
+    if "novread" in OPT:
+        lg.fake.add(("v", m, 1))
+        return
     emit(f"ds_read_b64_tr_b16 {vr(VF[slot], 2)}, {v(VADDR[db])} offset:{vbuf_imm + kk * 4096}")
     lg.issue(("v", m, 0))
     emit(f"ds_read_b64_tr_b16 {vr(VF[slot] + 2, 2)}, {v(VADDR[db])} offset:{vbuf_imm + kk * 4096 + 2048}")
@@ -125,6 +149,8 @@ def v_read(lg, slot, vbuf_imm, m):
 
 def softmax_pair(scur, pidx):
     """7 VALU: P for accumulator elements 2*pidx, 2*pidx+1 of the 32 (kb = e>>4, r = e&15)."""
+    if "nosoftmax" in OPT:
+        return
     e0, e1 = 2 * pidx, 2 * pidx + 1
     r0 = scur[e0 >> 4] + (e0 & 15)
     r1 = scur[e1 >> 4] + (e1 & 15)
@@ -142,10 +168,8 @@ def softmax_pair(scur, pidx):
 
 def dma_fast(n_sgpr, do_k, kbuf_imm, do_v, vbuf_imm, sk_tmp, sv_tmp):
     """8 (or 4) LDS-DMA pieces of tile n (SGPR): tile base in SGPRs + per-lane offsets LK/LV."""
-    # row_w = n*64 + 16*wave ; base = tensor_base + row_w * row_stride   (SALU, 64-bit)
+    # base = tensor_base + n*64 * row_stride   (SALU, 64-bit); the wave's 16-row slice is in the per-lane offsets
     emit(f"s_lshl_b32 {s(S_T0)}, {s(n_sgpr)}, 6")
-    emit(f"s_lshl_b32 {s(S_T1)}, {s(S_WAVE)}, 4")
-    emit(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_T1)}")
     if do_k:
         emit(f"s_mul_hi_u32 {s(sk_tmp + 1)}, {s(S_T0)}, {s(S_KRS)}")
         emit(f"s_mul_i32 {s(sk_tmp)}, {s(S_T0)}, {s(S_KRS)}")
@@ -200,6 +224,60 @@ def dma_ragged(n_sgpr, do_k, kbuf_imm, do_v, vbuf_imm):
             emit("s_nop 0")
             emit(f"global_load_lds_dwordx4 {vr(T[4], 2)}, off")
 
+
+def dma_bases():
+    """Tile bases for the spread placement: K(i+2) -> S_TB, V(i+1) -> S_VB, relative to the tile's first row (clamped so
+    that a ragged tile never reads past the tensor; such a tile is re-staged by dma_fixup at the end of the step)."""
+    emit(f"s_mov_b32 {s(S_RAG)}, 0")
+    for (n_sgpr, rs, base, dst, bit) in ((S_N2, S_KRS, S_KBASE, S_TB, 1), (S_N1, S_VRS, S_VBASE, S_VB, 2)):
+        emit(f"s_lshl_b32 {s(S_T0)}, {s(n_sgpr)}, 6")
+        emit(f"s_cmp_gt_u32 {s(S_T0)}, {s(S_SAFEROW)}")
+        emit(f"s_cselect_b32 {s(S_T1)}, {bit}, 0")
+        emit(f"s_or_b32 {s(S_RAG)}, {s(S_RAG)}, {s(S_T1)}")
+        emit(f"s_min_u32 {s(S_T0)}, {s(S_T0)}, {s(S_SAFEROW)}")
+        emit(f"s_mul_hi_u32 {s(dst + 1)}, {s(S_T0)}, {s(rs)}")
+        emit(f"s_mul_i32 {s(dst)}, {s(S_T0)}, {s(rs)}")
+        emit(f"s_add_u32 {s(dst)}, {s(dst)}, {s(base)}")
+        emit(f"s_addc_u32 {s(dst + 1)}, {s(dst + 1)}, {s(base + 1)}")
+
+
+def piece_pre(kind, j, kbuf_imm, vbuf_imm):
+    imm = (kbuf_imm if kind == "k" else V_REGION + vbuf_imm) + j * 1024
+    emit(f"s_add_u32 m0, {s(S_DMAW)}, {imm}")
+
+
+def piece_load(kind, j):
+    if kind == "k":
+        emit(f"global_load_lds_dwordx4 {v(LK[j])}, {sr(S_TB)}")
+    else:
+        emit(f"global_load_lds_dwordx4 {v(LV[j])}, {sr(S_VB)}")
+
+
+def dma_fixup(kbuf_imm, vbuf_imm):
+    """Rare: a staged tile was ragged (rows past seqlen_k): re-stage it with per-lane clamped rows after the fast pieces."""
+    done = new_label("fix_done")
+    nov = new_label("fix_nov")
+    emit(f"s_cmp_eq_u32 {s(S_RAG)}, 0")
+    emit(f"s_cbranch_scc1 {done}")
+    emit("s_waitcnt vmcnt(0)")
+    emit(f"s_bitcmp1_b32 {s(S_RAG)}, 0")
+    emit(f"s_cbranch_scc0 {nov}")
+    dma_ragged(S_N2, True, kbuf_imm, False, 0)
+    label(nov)
+    emit(f"s_bitcmp1_b32 {s(S_RAG)}, 1")
+    emit(f"s_cbranch_scc0 {done}")
+    dma_ragged(S_N1, False, 0, True, vbuf_imm)
+    label(done)
+
+
+PLACEMENTS = {   # piece order V0..V3 then K0..K3 unless stated: (phase, slot) per piece
+    "p1": [(1, t) for t in (1, 3, 5, 7, 9, 11, 13, 15)],
+    "p1a": [(1, t) for t in range(8)],
+    "p1b": [(1, t) for t in range(8, 16)],
+    "p2": [(2, t) for t in range(8)],
+    "p2s": [(2, t) for t in (0, 2, 4, 6, 8, 10, 12, 14)],
+    "mix": [(1, 3), (1, 7), (1, 11), (1, 15), (2, 1), (2, 3), (2, 5), (2, 7)],
+}
 
 uid = [0]
 
@@ -334,28 +412,50 @@ def step(variant):
     lg.issue("n1")
     emit(f"ds_read_b32 {v(T[6])}, {v(T[4])}")
     lg.issue("n2")
-    for j in range(4):
-        k_read(lg, j, kbuf_next, j)
+    ord1 = [(t & 1) * 8 + (t >> 1) for t in range(16)] if ILV else list(range(16))     # t -> K fragment j = 8*kb + ks
+    ord2 = [(t & 3) * 4 + (t >> 2) for t in range(16)] if ILV else list(range(16))     # t -> V^T fragment m = 4*db + kk
+    for t in range(4):
+        k_read(lg, t, kbuf_next, ord1[t])
     lg.wait_for("n2")
     emit(f"v_readfirstlane_b32 {s(S_N1)}, {v(T[5])}")
     emit(f"v_readfirstlane_b32 {s(S_N2)}, {v(T[6])}")
     emit("s_nop 3")
-    dma_tile(S_N2, True, kbuf_stage, False, 0)
-    dma_tile(S_N1, False, 0, True, vbuf_stage)
+    if "dmal2" in OPT:      # ablation: every step re-stages tile 0 (always L2-hot)
+        emit(f"s_mov_b32 {s(S_N1)}, 0")
+        emit(f"s_mov_b32 {s(S_N2)}, 0")
+    plan = {}
+    if "nodma" not in OPT:
+        if DMA_PLACE == "head":
+            dma_tile(S_N2, True, kbuf_stage, False, 0)
+            dma_tile(S_N1, False, 0, True, vbuf_stage)
+        else:
+            dma_bases()
+            order = [("v", j) for j in range(4)] + [("k", j) for j in range(4)]
+            for pc, where in zip(order, PLACEMENTS[DMA_PLACE]):
+                if "dmahalf" in OPT and pc[0] == "v":
+                    continue
+                plan[where] = pc
 
     # ---- phase 1: QK^T(i+1) || softmax(i)
     emit(f"v_mov_b32 {v(PSUM)}, 0")
     emit(f"v_mov_b32 {v(T[2])}, 0")
-    for j in range(16):
+    for t in range(16):
+        j = ord1[t]
         lg.wait_for(("k", j))
         kb, ks = j >> 3, j & 7
-        mfma(snxt[kb], KF[j % 4], Q[ks], c_init_zero=(ks == 0))
-        if j + 4 < 16:
-            k_read(lg, j % 4, kbuf_next, j + 4)
-        elif j >= 12:
-            # K reads are all issued: start the V^T fragment ring (fragment m = j - 12)
-            v_read(lg, j - 12, vbuf_cur, j - 12)
-        softmax_pair(scur, j)
+        pc = plan.get((1, t))
+        if pc:
+            piece_pre(pc[0], pc[1], kbuf_stage, vbuf_stage)
+        if "nomfma1" not in OPT:
+            mfma(snxt[kb], KF[t % 4], Q[ks], c_init_zero=(ks == 0))
+        if t + 4 < 16:
+            k_read(lg, t % 4, kbuf_next, ord1[t + 4])
+        elif t >= 12:
+            # K reads are all issued: start the V^T fragment ring
+            v_read(lg, t - 12, vbuf_cur, ord2[t - 12])
+        if pc:
+            piece_load(pc[0], pc[1])
+        softmax_pair(scur, t)
     emit(f"v_add_f32 {v(PSUM)}, {v(PSUM)}, {v(T[2])}")
     emit(f"v_fma_f32 {v(LRUN)}, {v(LRUN)}, {v(ALPHA)}, {v(PSUM)}")
 
@@ -365,22 +465,34 @@ def step(variant):
     per_slot = [[] for _ in range(16)]
     for idx, op in enumerate(rmax):
         per_slot[min(15, 2 + idx)].append(op) if idx < 9 else per_slot[min(15, idx)].append(op)
-    for m in range(16):
+    for t in range(16):
+        m = ord2[t]
         lg.wait_for(("v", m, 1))
         db, kk = m >> 2, m & 3
-        mfma(O[db], VF[m % 4], PF[kk])
-        if m + 4 < 16:
-            v_read(lg, m % 4, vbuf_cur, m + 4)
-        for op in per_slot[m]:
-            emit(op)
+        pc = plan.get((2, t))
+        if pc:
+            piece_pre(pc[0], pc[1], kbuf_stage, vbuf_stage)
+        if "nomfma2" not in OPT:
+            mfma(O[db], VF[t % 4], PF[kk])
+        if t + 4 < 16:
+            v_read(lg, t % 4, vbuf_cur, ord2[t + 4])
+        if pc:
+            piece_load(pc[0], pc[1])
+        if "norowmax" not in OPT:
+            for op in per_slot[t]:
+                emit(op)
     lg.drain()
+    if plan:
+        dma_fixup(kbuf_stage, vbuf_stage)
 
     # ---- tail
     emit(f"s_add_u32 {s(S_T2)}, {s(S_I)}, 1")
-    stats_tail(S_T2, S_HASNEXT)
-    rescale_o()
-    emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    emit("s_barrier")
+    if "notail" not in OPT:
+        stats_tail(S_T2, S_HASNEXT)
+        rescale_o()
+    emit("s_waitcnt lgkmcnt(0)" if "nowaitvm" in OPT else "s_waitcnt vmcnt(0) lgkmcnt(0)")
+    if "nobarrier" not in OPT:
+        emit("s_barrier")
     emit(f"s_add_u32 {s(S_I)}, {s(S_I)}, 1")
 
 
@@ -400,6 +512,10 @@ def prologue():
         emit(f"v_readfirstlane_b32 {s(sg)}, {v(O[0] + idx)}")
     emit("s_nop 4")
     emit(f"s_sub_u32 {s(S_NM1)}, {s(S_NTILES)}, 1")
+    emit(f"s_sub_u32 {s(S_SAFEROW)}, {s(S_LASTROW)}, 63")
+    emit(f"s_max_i32 {s(S_SAFEROW)}, {s(S_SAFEROW)}, 0")
+    emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, 12")
+    emit(f"s_add_u32 {s(S_DMAW)}, {s(S_DMAW)}, {s(S_LDS)}")
     emit(f"s_mov_b32 {s(S_I)}, 0")
     emit(f"s_mov_b32 {s(S_DOMASK)}, 1")        # the first walked tile is never flagged (softmax.h:153)
 
@@ -439,8 +555,8 @@ def prologue():
     emit(f"v_xor_b32 {v(T[8])}, {v(T[2])}, {v(T[8])}")
     emit(f"v_lshlrev_b32 {v(T[8])}, 4, {v(T[8])}")            # T8 = (cpos ^ (rip<<2)) << 4 (kept for the ragged path)
     for j in range(4):
-        # LK[j] = (4j + rip) * k_rs + (T7 ^ (j<<6)) ; LV[j] = (4j + rip) * v_rs + T8
-        emit(f"v_add_u32 {v(T[4])}, {4 * j}, {v(T[6])}")
+        # LK[j] = (16w + 4j + rip) * k_rs + (T7 ^ (j<<6)) ; LV[j] = (16w + 4j + rip) * v_rs + T8   (relative to the tile)
+        emit(f"v_add_u32 {v(T[4])}, {4 * j}, {v(RIPROW)}")
         emit(f"v_mul_lo_u32 {v(LK[j])}, {v(T[4])}, {s(S_KRS)}")
         emit(f"v_xor_b32 {v(T[5])}, {j << 6}, {v(T[7])}")
         emit(f"v_add_u32 {v(LK[j])}, {v(LK[j])}, {v(T[5])}")
