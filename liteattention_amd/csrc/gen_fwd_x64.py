@@ -1,0 +1,761 @@
+#!/usr/bin/env python
+"""Generates la_fwd_x64_body.inc: hand-scheduled gfx950 main loop of the bf16 / head_dim-128 QK-Skip forward with
+ONE wave per SIMD and 64 query rows per wave (q-tile 256 x k-tile 64, one 4-wave workgroup per CU).
+
+Why this shape (measured): with two 32-row waves per SIMD the MFMA pipe idles 37 % of the
+cycles and the chip clocks at 1.69 GHz, because every wave re-reads the whole K/V tile from LDS for only 32 rows and
+the two unsynchronised waves fight for issue slots. One wave with the whole 512-register file halves the LDS bytes
+per FLOP, and its single in-order stream is scheduled here gap by gap.
+
+Register file (per lane):  AGPR  a[0:127]   O^T  (2 q-blocks x 4 d-blocks x 16)
+                                 a[128:191] Q    (2 q-blocks x 8 k-steps x 4, B operand of S^T = K Q^T)
+                                 a[192:255] K    fragments of the NEXT tile (16 x 4, A operand)
+                           VGPR  v[0:63] / v[64:127]  S^T ping / pong (2 key blocks x 2 q-blocks x 16); P (bf16) is
+                                 compacted IN PLACE into the first 4 registers of every 8, which is exactly the B operand
+                                 of the PV MFMA, so P needs no registers of its own
+                                 v[128:159] V^T fragment ring (8 x 4), then addresses / running state / temporaries.
+
+Step i (S_cur = scores of tile i, partly exponentiated; K fragments of tile i+1 in AGPRs; V(i), K(i+2) in LDS):
+  phase 1  32 MFMA  S_nxt = K(i+1) Q^T   ||  rest of P(i) = exp2(S_cur*c - m_ref*c), row sums, bf16 compaction;
+                                              LDS-DMA issue of V(i+1), K(i+3); first 8 V^T fragment reads
+  phase 2  32 MFMA  O^T += V(i)^T P(i)^T ||  K(i+2) fragment reads -> AGPRs; remaining V^T fragment reads; row max of
+                                              S_nxt, running max, skip vote, lazy-rescale decision; first part of P(i+1)
+  tail     rare O rescale, vmcnt/lgkmcnt drain, ONE barrier.
+Lazy rescale: O and l are kept relative to a reference max m_ref that only follows the true running max m_true when
+it has grown by more than `tau` (log2 units); P stays <= 2^tau. The skip vote uses m_true, so lists are bit-exact.
+"""
+import os
+import sys
+
+OPT = set(x for x in os.environ.get("LA_X64_OPT", "").split(",") if x)
+
+
+def opt_val(key, default):
+    for o in OPT:
+        if o.startswith(key + ":"):
+            return o[len(key) + 1:]
+    return default
+
+
+XPAIRS = int(opt_val("x", "5"))          # pair-groups (of 16; one group = the same pair of both q-blocks) done in phase 2
+CAP1 = int(opt_val("cap1", "0"))          # fillers per MFMA gap the distributor may place (0 = balance evenly)
+CAP2 = int(opt_val("cap2", "0"))
+DMA_GAPS = [int(x) for x in opt_val("dmagaps", "1,2,4,6,8,10,11,13,15,17").split(",")]   # m0K,K0..3,m0V,V0..3 (phase 1)
+
+# ---------------------------------------------------------------- AGPR map
+def O_(qb, db):
+    return 64 * qb + 16 * db
+
+
+def QA(qb, ks):
+    return 128 + 32 * qb + 4 * ks
+
+
+def KA(j):
+    return 192 + 4 * j
+
+
+# ---------------------------------------------------------------- VGPR map
+def S_(sset, kb, qb):
+    return 64 * sset + 32 * kb + 16 * qb
+
+
+VF = [128 + 4 * i for i in range(8)]
+KADDR = list(range(160, 168))
+VADDR = list(range(168, 172))
+LK = list(range(172, 176))
+LV = list(range(176, 180))
+MTRUE, MREF, NMS, L0, L1, MLOC, MLOC2, ALPHA = ([180, 181], [182, 183], [184, 185], [186, 187], [188, 189], [190, 191],
+                                                [192, 193], [194, 195])
+T = list(range(196, 212))                 # temporaries; (T[4],T[5]) even-aligned 64-bit pair
+NEGINF, HH4, LANE, RIPROW = 212, 213, 214, 215
+QROW = [216, 217]
+RAGK, RAGV = 218, 219                     # ragged-path swizzled chunk offsets (constants)
+
+# ---------------------------------------------------------------- SGPR map (s32-s34 are ABI-reserved: unused)
+S_KBASE, S_VBASE, S_QBASE = 36, 38, 40    # 64-bit
+S_TB, S_VB, S_EXEC, S_T64, S_T64B = 42, 44, 46, 48, 50   # 64-bit temps
+(S_KRS, S_VRS, S_LASTROW, S_NTILES, S_C, S_THR, S_TAILVALID, S_KTM1, S_SEQ, S_DOFLAGS, S_WAVE, S_I, S_DOMASK,
+ S_NA, S_NB, S_NC, S_LDS, S_T0, S_T1, S_T2, S_T3, S_NM1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_PARAM, S_HASNEXT, S_NEGC,
+ S_SAFEROW, S_DMAW, S_RAG, S_TAU, S_RESC, S_NCUR) = range(52, 87)
+
+KV_TILE = 16384
+V_REGION = 32768
+
+out = []          # IR: str | ("LDS", str, tag) | ("WAIT", tag) | ("DRAIN",)
+
+
+def emit(x):
+    out.append(x if isinstance(x, tuple) else "    " + x)
+
+
+def label(s):
+    out.append(s + ":")
+
+
+def v(i):
+    return f"v{i}"
+
+
+def vr(a, n):
+    return f"v[{a}:{a + n - 1}]"
+
+
+def ar(a, n):
+    return f"a[{a}:{a + n - 1}]"
+
+
+def s(i):
+    return f"s{i}"
+
+
+def sr(a, n=2):
+    return f"s[{a}:{a + n - 1}]"
+
+
+uid = [0]
+
+
+def new_label(prefix):
+    uid[0] += 1
+    return f".LX{prefix}_{uid[0]}_%="
+
+
+def finalize(items):
+    """Counted lgkmcnt waits: LDS operations of one wave return in order."""
+    lines, q = [], []
+    for it in items:
+        if isinstance(it, str):
+            lines.append(it)
+        elif it[0] == "LDS":
+            lines.append("    " + it[1])
+            q.append(it[2])
+        elif it[0] == "WAIT":
+            if it[1] in q:
+                idx = max(i for i, t in enumerate(q) if t == it[1])
+                lines.append(f"    s_waitcnt lgkmcnt({min(len(q) - 1 - idx, 15)})")
+                q = q[idx + 1:]
+        elif it[0] == "DRAIN":
+            lines.append("    s_waitcnt vmcnt(0) lgkmcnt(0)")
+            q = []
+    return lines
+
+
+# ---------------------------------------------------------------- building blocks (return item lists)
+def k_read(kbuf_imm, j):
+    kb, ks = j >> 3, j & 7
+    return ("LDS", f"ds_read_b128 {ar(KA(j), 4)}, {v(KADDR[ks])} offset:{kbuf_imm + kb * 8192}", ("k", j))
+
+
+def v_read(slot, vbuf_imm, m):
+    db, kk = m >> 2, m & 3
+    return [("LDS", f"ds_read_b64_tr_b16 {vr(VF[slot], 2)}, {v(VADDR[db])} offset:{vbuf_imm + kk * 4096}", ("v", m, 0)),
+            ("LDS", f"ds_read_b64_tr_b16 {vr(VF[slot] + 2, 2)}, {v(VADDR[db])} offset:{vbuf_imm + kk * 4096 + 2048}", ("v", m, 1))]
+
+
+def mfma_qk(sset, j, qb):
+    kb, ks = j >> 3, j & 7
+    d = S_(sset, kb, qb)
+    c = "0" if ks == 0 else vr(d, 16)
+    return f"    v_mfma_f32_32x32x16_bf16 {vr(d, 16)}, {ar(KA(j), 4)}, {ar(QA(qb, ks), 4)}, {c}"
+
+
+def mfma_pv(sset, slot, m, qb):
+    db, kk = m >> 2, m & 3
+    pf = S_(sset, kk >> 1, qb) + 8 * (kk & 1)
+    return f"    v_mfma_f32_32x32x16_bf16 {ar(O_(qb, db), 16)}, {vr(VF[slot], 4)}, {vr(pf, 4)}, {ar(O_(qb, db), 16)}"
+
+
+def softmax_group(sset, p):
+    """Pair p (elements 2p, 2p+1 of the 32 per lane) of BOTH q-blocks, interleaved: 14 VALU."""
+    if "nosoftmax" in OPT:
+        return []
+    ops = [[], [], [], []]
+    for qb in (0, 1):
+        e0 = 2 * p
+        kb, r = e0 >> 4, e0 & 15
+        r0 = S_(sset, kb, qb) + r
+        r1 = r0 + 1
+        dst = S_(sset, kb, qb) + 8 * (r >> 3) + ((r & 7) >> 1)
+        ta, tb = T[8 + 2 * qb], T[9 + 2 * qb]
+        ops[0] += [f"    v_fma_f32 {v(ta)}, {v(r0)}, {s(S_C)}, {v(NMS[qb])}", f"    v_fma_f32 {v(tb)}, {v(r1)}, {s(S_C)}, {v(NMS[qb])}"]
+        ops[1] += [f"    v_exp_f32 {v(r0)}, {v(ta)}", f"    v_exp_f32 {v(r1)}, {v(tb)}"]
+        ops[2] += [f"    v_add_f32 {v(L0[qb])}, {v(L0[qb])}, {v(r0)}", f"    v_add_f32 {v(L1[qb])}, {v(L1[qb])}, {v(r1)}"]
+        ops[3] += [f"    v_cvt_pk_bf16_f32 {v(dst)}, {v(r0)}, {v(r1)}"]
+    return ops[0] + ops[1] + ops[2] + ops[3]
+
+
+def row_max_ops(sset):
+    """In-lane max of the 32 scores of each q-block into MLOC[qb] (two max3 chains each), interleaved over q-blocks."""
+    per = []
+    for qb in (0, 1):
+        regs = [S_(sset, 0, qb) + r for r in range(16)] + [S_(sset, 1, qb) + r for r in range(16)]
+        ops = [f"    v_max_f32 {v(MLOC[qb])}, {v(regs[0])}, {v(regs[1])}", f"    v_max_f32 {v(MLOC2[qb])}, {v(regs[2])}, {v(regs[3])}"]
+        rest = regs[4:]
+        chains = [MLOC[qb], MLOC2[qb]]
+        for n_, i in enumerate(range(0, len(rest), 2)):
+            ch = chains[n_ & 1]
+            ops.append(f"    v_max3_f32 {v(ch)}, {v(ch)}, {v(rest[i])}, {v(rest[i + 1])}")
+        ops.append(f"    v_max_f32 {v(MLOC[qb])}, {v(MLOC[qb])}, {v(MLOC2[qb])}")
+        per.append(ops)
+    return [x for pair in zip(*per) for x in pair]
+
+
+def stats_ops(pos_sgpr, valid_sgpr, rare_label, back_label, flush_label, flush_back, inval_label=None, inval_back=None):
+    """Half-wave max exchange, true running max, skip vote (one bit per position, OR over both q-blocks), lazy-rescale test."""
+    o = []
+    a = o.append
+    a(f"    v_mov_b32 {v(T[0])}, {v(MLOC[0])}")
+    a(f"    v_mov_b32 {v(T[1])}, {v(MLOC[1])}")
+    a("    s_nop 0")
+    a(f"    v_permlane32_swap_b32 {v(MLOC[0])}, {v(T[0])}")
+    a(f"    v_permlane32_swap_b32 {v(MLOC[1])}, {v(T[1])}")
+    a("    s_nop 0")
+    a(f"    v_max_f32 {v(MLOC[0])}, {v(MLOC[0])}, {v(T[0])}")
+    a(f"    v_max_f32 {v(MLOC[1])}, {v(MLOC[1])}, {v(T[1])}")
+    if valid_sgpr is not None:          # a clamped duplicate past the end of the walk must not touch the state
+        a(f"    s_cmp_lg_u32 {s(valid_sgpr)}, 0")
+        a("    s_cselect_b64 vcc, -1, 0")
+        a(f"    v_cndmask_b32 {v(MLOC[0])}, {v(NEGINF)}, {v(MLOC[0])}, vcc")
+        a(f"    v_cndmask_b32 {v(MLOC[1])}, {v(NEGINF)}, {v(MLOC[1])}, vcc")
+    a(f"    v_mov_b32 {v(T[2])}, {v(MTRUE[0])}")                     # m_prev
+    a(f"    v_mov_b32 {v(T[3])}, {v(MTRUE[1])}")
+    a(f"    v_max_f32 {v(MTRUE[0])}, {v(MTRUE[0])}, {v(MLOC[0])}")
+    a(f"    v_max_f32 {v(MTRUE[1])}, {v(MTRUE[1])}, {v(MLOC[1])}")
+    # vote: (m_loc - m_prev) * c > thr   (softmax.h:194)
+    a(f"    v_sub_f32 {v(T[2])}, {v(MLOC[0])}, {v(T[2])}")
+    a(f"    v_sub_f32 {v(T[3])}, {v(MLOC[1])}, {v(T[3])}")
+    a(f"    v_mul_f32 {v(T[2])}, {s(S_C)}, {v(T[2])}")
+    a(f"    v_mul_f32 {v(T[3])}, {s(S_C)}, {v(T[3])}")
+    a(f"    v_cmp_gt_f32 {sr(S_T64)}, {v(T[2])}, {s(S_THR)}")
+    a(f"    v_cmp_gt_f32 vcc, {v(T[3])}, {s(S_THR)}")
+    a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")
+    a("    s_cmp_lg_u64 vcc, 0")
+    a(f"    s_cselect_b32 {s(S_T0)}, 1, 0")
+    if valid_sgpr is not None:
+        a(f"    s_and_b32 {s(S_T0)}, {s(S_T0)}, {s(valid_sgpr)}")
+    a(f"    s_and_b32 {s(S_T1)}, {s(pos_sgpr)}, 31")
+    a(f"    s_lshl_b32 {s(S_T0)}, {s(S_T0)}, {s(S_T1)}")
+    a(f"    s_or_b32 {s(S_DOMASK)}, {s(S_DOMASK)}, {s(S_T0)}")
+    # lazy rescale: (m_true - m_ref) * c > tau on any lane of either q-block -> rare block
+    a(f"    v_sub_f32 {v(T[2])}, {v(MTRUE[0])}, {v(MREF[0])}")
+    a(f"    v_sub_f32 {v(T[3])}, {v(MTRUE[1])}, {v(MREF[1])}")
+    a(f"    v_mul_f32 {v(T[2])}, {s(S_C)}, {v(T[2])}")
+    a(f"    v_mul_f32 {v(T[3])}, {s(S_C)}, {v(T[3])}")
+    a(f"    v_cmp_gt_f32 {sr(S_T64)}, {v(T[2])}, {s(S_TAU)}")
+    a(f"    v_cmp_gt_f32 vcc, {v(T[3])}, {s(S_TAU)}")
+    a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")
+    a(f"    s_cbranch_vccnz {rare_label}")
+    o.append(back_label + ":")
+    if valid_sgpr is not None:
+        # past the end of the walk: the part of P(i+1) computed in this phase must be 0 (it is added to the row sums)
+        a(f"    s_cmp_eq_u32 {s(valid_sgpr)}, 0")
+        a(f"    s_cbranch_scc1 {inval_label}")
+        o.append(inval_back + ":")
+    # flush the vote word when position & 31 == 31 and the position is real
+    a(f"    s_cmp_eq_u32 {s(S_T1)}, 31")
+    a(f"    s_cselect_b32 {s(S_T0)}, 1, 0")
+    if valid_sgpr is not None:
+        a(f"    s_and_b32 {s(S_T0)}, {s(S_T0)}, {s(valid_sgpr)}")
+    a(f"    s_cmp_lg_u32 {s(S_T0)}, 0")
+    a(f"    s_cbranch_scc1 {flush_label}")
+    o.append(flush_back + ":")
+    return o
+
+
+def rare_rescale_block(rare_label, back_label):
+    """Out of line: m_ref follows m_true; alpha = exp2((m_ref_old - m_true)*c); l *= alpha; O rescale flagged."""
+    label(rare_label)
+    for qb in (0, 1):
+        emit(f"v_sub_f32 {v(T[2 + qb])}, {v(MREF[qb])}, {v(MTRUE[qb])}")
+    for qb in (0, 1):
+        emit(f"v_mul_f32 {v(T[2 + qb])}, {s(S_C)}, {v(T[2 + qb])}")
+    for qb in (0, 1):
+        emit(f"v_exp_f32 {v(ALPHA[qb])}, {v(T[2 + qb])}")
+    for qb in (0, 1):
+        emit(f"v_mov_b32 {v(MREF[qb])}, {v(MTRUE[qb])}")
+    for qb in (0, 1):
+        emit(f"v_mul_f32 {v(NMS[qb])}, {s(S_NEGC)}, {v(MREF[qb])}")
+    for qb in (0, 1):
+        emit(f"v_mul_f32 {v(L0[qb])}, {v(L0[qb])}, {v(ALPHA[qb])}")
+        emit(f"v_mul_f32 {v(L1[qb])}, {v(L1[qb])}, {v(ALPHA[qb])}")
+    emit(f"s_mov_b32 {s(S_RESC)}, 1")
+    emit(f"s_branch {back_label}")
+
+
+def inval_block(lbl, back):
+    """Out of line (last step of a walk): -m_ref*c := -inf, so exp2(S*c - inf) = 0 for the tile that does not exist."""
+    label(lbl)
+    for qb in (0, 1):
+        emit(f"v_mov_b32 {v(NMS[qb])}, {v(NEGINF)}")
+    emit(f"s_branch {back}")
+
+
+def flush_block(flush_label, back_label, pos_sgpr):
+    """Out of line: doflags[pos >> 5] |= domask by one lane; domask = 0. Drains lgkmcnt (keeps counted waits valid)."""
+    label(flush_label)
+    flush_domask(pos_sgpr)
+    emit("s_waitcnt lgkmcnt(0)")
+    emit(f"s_branch {back_label}")
+
+
+def flush_domask(pos_sgpr):
+    emit(f"s_lshr_b32 {s(S_T0)}, {s(pos_sgpr)}, 5")
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_T0)}, 2")
+    emit(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_DOFLAGS)}")
+    emit(f"v_mov_b32 {v(T[4])}, {s(S_T0)}")
+    emit(f"v_mov_b32 {v(T[5])}, {s(S_DOMASK)}")
+    emit(f"s_mov_b64 {sr(S_EXEC)}, exec")
+    emit("s_mov_b64 exec, 1")
+    emit(f"ds_or_b32 {v(T[4])}, {v(T[5])}")
+    emit(f"s_mov_b64 exec, {sr(S_EXEC)}")
+    emit(f"s_mov_b32 {s(S_DOMASK)}, 0")
+
+
+def rescale_o_block(lbl, back):
+    """Out of line (rare): O^T *= alpha for both q-blocks (AGPR -> VGPR -> AGPR), after the PV MFMAs have drained."""
+    label(lbl)
+    emit("s_nop 15")
+    emit("s_nop 15")
+    for qb in (0, 1):
+        for base in range(0, 64, 8):
+            for k in range(8):
+                emit(f"v_accvgpr_read_b32 {v(T[k])}, a{64 * qb + base + k}")
+            for k in range(8):
+                emit(f"v_mul_f32 {v(T[k])}, {v(T[k])}, {v(ALPHA[qb])}")
+            for k in range(8):
+                emit(f"v_accvgpr_write_b32 a{64 * qb + base + k}, {v(T[k])}")
+    emit(f"s_mov_b32 {s(S_RESC)}, 0")
+    emit("s_nop 7")
+    emit(f"s_branch {back}")
+
+
+def dma_bases(n_k, n_v):
+    """Tile bases (clamped so a ragged tile never reads past the tensor; it is re-staged by dma_fixup): K -> S_TB, V -> S_VB."""
+    o = [f"    s_mov_b32 {s(S_RAG)}, 0"]
+    for (n_sgpr, rs, base, dst, bit) in ((n_k, S_KRS, S_KBASE, S_TB, 1), (n_v, S_VRS, S_VBASE, S_VB, 2)):
+        o += [f"    s_lshl_b32 {s(S_T0)}, {s(n_sgpr)}, 6",
+              f"    s_cmp_gt_u32 {s(S_T0)}, {s(S_SAFEROW)}",
+              f"    s_cselect_b32 {s(S_T1)}, {bit}, 0",
+              f"    s_or_b32 {s(S_RAG)}, {s(S_RAG)}, {s(S_T1)}",
+              f"    s_min_u32 {s(S_T0)}, {s(S_T0)}, {s(S_SAFEROW)}",
+              f"    s_mul_hi_u32 {s(dst + 1)}, {s(S_T0)}, {s(rs)}",
+              f"    s_mul_i32 {s(dst)}, {s(S_T0)}, {s(rs)}",
+              f"    s_add_u32 {s(dst)}, {s(dst)}, {s(base)}",
+              f"    s_addc_u32 {s(dst + 1)}, {s(dst + 1)}, {s(base + 1)}"]
+    return o
+
+
+def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True):
+    """[m0K, K0..K3, m0V, V0..V3]: one M0 per tensor, the piece index rides on the instruction offset (applied to both the
+    global and the LDS address; LK/LV are pre-compensated by -1024*j)."""
+    if "nodma" in OPT:
+        return []
+    o = []
+    if do_k:
+        o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {kbuf_imm}")
+        o += [f"    global_load_lds_dwordx4 {v(LK[j])}, {sr(S_TB)} offset:{1024 * j}" for j in range(4)]
+    if do_v:
+        o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {V_REGION + vbuf_imm}")
+        o += [f"    global_load_lds_dwordx4 {v(LV[j])}, {sr(S_VB)} offset:{1024 * j}" for j in range(4)]
+    return o
+
+
+def dma_ragged(n_sgpr, is_k, buf_imm):
+    """Slow path for a tile with rows past seqlen_k: per-lane clamped rows (rare: only tile k_tiles-1 can be ragged)."""
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(n_sgpr)}, 6")
+    rs, base, region, cst = (S_KRS, S_KBASE, 0, RAGK) if is_k else (S_VRS, S_VBASE, V_REGION, RAGV)
+    for j in range(4):
+        emit(f"v_add_u32 {v(T[3])}, {s(S_T0)}, {v(RIPROW)}")
+        if j:
+            emit(f"v_add_u32 {v(T[3])}, {4 * j}, {v(T[3])}")
+        emit(f"v_min_i32 {v(T[3])}, {v(T[3])}, {s(S_LASTROW)}")
+        emit(f"v_mad_u64_u32 {vr(T[4], 2)}, {sr(S_T64)}, {v(T[3])}, {s(rs)}, 0")
+        if is_k:
+            emit(f"v_xor_b32 {v(T[6])}, {j << 6}, {v(cst)}")
+        else:
+            emit(f"v_mov_b32 {v(T[6])}, {v(cst)}")
+        emit(f"v_add_co_u32 {v(T[4])}, vcc, {v(T[4])}, {v(T[6])}")
+        emit(f"v_addc_co_u32 {v(T[5])}, vcc, 0, {v(T[5])}, vcc")
+        emit(f"v_add_co_u32 {v(T[4])}, vcc, {s(base)}, {v(T[4])}")
+        emit(f"v_mov_b32 {v(T[6])}, {s(base + 1)}")
+        emit(f"v_addc_co_u32 {v(T[5])}, vcc, {v(T[5])}, {v(T[6])}, vcc")
+        emit(f"s_add_u32 m0, {s(S_DMAW)}, {region + buf_imm + j * 1024}")
+        emit("s_nop 0")
+        emit(f"global_load_lds_dwordx4 {vr(T[4], 2)}, off")
+
+
+def dma_fixup_block(lbl, back, n_k, kbuf_imm, n_v, vbuf_imm):
+    label(lbl)
+    nov = new_label("fix_nov")
+    emit("s_waitcnt vmcnt(0)")
+    emit(f"s_bitcmp1_b32 {s(S_RAG)}, 0")
+    emit(f"s_cbranch_scc0 {nov}")
+    dma_ragged(n_k, True, kbuf_imm)
+    label(nov)
+    emit(f"s_bitcmp1_b32 {s(S_RAG)}, 1")
+    emit(f"s_cbranch_scc0 {back}")
+    dma_ragged(n_v, False, vbuf_imm)
+    emit(f"s_branch {back}")
+
+
+def n_fill(items):
+    return sum(1 for it in items if not (isinstance(it, str) and it.endswith(":")))
+
+
+def distribute(queue, post, start, cap):
+    """Append the ops of `queue` (order kept) to post[start..31], topping every gap up to `cap` fillers."""
+    q = list(queue)
+    if cap <= 0:
+        total = sum(n_fill(post[t]) for t in range(start, 32)) + n_fill(q)
+        cap = -(-total // (32 - start))
+    for t in range(start, 32):
+        while q and n_fill(post[t]) < cap:
+            post[t].append(q.pop(0))
+            while q and isinstance(q[0], str) and q[0].endswith(":"):      # a label sticks to the op before it
+                post[t].append(q.pop(0))
+    post[31] += q
+
+
+deferred = []     # out-of-line blocks emitted after the loop: callables
+
+
+def step(variant):
+    """One pipeline step; variant = parity of i: S_cur = S set `variant`, K(i+2)/V(i) in LDS buffer `variant`."""
+    cur, nxt = variant, variant ^ 1
+    kbuf_read = cur * KV_TILE                # K(i+2)
+    kbuf_stage = nxt * KV_TILE               # K(i+3) goes where K(i+1) was
+    vbuf_cur = cur * KV_TILE                 # V(i)
+    vbuf_stage = nxt * KV_TILE               # V(i+1)
+    ord1 = [(f & 1) * 8 + (f >> 1) for f in range(16)]       # K fragment order: alternate key blocks
+    ord2 = [(f & 3) * 4 + (f >> 2) for f in range(16)]       # V^T fragment order: kk outer, d-block inner
+
+    # ---- head (SALU): has_next, bases of V(i+1) = tile S_NA and K(i+3) = tile S_NC, address of seq[min(i+4, n-1)]
+    head = [f"    s_add_u32 {s(S_T2)}, {s(S_I)}, 1",
+            f"    s_cmp_lt_u32 {s(S_T2)}, {s(S_NTILES)}",
+            f"    s_cselect_b32 {s(S_HASNEXT)}, 1, 0",
+            f"    s_add_u32 {s(S_T3)}, {s(S_I)}, 4",
+            f"    s_min_u32 {s(S_T3)}, {s(S_T3)}, {s(S_NM1)}",
+            f"    s_lshl_b32 {s(S_T3)}, {s(S_T3)}, 2",
+            f"    s_add_u32 {s(S_T3)}, {s(S_T3)}, {s(S_SEQ)}",
+            f"    v_mov_b32 {v(T[6])}, {s(S_T3)}",
+            ("LDS", f"ds_read_b32 {v(T[7])}, {v(T[6])}", "seq")]
+    head += dma_bases(S_NC, S_NA)
+    for it in head:
+        out.append(it)
+
+    # ---- phase 1: QK^T(i+1) || rest of softmax(i), DMA issue, first V^T fragments
+    pre = [[] for _ in range(32)]
+    post = [[] for _ in range(32)]
+    mf = []
+    for t in range(32):
+        mf.append(mfma_qk(nxt, ord1[t >> 1], t & 1) if "nomfma1" not in OPT else "    s_nop 0")
+    for g, op in zip(DMA_GAPS, dma_ops(kbuf_stage, vbuf_stage)):
+        post[g].append(op)
+    if "novread" not in OPT:
+        for f in range(8):
+            post[16 + 2 * f] += v_read(f, vbuf_cur, ord2[f])
+    vq = []
+    for p in range(XPAIRS, 16):
+        vq += softmax_group(cur, p)
+    distribute(vq, post, 0, CAP1)
+    for t in range(32):
+        for it in pre[t] + [mf[t]] + post[t]:
+            out.append(it)
+
+    # ---- phase 2: PV(i) || K(i+2) fragments -> AGPRs, rest of the V^T fragments, stats(i+1), first part of softmax(i+1)
+    pre = [[] for _ in range(32)]
+    post = [[] for _ in range(32)]
+    mf = []
+    for t in range(32):
+        f = t >> 1
+        if (t & 1) == 0 and "novread" not in OPT:
+            pre[t].append(("WAIT", ("v", ord2[f], 1)))
+        mf.append(mfma_pv(cur, f % 8, ord2[f], t & 1) if "nomfma2" not in OPT else "    s_nop 0")
+        if (t & 1) == 1 and f + 8 < 16 and "novread" not in OPT:
+            post[t] += v_read(f % 8, vbuf_cur, ord2[f + 8])
+        if (t & 1) == 0 and "nokread" not in OPT:
+            post[t].append(k_read(kbuf_read, ord1[f]))
+    post[1] += [("WAIT", "seq"), f"    v_readfirstlane_b32 {s(S_T3)}, {v(T[7])}"]
+    rare, back = new_label("rare"), new_label("rare_back")
+    fl, flback = new_label("flush"), new_label("flush_back")
+    vq = []
+    if "norowmax" not in OPT:
+        vq += row_max_ops(nxt)
+    if "notail" not in OPT:
+        inv, invback = new_label("inval"), new_label("inval_back")
+        vq += stats_ops(S_T2, S_HASNEXT, rare, back, fl, flback, inv, invback)
+        deferred.append(lambda: inval_block(inv, invback))
+        deferred.append(lambda: rare_rescale_block(rare, back))
+        deferred.append(lambda: flush_block(fl, flback, S_T2))
+    for p in range(XPAIRS):
+        vq += softmax_group(nxt, p)
+    distribute(vq, post, 2, CAP2)
+    for t in range(32):
+        for it in pre[t] + [mf[t]] + post[t]:
+            out.append(it)
+
+    # ---- tail: rare O rescale, rare ragged re-stage, drain, barrier, advance the tile shift register
+    resc, resc_back = new_label("resc"), new_label("resc_back")
+    emit(f"s_cmp_lg_u32 {s(S_RESC)}, 0")
+    emit(f"s_cbranch_scc1 {resc}")
+    label(resc_back)
+    deferred.append(lambda: rescale_o_block(resc, resc_back))
+    if "nodma" not in OPT:
+        fix, fix_back = new_label("fix"), new_label("fix_back")
+        emit(f"s_cmp_lg_u32 {s(S_RAG)}, 0")
+        emit(f"s_cbranch_scc1 {fix}")
+        label(fix_back)
+        deferred.append(lambda: dma_fixup_block(fix, fix_back, S_NC, kbuf_stage, S_NA, vbuf_stage))
+    emit(("DRAIN",))
+    if "nobarrier" not in OPT:
+        emit("s_barrier")
+    emit(f"s_mov_b32 {s(S_NA)}, {s(S_NB)}")
+    emit(f"s_mov_b32 {s(S_NB)}, {s(S_NC)}")
+    emit(f"s_mov_b32 {s(S_NC)}, {s(S_T3)}")
+    emit(f"s_add_u32 {s(S_I)}, {s(S_I)}, 1")
+
+
+def prologue():
+    emit("; ---- lane id, parameter block -> SGPRs")
+    emit(f"v_mbcnt_lo_u32_b32 {v(LANE)}, -1, 0")
+    emit(f"v_mbcnt_hi_u32_b32 {v(LANE)}, -1, {v(LANE)}")
+    emit(f"s_mov_b32 {s(S_WAVE)}, %0")
+    emit(f"s_mov_b32 {s(S_PARAM)}, %1")
+    emit(f"v_mov_b32 {v(T[0])}, {s(S_PARAM)}")
+    for q in range(6):
+        emit(f"ds_read_b128 {vr(4 * q, 4)}, {v(T[0])} offset:{16 * q}")
+    emit("s_waitcnt lgkmcnt(0)")
+    plist = [S_KBASE, S_KBASE + 1, S_VBASE, S_VBASE + 1, S_KRS, S_VRS, S_LASTROW, S_NTILES, S_C, S_THR, S_TAILVALID,
+             S_KTM1, S_SEQ, S_DOFLAGS, S_QBASE, S_QBASE + 1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_LDS, S_NEGC, S_TAU]
+    for idx, sg in enumerate(plist):
+        emit(f"v_readfirstlane_b32 {s(sg)}, {v(idx)}")
+    emit("s_nop 4")
+    emit(f"s_sub_u32 {s(S_NM1)}, {s(S_NTILES)}, 1")
+    emit(f"s_sub_u32 {s(S_SAFEROW)}, {s(S_LASTROW)}, 63")
+    emit(f"s_max_i32 {s(S_SAFEROW)}, {s(S_SAFEROW)}, 0")
+    emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, 12")
+    emit(f"s_add_u32 {s(S_DMAW)}, {s(S_DMAW)}, {s(S_LDS)}")
+    emit(f"s_mov_b32 {s(S_I)}, 0")
+    emit(f"s_mov_b32 {s(S_RESC)}, 0")
+    emit(f"s_mov_b32 {s(S_RAG)}, 0")
+    emit(f"v_mov_b32 {v(NEGINF)}, 0xff800000")
+
+    emit("; ---- per-lane constants")
+    emit(f"v_lshrrev_b32 {v(T[0])}, 5, {v(LANE)}")            # hh
+    emit(f"v_lshlrev_b32 {v(HH4)}, 2, {v(T[0])}")
+    emit(f"v_and_b32 {v(T[1])}, 31, {v(LANE)}")               # l31
+    emit(f"v_and_b32 {v(T[2])}, 15, {v(LANE)}")               # a16 / cpos
+    emit(f"v_lshlrev_b32 {v(T[3])}, 8, {v(T[1])}")            # l31 * 256
+    emit(f"v_add_u32 {v(T[3])}, {s(S_LDS)}, {v(T[3])}")
+    for ks in range(8):
+        emit(f"v_add_u32 {v(T[4])}, {2 * ks}, {v(T[0])}")
+        emit(f"v_xor_b32 {v(T[4])}, {v(T[4])}, {v(T[2])}")
+        emit(f"v_lshl_add_u32 {v(KADDR[ks])}, {v(T[4])}, 4, {v(T[3])}")
+    emit(f"v_lshrrev_b32 {v(T[4])}, 2, {v(T[2])}")            # kq = a16 >> 2
+    emit(f"v_add_u32 {v(T[5])}, {v(HH4)}, {v(T[4])}")         # key0
+    emit(f"v_lshlrev_b32 {v(T[5])}, 8, {v(T[5])}")
+    emit(f"v_add_u32 {v(T[5])}, {s(S_LDS)}, {v(T[5])}")
+    emit(f"v_add_u32 {v(T[5])}, {V_REGION}, {v(T[5])}")
+    emit(f"v_lshrrev_b32 {v(T[6])}, 4, {v(LANE)}")            # g = lane >> 4 = rip
+    emit(f"v_and_b32 {v(T[7])}, 1, {v(T[6])}")
+    emit(f"v_lshlrev_b32 {v(T[7])}, 5, {v(T[7])}")
+    emit(f"v_and_b32 {v(T[8])}, 3, {v(T[2])}")                # a3
+    emit(f"v_lshl_or_b32 {v(T[7])}, {v(T[8])}, 3, {v(T[7])}")
+    emit(f"v_add_u32 {v(T[5])}, {v(T[5])}, {v(T[7])}")
+    for db in range(4):
+        emit(f"v_xor_b32 {v(T[7])}, {db}, {v(T[4])}")
+        emit(f"v_lshl_add_u32 {v(VADDR[db])}, {v(T[7])}, 6, {v(T[5])}")
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 4")
+    emit(f"v_add_u32 {v(RIPROW)}, {s(S_T0)}, {v(T[6])}")      # 16*wave + rip
+    emit(f"v_xor_b32 {v(RAGK)}, {v(T[2])}, {v(T[6])}")
+    emit(f"v_lshlrev_b32 {v(RAGK)}, 4, {v(RAGK)}")            # (cpos ^ rip) << 4
+    emit(f"v_lshlrev_b32 {v(RAGV)}, 2, {v(T[6])}")
+    emit(f"v_xor_b32 {v(RAGV)}, {v(T[2])}, {v(RAGV)}")
+    emit(f"v_lshlrev_b32 {v(RAGV)}, 4, {v(RAGV)}")            # (cpos ^ (rip<<2)) << 4
+    emit(f"s_max_i32 {s(S_T1)}, {s(S_LASTROW)}, 63")          # seqlen_k < 64: the only tile is ragged, clamp its rows here
+    for j in range(4):
+        # LK[j] = (16w + 4j + rip)*k_rs + (RAGK ^ (j<<6)) - 1024j ; LV[j] = (16w + 4j + rip)*v_rs + RAGV - 1024j
+        emit(f"v_add_u32 {v(T[4])}, {4 * j}, {v(RIPROW)}")
+        emit(f"v_min_i32 {v(T[4])}, {v(T[4])}, {s(S_T1)}")
+        emit(f"v_mul_lo_u32 {v(LK[j])}, {v(T[4])}, {s(S_KRS)}")
+        emit(f"v_xor_b32 {v(T[5])}, {j << 6}, {v(RAGK)}")
+        emit(f"v_add_u32 {v(LK[j])}, {v(LK[j])}, {v(T[5])}")
+        emit(f"v_mul_lo_u32 {v(LV[j])}, {v(T[4])}, {s(S_VRS)}")
+        emit(f"v_add_u32 {v(LV[j])}, {v(LV[j])}, {v(RAGV)}")
+        if j:
+            emit(f"v_subrev_u32 {v(LK[j])}, {1024 * j}, {v(LK[j])}")
+            emit(f"v_subrev_u32 {v(LV[j])}, {1024 * j}, {v(LV[j])}")
+
+    emit("; ---- Q fragments -> AGPRs: row q_row0 + 64*wave + 32*qb + l31, d = 16*ks + 8*hh; rows past seqlen_q are ZERO rows")
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 6")
+    emit(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_QROW0)}")
+    emit(f"s_sub_u32 {s(S_T1)}, {s(S_SEQLENQ)}, 1")
+    emit(f"v_lshlrev_b32 {v(T[6])}, 4, {v(T[0])}")            # hh * 16 bytes
+    for qb in (0, 1):
+        emit(f"v_add_u32 {v(QROW[qb])}, {s(S_T0)}, {v(T[1])}")
+        if qb:
+            emit(f"v_add_u32 {v(QROW[qb])}, 32, {v(QROW[qb])}")
+        emit(f"v_min_i32 {v(T[3])}, {v(QROW[qb])}, {s(S_T1)}")
+        emit(f"v_mad_u64_u32 {vr(T[4], 2)}, {sr(S_T64)}, {v(T[3])}, {s(S_QRS)}, 0")
+        emit(f"v_add_co_u32 {v(T[4])}, vcc, {v(T[4])}, {v(T[6])}")
+        emit(f"v_addc_co_u32 {v(T[5])}, vcc, 0, {v(T[5])}, vcc")
+        emit(f"v_add_co_u32 {v(T[4])}, vcc, {s(S_QBASE)}, {v(T[4])}")
+        emit(f"v_mov_b32 {v(T[7])}, {s(S_QBASE + 1)}")
+        emit(f"v_addc_co_u32 {v(T[5])}, vcc, {v(T[5])}, {v(T[7])}, vcc")
+        for ks in range(8):
+            emit(f"global_load_dwordx4 {vr(32 * qb + 4 * ks, 4)}, {vr(T[4], 2)}, off offset:{32 * ks}")
+    emit("s_waitcnt vmcnt(0)")
+    for qb in (0, 1):
+        emit(f"v_cmp_gt_i32 vcc, {s(S_SEQLENQ)}, {v(QROW[qb])}")
+        for r in range(32):
+            emit(f"v_cndmask_b32 {v(32 * qb + r)}, 0, {v(32 * qb + r)}, vcc")
+    for r in range(64):
+        emit(f"v_accvgpr_write_b32 a{128 + r}, {v(r)}")
+    emit("; ---- state")
+    for r in range(128):
+        emit(f"v_accvgpr_write_b32 a{r}, 0")
+    for qb in (0, 1):
+        emit(f"v_mov_b32 {v(MTRUE[qb])}, 0xff800000")
+        emit(f"v_mov_b32 {v(L0[qb])}, 0")
+        emit(f"v_mov_b32 {v(L1[qb])}, 0")
+        emit(f"v_mov_b32 {v(ALPHA[qb])}, 1.0")
+
+    emit("; ---- tiles of positions 0..3; K(0) fragments -> AGPRs, S(0) = K(0) Q^T, then K(1) fragments")
+    for p_, dst in ((0, S_NCUR), (1, S_NA), (2, S_NB), (3, S_NC)):
+        emit(f"s_min_u32 {s(S_T0)}, {p_}, {s(S_NM1)}")
+        emit(f"s_lshl_b32 {s(S_T0)}, {s(S_T0)}, 2")
+        emit(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_SEQ)}")
+        emit(f"v_mov_b32 {v(T[6])}, {s(S_T0)}")
+        emit(f"ds_read_b32 {v(T[8 + p_])}, {v(T[6])}")
+    for j in range(16):
+        emit(k_read(0, j))
+    emit(("DRAIN",))
+    for p_, dst in ((0, S_NCUR), (1, S_NA), (2, S_NB), (3, S_NC)):
+        emit(f"v_readfirstlane_b32 {s(dst)}, {v(T[8 + p_])}")
+    ord1 = [(f & 1) * 8 + (f >> 1) for f in range(16)]
+    for t in range(32):
+        out.append(mfma_qk(0, ord1[t >> 1], t & 1))
+    for j in range(16):
+        emit(k_read(KV_TILE, j))
+    emit(("DRAIN",))
+    emit("s_barrier")                                          # every wave has read K(0) and K(1): both K buffers are free
+    # K(2) -> K buffer 0 (tile S_NB). V(1)/K(3) are staged by step 0.
+    for it in dma_bases(S_NB, S_NB):
+        out.append(it)
+    for it in dma_ops(0, 0, do_k=True, do_v=False):
+        out.append(it)
+        if "m0" in it:
+            emit("s_nop 0")
+    emit(f"s_and_b32 {s(S_RAG)}, {s(S_RAG)}, 1")
+    fix, fix_back = new_label("pfix"), new_label("pfix_back")
+    emit(f"s_cmp_lg_u32 {s(S_RAG)}, 0")
+    emit(f"s_cbranch_scc1 {fix}")
+    label(fix_back)
+    deferred.append(lambda: dma_fixup_block(fix, fix_back, S_NB, 0, S_NB, 0))
+    emit("s_nop 7")
+    # seqlen-k mask: only if n0 == k_tiles-1 and tail_valid < 64  (mask.h:44-78; first walked tile only, mainloop...:1626)
+    nomask = new_label("nomask")
+    emit(f"s_cmp_eq_u32 {s(S_NCUR)}, {s(S_KTM1)}")
+    emit(f"s_cbranch_scc0 {nomask}")
+    emit(f"s_cmp_lt_i32 {s(S_TAILVALID)}, 64")
+    emit(f"s_cbranch_scc0 {nomask}")
+    for kb in range(2):
+        for r in range(16):
+            key = 32 * kb + (r & 3) + 8 * (r >> 2)
+            emit(f"v_add_u32 {v(T[0])}, {key}, {v(HH4)}")
+            emit(f"v_cmp_gt_i32 vcc, {s(S_TAILVALID)}, {v(T[0])}")            # key < tail_valid -> keep
+            for qb in (0, 1):
+                emit(f"v_cndmask_b32 {v(S_(0, kb, qb) + r)}, {v(NEGINF)}, {v(S_(0, kb, qb) + r)}, vcc")
+    label(nomask)
+    for op in row_max_ops(0):
+        out.append(op)
+    # first-tile stats: m_true = m_ref = row max; position 0 is never flagged (softmax.h:153)
+    emit(f"v_mov_b32 {v(T[0])}, {v(MLOC[0])}")
+    emit(f"v_mov_b32 {v(T[1])}, {v(MLOC[1])}")
+    emit("s_nop 1")
+    emit(f"v_permlane32_swap_b32 {v(MLOC[0])}, {v(T[0])}")
+    emit(f"v_permlane32_swap_b32 {v(MLOC[1])}, {v(T[1])}")
+    emit("s_nop 1")
+    for qb in (0, 1):
+        emit(f"v_max_f32 {v(MTRUE[qb])}, {v(MLOC[qb])}, {v(T[qb])}")
+    for qb in (0, 1):
+        emit(f"v_mov_b32 {v(MREF[qb])}, {v(MTRUE[qb])}")
+        emit(f"v_mul_f32 {v(NMS[qb])}, {s(S_NEGC)}, {v(MTRUE[qb])}")
+    emit(f"s_mov_b32 {s(S_DOMASK)}, 1")
+    for p in range(XPAIRS):
+        for op in softmax_group(0, p):
+            out.append(op)
+    emit(("DRAIN",))
+    emit("s_barrier")
+
+
+def epilogue():
+    emit("; ---- flush the last vote word, export O^T / m_ref / l through LDS")
+    nofl = new_label("nolastflush")
+    emit(f"s_and_b32 {s(S_T0)}, {s(S_NTILES)}, 31")
+    emit(f"s_cmp_eq_u32 {s(S_T0)}, 0")
+    emit(f"s_cbranch_scc1 {nofl}")
+    emit(f"s_sub_u32 {s(S_T2)}, {s(S_NTILES)}, 1")
+    flush_domask(S_T2)
+    label(nofl)
+    emit("s_nop 15")
+    emit("s_nop 15")
+    # O: register group (qb, db, q4) at lds_base + ((qb*4 + db)*4 + q4)*4096 + tid*16 ; tid = wave*64 + lane
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 10")
+    emit(f"v_lshl_add_u32 {v(T[0])}, {v(LANE)}, 4, {s(S_T0)}")
+    emit(f"v_add_u32 {v(T[0])}, {s(S_LDS)}, {v(T[0])}")
+    for qb in (0, 1):
+        for db in range(4):
+            if (qb * 4 + db) * 16384 >= 65536:
+                pass
+            for q4 in range(4):
+                off = ((qb * 4 + db) * 4 + q4) * 4096
+                if off >= 65536:      # ds offsets are 16 bits: step the address register
+                    continue
+                emit(f"ds_write_b128 {v(T[0])}, {ar(O_(qb, db) + 4 * q4, 4)} offset:{off}")
+    emit(f"v_add_u32 {v(T[1])}, 0x10000, {v(T[0])}")
+    for qb in (0, 1):
+        for db in range(4):
+            for q4 in range(4):
+                off = ((qb * 4 + db) * 4 + q4) * 4096
+                if off < 65536:
+                    continue
+                emit(f"ds_write_b128 {v(T[1])}, {ar(O_(qb, db) + 4 * q4, 4)} offset:{off - 65536}")
+    # m_ref, l: export + (qb*256 + tid)*8
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 9")
+    emit(f"v_lshl_add_u32 {v(T[2])}, {v(LANE)}, 3, {s(S_T0)}")
+    emit(f"v_add_u32 {v(T[2])}, {s(S_EXPORT)}, {v(T[2])}")
+    for qb in (0, 1):
+        emit(f"v_mov_b32 {v(T[4])}, {v(MREF[qb])}")
+        emit(f"v_add_f32 {v(T[5])}, {v(L0[qb])}, {v(L1[qb])}")
+        emit(f"ds_write_b64 {v(T[2])}, {vr(T[4], 2)} offset:{2048 * qb}")
+    emit("s_waitcnt lgkmcnt(0)")
+
+
+def main():
+    prologue()
+    loop, done = new_label("loop"), new_label("done")
+    label(loop)
+    emit(f"s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}")
+    emit(f"s_cbranch_scc0 {done}")
+    step(0)
+    emit(f"s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}")
+    emit(f"s_cbranch_scc0 {done}")
+    step(1)
+    emit(f"s_branch {loop}")
+    for blk in deferred:
+        blk()
+    label(done)
+    epilogue()
+    lines = finalize(out)
+    text = "\n".join(lines)
+    path = sys.argv[1] if len(sys.argv) > 1 else "la_fwd_x64_body.inc"
+    with open(path, "w") as f:
+        f.write("// GENERATED by gen_fwd_x64.py — do not edit. Inline-asm body of la_fwd_bf16_d128_x64_kernel.\n")
+        f.write('R"ASM(\n' + text + '\n)ASM"\n')
+    print(f"wrote {path}: {len(lines)} lines, {text.count('v_mfma')} MFMAs")
+
+
+if __name__ == "__main__":
+    main()

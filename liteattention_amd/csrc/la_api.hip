@@ -16,6 +16,26 @@ namespace {
 thread_local int g_last_hip_error = 0;
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// bf16 / head_dim-128 kernel variant, fixed for the life of the process (env LA_FWD_KERNEL): the skip lists are
+// indexed by the selected kernel's tile, so la_get_tile_sizes and la_fwd must agree on it.
+enum class Bf16Kernel { v2, v1, w8, hand, x64 };
+Bf16Kernel bf16_d128_kernel() {
+    static const Bf16Kernel k = [] {
+        const char* e = getenv("LA_FWD_KERNEL");
+        if (e == nullptr) return Bf16Kernel::v2;
+        if (e[0] == 'v' && e[1] == '1') return Bf16Kernel::v1;
+        if (e[0] == 'w' && e[1] == '8') return Bf16Kernel::w8;
+        if (e[0] == 'a' && e[1] == 's') return Bf16Kernel::hand;
+        if (e[0] == 'x' && e[1] == '6') return Bf16Kernel::x64;
+        return Bf16Kernel::v2;
+    }();
+    return k;
+}
+float rescale_tau() {
+    static const float t = [] { const char* e = getenv("LA_RESCALE_TAU"); return e ? static_cast<float>(atof(e)) : 8.0f; }();
+    return t;
+}
 }  // namespace
 
 extern "C" {
@@ -44,8 +64,9 @@ const char* la_status_string(int status) {
 }
 
 int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n) {
-    const la::TileShape t = la::tile_shape(head_dim, element_size);
+    la::TileShape t = la::tile_shape(head_dim, element_size);
     if (t.block_m == 0) return (element_size == 2 || element_size == 1) ? LA_ERR_HEAD_DIM : LA_ERR_DTYPE;
+    if (element_size == 2 && head_dim == 128 && bf16_d128_kernel() == Bf16Kernel::x64) t.block_m = 256;   // 64 rows per wave
     if (block_m) *block_m = t.block_m;
     if (block_n) *block_n = t.block_n;
     return LA_OK;
@@ -119,6 +140,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     p.k_tiles = (a->seqlen_k + bn - 1) / bn;
     p.scale_log2 = static_cast<float>(static_cast<double>(a->softmax_scale) * 1.4426950408889634);  // flash_api.cpp:125-126
     p.thr = a->thr;                                                                      // flash_api.cpp:930
+    p.rescale_tau = rescale_tau();
     p.read_list = a->read_list;
     p.write_list = a->write_list;
     p.must_do_list = a->must_do_list;
@@ -143,17 +165,22 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         if (e8 != hipSuccess) { g_last_hip_error = static_cast<int>(e8); return LA_ERR_LAUNCH; }
         return LA_OK;
     }
-    // LA_FWD_KERNEL=v1 selects the register-staged kernel (A/B and fallback); default is the pipelined v2.
-    static const bool use_v1 = [] { const char* e = getenv("LA_FWD_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
+    // LA_FWD_KERNEL selects an A/B variant for head_dim 128 (v1 register-staged, w8, asm, x64); default is the pipelined v2.
     const bool skipable = a->read_list != nullptr;                                      // is_skipable, flash_api.cpp:931
-    static const bool use_w8 = [] { const char* e = getenv("LA_FWD_KERNEL"); return e && e[0] == 'w' && e[1] == '8'; }();
-    const bool d128 = a->head_dim == 128;                                               // v1 / w8 are head_dim-128 only
-    const bool w8_fits = la::fwd_w8_lds_bytes(p.k_tiles, nullptr) <= 160 * 1024;
-    static const bool use_asm = [] { const char* e = getenv("LA_FWD_KERNEL"); return e && e[0] == 'a' && e[1] == 's'; }();
-    const hipError_t err = (use_asm && d128)            ? la::launch_fwd_bf16_d128_asm(p, skipable, stream)
-                           : (use_w8 && d128 && w8_fits) ? la::launch_fwd_bf16_d128_w8(p, skipable, stream)
-                           : (use_v1 && d128)          ? la::launch_fwd_bf16_d128(p, skipable, stream)
-                                                       : la::launch_fwd_bf16_v2(p, a->head_dim, skipable, stream);
+    const Bf16Kernel kern = a->head_dim == 128 ? bf16_d128_kernel() : Bf16Kernel::v2;
+    hipError_t err;
+    if (kern == Bf16Kernel::x64) {
+        if (la::fwd_lds_bytes_x64(p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
+        err = la::launch_fwd_bf16_d128_x64(p, skipable, stream);
+    } else if (kern == Bf16Kernel::hand) {
+        err = la::launch_fwd_bf16_d128_asm(p, skipable, stream);
+    } else if (kern == Bf16Kernel::w8 && la::fwd_w8_lds_bytes(p.k_tiles, nullptr) <= 160 * 1024) {
+        err = la::launch_fwd_bf16_d128_w8(p, skipable, stream);
+    } else if (kern == Bf16Kernel::v1) {
+        err = la::launch_fwd_bf16_d128(p, skipable, stream);
+    } else {
+        err = la::launch_fwd_bf16_v2(p, a->head_dim, skipable, stream);
+    }
     if (err != hipSuccess) {
         g_last_hip_error = static_cast<int>(err);
         return LA_ERR_LAUNCH;

@@ -20,6 +20,7 @@ struct FwdParams {
     int q_tiles, k_tiles;
     int seq_cap;            // int32 slots reserved in LDS for the expanded tile sequence
     float scale_log2;       // softmax_scale * log2(e)   (flash_api.cpp:125-126)
+    float rescale_tau;      // x64 kernel: O/l follow the running max only when it grew by more than this (log2 units)
     float thr;
     const int* read_list;
     int* write_list;
@@ -40,6 +41,8 @@ size_t fwd_lds_bytes_v2(int head_dim, int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, hipStream_t stream);   // v2: LDS-DMA, pipelined; head_dim 128 / 64
 size_t fwd_lds_bytes_asm(int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_d128_asm(const FwdParams& p, bool skipable, hipStream_t stream);  // v2 with a hand-scheduled main loop
+size_t fwd_lds_bytes_x64(int k_tiles, int* seq_cap_out);
+hipError_t launch_fwd_bf16_d128_x64(const FwdParams& p, bool skipable, hipStream_t stream);  // 1 wave/SIMD, 64 rows/wave, q-tile 256
 size_t fwd_w8_lds_bytes(int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_d128_w8(const FwdParams& p, bool skipable, hipStream_t stream);   // 8 waves, 256 rows, two list tiles
 size_t fwd_lds_bytes_fp8(int k_tiles, int* seq_cap_out);

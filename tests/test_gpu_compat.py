@@ -7,7 +7,14 @@ import torch
 from helpers import structured_qkv
 
 pytestmark = pytest.mark.gpu
-BM, BN = 128, 64
+
+
+def _tiles():
+    import liteattention_amd as L
+    return L.get_tile_sizes(128, 2)
+
+
+BM, BN = _tiles()       # the lists follow the selected kernel's tile
 
 
 def _tol(o):

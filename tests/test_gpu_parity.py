@@ -20,12 +20,19 @@ from helpers import DENSE_CASES, load_dense_case, ref_tolerance, structured_qkv
 
 pytestmark = pytest.mark.gpu
 
-BM, BN = 128, 64
+def _tiles(head_dim):
+    """The skip lists follow the tile of the kernel the library selected (LA_FWD_KERNEL): ask it, as LiteAttention.get_MN does."""
+    import liteattention_amd as L
+    return L.get_tile_sizes(head_dim, 2)
+
+
+BM, BN = _tiles(128)          # (128, 64) for the default kernels, (256, 64) for the 64-rows-per-wave kernel
+BM64, BN64 = _tiles(64)
 
 
 def _L():
     import liteattention_amd as L
-    assert L.get_tile_sizes(128, 2) == (BM, BN)
+    assert L.get_tile_sizes(128, 2) in ((128, 64), (256, 64))
     return L
 
 
@@ -313,7 +320,7 @@ def test_error_behaviour():
     q96 = torch.randn(1, 256, 2, 96, device="cuda").bfloat16()
     with pytest.raises(RuntimeError):
         L.flash_attn_func(q96, q96, q96)                                       # head_dim not instantiated
-    lists = torch.zeros(1, 2, 2, 5, dtype=torch.int32, device="cuda")
+    lists = torch.zeros(1, 2, 256 // BM, 5, dtype=torch.int32, device="cuda")
     with pytest.raises(RuntimeError, match="attn_read_list"):
         L.flash_attn_func(q, q, q, attn_read_list=lists.long(), attn_write_list=lists)
     with pytest.raises(RuntimeError, match="shape"):
@@ -364,7 +371,7 @@ def test_skip_list_stats_kernel_and_skip_fraction():
     counts = L.skip_list_stats(rl, batch=2).cpu()
     assert counts[0].item() == orc.listed_tiles(rl[:2].cpu()) and counts[1].item() == 2 * 3 * (1536 // BM)
     frac = att.get_skip_fraction(batch=2)
-    assert abs((1 - frac) - orc.listed_tiles(rl[:2].cpu()) / (2 * 3 * 12 * 24)) < 1e-9 and frac > 0.05
+    assert abs((1 - frac) - orc.listed_tiles(rl[:2].cpu()) / (2 * 3 * (1536 // BM) * 24)) < 1e-9 and frac > 0.05
     assert abs(L.LiteAttention.calc_percentage(rl[:2]) - L.LiteAttention.calc_percentage(rl[:2].cpu())) < 1e-12
 
 
@@ -380,7 +387,7 @@ def test_seq_parallel_splits_plus_combine_equal_full_attention():
         o, l = sp(qd, kd[:, j * 256:(j + 1) * 256], vd[:, j * 256:(j + 1) * 256], split_idx=j, return_softmax_lse=True)
         outs.append(o)
         lses.append(l)
-    assert sp.lite_attention[2]._skip_list.shape == (2, 1, 2, 8, 5)          # Kt from the split length
+    assert sp.lite_attention[2]._skip_list.shape == (2, 1, 2, 1024 // BM, 5)  # Kt from the split length
     out, lse = L.flash_attn_combine(torch.stack(outs), torch.stack(lses))
     o_ref, lse_ref = orc.attention_dense_ref(q, k, v)
     o_c, lse_c = orc.attention_combine_ref(torch.stack(outs).float().cpu(), torch.stack(lses).transpose(2, 3).cpu())
@@ -431,10 +438,10 @@ def test_head_dim_64_dense_matches_oracle(shape):
     (1,2048,1,64) is BASELINE.json configs[0]'s shape in bf16."""
     import liteattention_amd as L
     orc = _orc()
-    assert L.get_tile_sizes(64, 2) == (BM, BN)
+    assert L.get_tile_sizes(64, 2) == (BM64, BN64) == (128, 64)
     B, Sq, H, Sk = shape
     q, k, v = _randn(B, Sq, H, D=64, seed=Sq, Sk=Sk)
-    o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN)
+    o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=BM64, block_n=BN64)
     out, lse = L.flash_attn_func(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
     assert (out.float().cpu() - o_ref).abs().max().item() <= _oracle_tol(o_ref)
     assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
@@ -448,9 +455,9 @@ def test_head_dim_64_skip_lists_match_oracle():
     import liteattention_amd as L
     orc = _orc()
     B, S, H, thr = 1, 1536, 3, -3.0
-    Qt, Kt = S // BM, S // BN
+    Qt, Kt = S // BM64, S // BN64
     att = L.LiteAttention(threshold=thr, max_batch_size=B)
-    md_row = orc.expand_must_do_ref([0, 0], BN, Kt + 1)
+    md_row = orc.expand_must_do_ref([0, 0], BN64, Kt + 1)
     margins = torch.empty(B, H, Qt, Kt)
     listed = []
     for step in range(4):
@@ -461,7 +468,7 @@ def test_head_dim_64_skip_lists_match_oracle():
         out, lse = att(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
         rd, wr = att._skip_list[rd_idx].cpu(), att._skip_list[1 - rd_idx].cpu()
         wr_orc = torch.zeros_like(wr)
-        o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN, read_list=rd, write_list=wr_orc,
+        o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=BM64, block_n=BN64, read_list=rd, write_list=wr_orc,
                                            must_do_list=md_row, thr=thr, margins=margins)
         assert (out.float().cpu() - o_ref).abs().max().item() <= _oracle_tol(o_ref)
         assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3

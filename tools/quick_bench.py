@@ -23,9 +23,10 @@ for S, H in [(32768, 40), (75600, 40)]:
         att = L.LiteAttention(max_batch_size=1); att.threshold = float("-inf")
         att(q, k, v)
         for s in (0.42, 0.77):
-            rows = banded_rows(-(-S // 128), -(-S // 64), 128, 64, s)
+            bm, bn = L.get_tile_sizes(128, 2)
+            rows = banded_rows(-(-S // bm), -(-S // bn), bm, bn, s)
             impose_lists(att, rows)
-            fl = executed_flops(rows, H, 1, S, S, 128, 64, 128)
+            fl = executed_flops(rows, H, 1, S, S, bm, bn, 128)
             dt = timeit(lambda: att(q, k, v))
             out.append(f"sparse{int(s*100)} S={S}: {dt*1e3:.2f} ms exec {fl/dt/1e12:.0f} TF")
     del q, k, v
