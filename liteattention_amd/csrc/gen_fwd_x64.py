@@ -78,6 +78,8 @@ S_TB, S_VB, S_EXEC, S_T64, S_T64B = 42, 44, 46, 48, 50   # 64-bit temps
 (S_KRS, S_VRS, S_LASTROW, S_NTILES, S_C, S_THR, S_TAILVALID, S_KTM1, S_SEQ, S_DOFLAGS, S_WAVE, S_I, S_DOMASK,
  S_NA, S_NB, S_NC, S_LDS, S_T0, S_T1, S_T2, S_T3, S_NM1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_PARAM, S_HASNEXT, S_NEGC,
  S_SAFEROW, S_DMAW, S_RAG, S_TAU, S_RESC, S_NCUR) = range(52, 87)
+S_RAG2, S_TB2, S_VB2, S_POS = 87, 88, 90, 92     # second set of DMA bases / ragged flags (the loop is unrolled by two)
+TBS, VBS, RAGS = [S_TB, S_TB2], [S_VB, S_VB2], [S_RAG, S_RAG2]
 
 KV_TILE = 16384
 V_REGION = 32768
@@ -330,10 +332,12 @@ def rescale_o_block(lbl, back):
     emit(f"s_branch {back}")
 
 
-def dma_bases(n_k, n_v):
-    """Tile bases (clamped so a ragged tile never reads past the tensor; it is re-staged by dma_fixup): K -> S_TB, V -> S_VB."""
+def dma_bases(n_k, n_v, st=0):
+    """Tile bases into register set `st` (clamped so a ragged tile never reads past the tensor; such a tile is re-staged by
+    dma_fixup): K -> TBS[st], V -> VBS[st], ragged flags -> RAGS[st]."""
+    S_RAG = RAGS[st]
     o = [f"    s_mov_b32 {s(S_RAG)}, 0"]
-    for (n_sgpr, rs, base, dst, bit) in ((n_k, S_KRS, S_KBASE, S_TB, 1), (n_v, S_VRS, S_VBASE, S_VB, 2)):
+    for (n_sgpr, rs, base, dst, bit) in ((n_k, S_KRS, S_KBASE, TBS[st], 1), (n_v, S_VRS, S_VBASE, VBS[st], 2)):
         o += [f"    s_lshl_b32 {s(S_T0)}, {s(n_sgpr)}, 6",
               f"    s_cmp_gt_u32 {s(S_T0)}, {s(S_SAFEROW)}",
               f"    s_cselect_b32 {s(S_T1)}, {bit}, 0",
@@ -346,7 +350,7 @@ def dma_bases(n_k, n_v):
     return o
 
 
-def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True):
+def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True, st=0):
     """[m0K, K0..K3, m0V, V0..V3]: one M0 per tensor, the piece index rides on the instruction offset (applied to both the
     global and the LDS address; LK/LV are pre-compensated by -1024*j)."""
     if "nodma" in OPT:
@@ -354,10 +358,10 @@ def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True):
     o = []
     if do_k:
         o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {kbuf_imm}")
-        o += [f"    global_load_lds_dwordx4 {v(LK[j])}, {sr(S_TB)} offset:{1024 * j}" for j in range(4)]
+        o += [f"    global_load_lds_dwordx4 {v(LK[j])}, {sr(TBS[st])} offset:{1024 * j}" for j in range(4)]
     if do_v:
         o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {V_REGION + vbuf_imm}")
-        o += [f"    global_load_lds_dwordx4 {v(LV[j])}, {sr(S_VB)} offset:{1024 * j}" for j in range(4)]
+        o += [f"    global_load_lds_dwordx4 {v(LV[j])}, {sr(VBS[st])} offset:{1024 * j}" for j in range(4)]
     return o
 
 
@@ -385,22 +389,52 @@ def dma_ragged(n_sgpr, is_k, buf_imm):
         emit(f"global_load_lds_dwordx4 {vr(T[4], 2)}, off")
 
 
-def dma_fixup_block(lbl, back, n_k, kbuf_imm, n_v, vbuf_imm):
+def seq_at(dst_sgpr, offset):
+    """dst = seq[min(i + offset, n-1)] (rare paths only: a dependent LDS read)."""
+    emit(f"s_add_u32 {s(S_T0)}, {s(S_I)}, {offset}")
+    emit(f"s_min_u32 {s(S_T0)}, {s(S_T0)}, {s(S_NM1)}")
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_T0)}, 2")
+    emit(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_SEQ)}")
+    emit(f"v_mov_b32 {v(T[3])}, {s(S_T0)}")
+    emit(f"ds_read_b32 {v(T[3])}, {v(T[3])}")
+    emit("s_waitcnt lgkmcnt(0)")
+    emit(f"v_readfirstlane_b32 {s(dst_sgpr)}, {v(T[3])}")
+    emit("s_nop 3")
+
+
+def dma_fixup_block(lbl, back, n_k, kbuf_imm, n_v, vbuf_imm, st=0):
+    """n_k / n_v: SGPR holding the tile number, or ("pos", d) = look up seq[min(i + d, n-1)]."""
     label(lbl)
     nov = new_label("fix_nov")
     emit("s_waitcnt vmcnt(0)")
-    emit(f"s_bitcmp1_b32 {s(S_RAG)}, 0")
+    emit(f"s_bitcmp1_b32 {s(RAGS[st])}, 0")
     emit(f"s_cbranch_scc0 {nov}")
+    if isinstance(n_k, tuple):
+        seq_at(S_T1, n_k[1])
+        n_k = S_T1
     dma_ragged(n_k, True, kbuf_imm)
     label(nov)
-    emit(f"s_bitcmp1_b32 {s(S_RAG)}, 1")
+    emit(f"s_bitcmp1_b32 {s(RAGS[st])}, 1")
     emit(f"s_cbranch_scc0 {back}")
+    if isinstance(n_v, tuple):
+        seq_at(S_T1, n_v[1])
+        n_v = S_T1
     dma_ragged(n_v, False, vbuf_imm)
     emit(f"s_branch {back}")
 
 
+def weight(it):
+    """Issue cost in quad-cycles as measured (PMC: SQ_ACTIVE_INST_VALU): a transcendental takes two slots, labels none."""
+    if isinstance(it, str):
+        if it.endswith(":"):
+            return 0
+        if "v_exp_f32" in it:
+            return 2
+    return 1
+
+
 def n_fill(items):
-    return sum(1 for it in items if not (isinstance(it, str) and it.endswith(":")))
+    return sum(weight(it) for it in items)
 
 
 def distribute(queue, post, start, cap):
@@ -421,7 +455,9 @@ deferred = []     # out-of-line blocks emitted after the loop: callables
 
 
 def step(variant):
-    """One pipeline step; variant = parity of i: S_cur = S set `variant`, K(i+2)/V(i) in LDS buffer `variant`."""
+    """One pipeline step; variant = parity of i: S_cur = S set `variant`, K(i+2)/V(i) in LDS buffer `variant`, DMA bases
+    in SGPR set `variant` (computed during the previous step). Nothing but the drain, the barrier and the loop test sits
+    between the last MFMA of a step and the first of the next."""
     cur, nxt = variant, variant ^ 1
     kbuf_read = cur * KV_TILE                # K(i+2)
     kbuf_stage = nxt * KV_TILE               # K(i+3) goes where K(i+1) was
@@ -430,27 +466,13 @@ def step(variant):
     ord1 = [(f & 1) * 8 + (f >> 1) for f in range(16)]       # K fragment order: alternate key blocks
     ord2 = [(f & 3) * 4 + (f >> 2) for f in range(16)]       # V^T fragment order: kk outer, d-block inner
 
-    # ---- head (SALU): has_next, bases of V(i+1) = tile S_NA and K(i+3) = tile S_NC, address of seq[min(i+4, n-1)]
-    head = [f"    s_add_u32 {s(S_T2)}, {s(S_I)}, 1",
-            f"    s_cmp_lt_u32 {s(S_T2)}, {s(S_NTILES)}",
-            f"    s_cselect_b32 {s(S_HASNEXT)}, 1, 0",
-            f"    s_add_u32 {s(S_T3)}, {s(S_I)}, 4",
-            f"    s_min_u32 {s(S_T3)}, {s(S_T3)}, {s(S_NM1)}",
-            f"    s_lshl_b32 {s(S_T3)}, {s(S_T3)}, 2",
-            f"    s_add_u32 {s(S_T3)}, {s(S_T3)}, {s(S_SEQ)}",
-            f"    v_mov_b32 {v(T[6])}, {s(S_T3)}",
-            ("LDS", f"ds_read_b32 {v(T[7])}, {v(T[6])}", "seq")]
-    head += dma_bases(S_NC, S_NA)
-    for it in head:
-        out.append(it)
-
-    # ---- phase 1: QK^T(i+1) || rest of softmax(i), DMA issue, first V^T fragments
+    # ---- phase 1: QK^T(i+1) || rest of softmax(i), DMA issue (V(i+1), K(i+3)), first V^T fragments
     pre = [[] for _ in range(32)]
     post = [[] for _ in range(32)]
     mf = []
     for t in range(32):
         mf.append(mfma_qk(nxt, ord1[t >> 1], t & 1) if "nomfma1" not in OPT else "    s_nop 0")
-    for g, op in zip(DMA_GAPS, dma_ops(kbuf_stage, vbuf_stage)):
+    for g, op in zip(DMA_GAPS, dma_ops(kbuf_stage, vbuf_stage, st=variant)):
         post[g].append(op)
     if "novread" not in OPT:
         for f in range(8):
@@ -463,7 +485,8 @@ def step(variant):
         for it in pre[t] + [mf[t]] + post[t]:
             out.append(it)
 
-    # ---- phase 2: PV(i) || K(i+2) fragments -> AGPRs, rest of the V^T fragments, stats(i+1), first part of softmax(i+1)
+    # ---- phase 2: PV(i) || K(i+2) fragments -> AGPRs, rest of the V^T fragments, next step's DMA bases,
+    #               stats(i+1), first part of softmax(i+1)
     pre = [[] for _ in range(32)]
     post = [[] for _ in range(32)]
     mf = []
@@ -476,43 +499,73 @@ def step(variant):
             post[t] += v_read(f % 8, vbuf_cur, ord2[f + 8])
         if (t & 1) == 0 and "nokread" not in OPT:
             post[t].append(k_read(kbuf_read, ord1[f]))
-    post[1] += [("WAIT", "seq"), f"    v_readfirstlane_b32 {s(S_T3)}, {v(T[7])}"]
     rare, back = new_label("rare"), new_label("rare_back")
     fl, flback = new_label("flush"), new_label("flush_back")
-    vq = []
+    # next step (i+1): V tile = seq[i+2] (S_NB), K tile = seq[min(i+4, n-1)] (read here); position / has_next of this step
+    vq = [f"    s_add_u32 {s(S_T3)}, {s(S_I)}, 4",
+          f"    s_min_u32 {s(S_T3)}, {s(S_T3)}, {s(S_NM1)}",
+          f"    s_lshl_b32 {s(S_T3)}, {s(S_T3)}, 2",
+          f"    s_add_u32 {s(S_T3)}, {s(S_T3)}, {s(S_SEQ)}",
+          f"    v_mov_b32 {v(T[6])}, {s(S_T3)}",
+          ("LDS", f"ds_read_b32 {v(T[7])}, {v(T[6])}", "seq"),
+          f"    s_add_u32 {s(S_POS)}, {s(S_I)}, 1",
+          f"    s_cmp_lt_u32 {s(S_POS)}, {s(S_NTILES)}",
+          f"    s_cselect_b32 {s(S_HASNEXT)}, 1, 0",
+          ("WAIT", "seq"),
+          f"    v_readfirstlane_b32 {s(S_T3)}, {v(T[7])}"]
     if "norowmax" not in OPT:
-        vq += row_max_ops(nxt)
+        rm = row_max_ops(nxt)
+    else:
+        rm = []
+    nb = dma_bases(S_T3, S_NB, st=variant ^ 1) + [f"    s_mov_b32 {s(S_NB)}, {s(S_NC)}", f"    s_mov_b32 {s(S_NC)}, {s(S_T3)}"]
+    # interleave the SALU base arithmetic with the row-max VALU (different issue ports are irrelevant for ONE wave, but
+    # the SALU results are needed late and the VALU chain is latency-bound)
+    mixed = []
+    while rm or nb:
+        if rm:
+            mixed += rm[:2]
+            rm = rm[2:]
+        if nb:
+            mixed.append(nb.pop(0))
+    vq += mixed
     if "notail" not in OPT:
         inv, invback = new_label("inval"), new_label("inval_back")
-        vq += stats_ops(S_T2, S_HASNEXT, rare, back, fl, flback, inv, invback)
+        vq += stats_ops(S_POS, S_HASNEXT, rare, back, fl, flback, inv, invback)
         deferred.append(lambda: inval_block(inv, invback))
         deferred.append(lambda: rare_rescale_block(rare, back))
-        deferred.append(lambda: flush_block(fl, flback, S_T2))
+        deferred.append(lambda: flush_block(fl, flback, S_POS))
     for p in range(XPAIRS):
         vq += softmax_group(nxt, p)
-    distribute(vq, post, 2, CAP2)
+    # the first two gaps may only hold ops that do not read S_nxt (MFMA -> VALU read hazard): the SALU / seq part
+    distribute(vq[:11], post, 0, CAP2 if CAP2 > 0 else 6)
+    distribute(vq[11:], post, 2, CAP2)
     for t in range(32):
         for it in pre[t] + [mf[t]] + post[t]:
             out.append(it)
 
-    # ---- tail: rare O rescale, rare ragged re-stage, drain, barrier, advance the tile shift register
-    resc, resc_back = new_label("resc"), new_label("resc_back")
-    emit(f"s_cmp_lg_u32 {s(S_RESC)}, 0")
-    emit(f"s_cbranch_scc1 {resc}")
-    label(resc_back)
-    deferred.append(lambda: rescale_o_block(resc, resc_back))
-    if "nodma" not in OPT:
-        fix, fix_back = new_label("fix"), new_label("fix_back")
-        emit(f"s_cmp_lg_u32 {s(S_RAG)}, 0")
+    # ---- tail: rare paths (O rescale, ragged re-stage), drain, barrier
+    slow, slow_back = new_label("slow"), new_label("slow_back")
+    emit(f"s_or_b32 {s(S_T0)}, {s(S_RESC)}, {s(RAGS[variant])}")
+    emit(f"s_cmp_lg_u32 {s(S_T0)}, 0")
+    emit(f"s_cbranch_scc1 {slow}")
+    label(slow_back)
+
+    def slow_block():
+        label(slow)
+        resc, resc_back = new_label("resc"), new_label("resc_back")
+        emit(f"s_cmp_lg_u32 {s(S_RESC)}, 0")
+        emit(f"s_cbranch_scc1 {resc}")
+        label(resc_back)
+        fix = new_label("fix")
+        emit(f"s_cmp_lg_u32 {s(RAGS[variant])}, 0")
         emit(f"s_cbranch_scc1 {fix}")
-        label(fix_back)
-        deferred.append(lambda: dma_fixup_block(fix, fix_back, S_NC, kbuf_stage, S_NA, vbuf_stage))
+        emit(f"s_branch {slow_back}")
+        rescale_o_block(resc, resc_back)
+        dma_fixup_block(fix, slow_back, ("pos", 3), kbuf_stage, ("pos", 1), vbuf_stage, st=variant)
+    deferred.append(slow_block)
     emit(("DRAIN",))
     if "nobarrier" not in OPT:
         emit("s_barrier")
-    emit(f"s_mov_b32 {s(S_NA)}, {s(S_NB)}")
-    emit(f"s_mov_b32 {s(S_NB)}, {s(S_NC)}")
-    emit(f"s_mov_b32 {s(S_NC)}, {s(S_T3)}")
     emit(f"s_add_u32 {s(S_I)}, {s(S_I)}, 1")
 
 
@@ -686,6 +739,8 @@ def prologue():
     for p in range(XPAIRS):
         for op in softmax_group(0, p):
             out.append(op)
+    for it in dma_bases(S_NC, S_NA, st=0):
+        out.append(it)
     emit(("DRAIN",))
     emit("s_barrier")
 

@@ -1,27 +1,33 @@
-"""Builds A/B variants of the hand-scheduled kernel: one library per LA_ASM_OPT setting, under build_variants/.
+"""Builds A/B variants of the hand-scheduled kernels: one library per generator-option setting, under build_variants/.
 
-    python tools/asm_variants.py base= nosm=nosoftmax nodma=nodma ...
-    (GPU box)  for f in build_variants/*.so; do LA_FWD_KERNEL=asm LITEATTENTION_AMD_LIB=$f python tools/abl_bench.py; done
-Ablation variants compute wrong results; they only price a component (DESIGN.md section 4.3).
+    python tools/asm_variants.py base= nosm=nosoftmax x_base=x64: x_nodma=x64:nodma ...
+      name=<opts>        gen_fwd_asm.py with LA_ASM_OPT=<opts>      (run with LA_FWD_KERNEL=asm)
+      name=x64:<opts>    gen_fwd_x64.py with LA_X64_OPT=<opts>      (run with LA_FWD_KERNEL=x64)
+    (GPU box)  LA_FWD_KERNEL=.. LITEATTENTION_AMD_LIB=$PWD/build_variants/<name>.so python tools/abl_bench.py
+Ablation variants compute wrong results; they only price a component (DESIGN.md section 4).
 """
 import os, subprocess, sys
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "liteattention_amd", "csrc")
 OUT = os.path.join(ROOT, "build_variants")
-SRC = ["la_fwd_kernel.hip", "la_fwd_kernel_v2.hip", "la_fwd_kernel_asm.hip", "la_fwd_kernel_w8.hip", "la_fwd_kernel_fp8.hip",
-       "la_aux_kernels.hip", "la_api.hip"]
+sys.path.insert(0, ROOT)
 
 
 def build_one(spec):
     name, _, opt = spec.partition("=")
+    x64 = opt.startswith("x64:")
+    if x64:
+        opt = opt[4:]
     inc = os.path.join(OUT, f"{name}.inc")
-    subprocess.run([sys.executable, os.path.join(CSRC, "gen_fwd_asm.py"), inc], check=True, env=dict(os.environ, LA_ASM_OPT=opt),
+    gen, env_key, macro = ("gen_fwd_x64.py", "LA_X64_OPT", "LA_X64_BODY_INC") if x64 else ("gen_fwd_asm.py", "LA_ASM_OPT", "LA_ASM_BODY_INC")
+    subprocess.run([sys.executable, os.path.join(CSRC, gen), inc], check=True, env=dict(os.environ, **{env_key: opt}),
                    stdout=subprocess.DEVNULL)
-    objs = os.path.join(OUT, "common.a")
+    # the other generated include must exist too (default options)
     so = os.path.join(OUT, f"{name}.so")
+    from liteattention_amd.build import SOURCES
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           f'-DLA_ASM_BODY_INC="{inc}"'] + [os.path.join(CSRC, s) for s in SRC] + ["-o", so]
+           f'-D{macro}="{inc}"'] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", so]
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     return so
 

@@ -14,7 +14,7 @@ for d in sys.argv[1:]:
     a = {k: acc[k] / n[k] for k in acc}
     ms = sum(dur) / max(len(dur), 1)
     cyc = a.get("GRBM_GUI_ACTIVE", 0) / 8
-    steps = 40960 * 256
+    steps = int(os.environ.get('WAVE_STEPS', 40960 * 256))
     g = lambda k: a.get(k, 0) / steps
     print(f"{os.path.basename(d)[5:]:12s} {ms:6.2f} ms  clk {cyc/ms/1e6:.2f} GHz  Mcyc {cyc/1e6:6.2f}  mfma_util {a.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/1024/max(cyc,1):.3f}"
           f"  quads/wave-step: total {g('SQ_WAVE_CYCLES'):.0f} active {g('SQ_ACTIVE_INST_ANY'):.0f} issue-stall {g('SQ_WAIT_INST_ANY'):.0f} parked {g('SQ_WAIT_ANY'):.0f} valu {g('SQ_ACTIVE_INST_VALU'):.0f}")
