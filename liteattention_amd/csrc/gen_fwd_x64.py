@@ -71,6 +71,7 @@ T = list(range(196, 212))                 # temporaries; (T[4],T[5]) even-aligne
 NEGINF, HH4, LANE, RIPROW = 212, 213, 214, 215
 QROW = [216, 217]
 RAGK, RAGV = 218, 219                     # ragged-path swizzled chunk offsets (constants)
+MTHR = [220, 221]                         # m_ref + tau/c: the lazy-rescale trigger level
 
 # ---------------------------------------------------------------- SGPR map (s32-s34 are ABI-reserved: unused)
 S_KBASE, S_VBASE, S_QBASE = 36, 38, 40    # 64-bit
@@ -138,7 +139,7 @@ def finalize(items):
                 lines.append(f"    s_waitcnt lgkmcnt({min(len(q) - 1 - idx, 15)})")
                 q = q[idx + 1:]
         elif it[0] == "DRAIN":
-            lines.append("    s_waitcnt vmcnt(0) lgkmcnt(0)")
+            lines.append("    s_waitcnt lgkmcnt(0)" if "nowaitvm" in OPT else "    s_waitcnt vmcnt(0) lgkmcnt(0)")
             q = []
     return lines
 
@@ -168,11 +169,9 @@ def mfma_pv(sset, slot, m, qb):
     return f"    v_mfma_f32_32x32x16_bf16 {ar(O_(qb, db), 16)}, {vr(VF[slot], 4)}, {vr(pf, 4)}, {ar(O_(qb, db), 16)}"
 
 
-def softmax_group(sset, p):
-    """Pair p (elements 2p, 2p+1 of the 32 per lane) of BOTH q-blocks, interleaved: 14 VALU."""
-    if "nosoftmax" in OPT:
-        return []
-    ops = [[], [], [], []]
+def softmax_parts(sset, p):
+    """Pair p (elements 2p, 2p+1 of the 32 per lane) of BOTH q-blocks: (4 fma, 4 exp, 4 add, 2 cvt)."""
+    F, E, A, C = [], [], [], []
     for qb in (0, 1):
         e0 = 2 * p
         kb, r = e0 >> 4, e0 & 15
@@ -180,11 +179,45 @@ def softmax_group(sset, p):
         r1 = r0 + 1
         dst = S_(sset, kb, qb) + 8 * (r >> 3) + ((r & 7) >> 1)
         ta, tb = T[8 + 2 * qb], T[9 + 2 * qb]
-        ops[0] += [f"    v_fma_f32 {v(ta)}, {v(r0)}, {s(S_C)}, {v(NMS[qb])}", f"    v_fma_f32 {v(tb)}, {v(r1)}, {s(S_C)}, {v(NMS[qb])}"]
-        ops[1] += [f"    v_exp_f32 {v(r0)}, {v(ta)}", f"    v_exp_f32 {v(r1)}, {v(tb)}"]
-        ops[2] += [f"    v_add_f32 {v(L0[qb])}, {v(L0[qb])}, {v(r0)}", f"    v_add_f32 {v(L1[qb])}, {v(L1[qb])}, {v(r1)}"]
-        ops[3] += [f"    v_cvt_pk_bf16_f32 {v(dst)}, {v(r0)}, {v(r1)}"]
-    return ops[0] + ops[1] + ops[2] + ops[3]
+        F += [f"    v_fma_f32 {v(ta)}, {v(r0)}, {s(S_C)}, {v(NMS[qb])}", f"    v_fma_f32 {v(tb)}, {v(r1)}, {s(S_C)}, {v(NMS[qb])}"]
+        E += [f"    v_exp_f32 {v(r0)}, {v(ta)}", f"    v_exp_f32 {v(r1)}, {v(tb)}"]
+        A += [f"    v_add_f32 {v(L0[qb])}, {v(L0[qb])}, {v(r0)}", f"    v_add_f32 {v(L1[qb])}, {v(L1[qb])}, {v(r1)}"]
+        C += [f"    v_cvt_pk_bf16_f32 {v(dst)}, {v(r0)}, {v(r1)}"]
+    return F, E, A, C
+
+
+def softmax_group(sset, p):
+    if "nosoftmax" in OPT:
+        return []
+    F, E, A, C = softmax_parts(sset, p)
+    return F + E + A + C
+
+
+def softmax_stream(sset, groups):
+    """Software-pipelined softmax of several pair-groups. A transcendental occupies its unit for ~4 quad-cycles but only
+    two issue slots, so exps are never adjacent: every v_exp of group g is followed by the fma of group g+1 (same temp,
+    just consumed), and the add / cvt of group g-1."""
+    if "nosoftmax" in OPT or not groups:
+        return []
+    if "expblock" in OPT:
+        return [op for p in groups for op in softmax_group(sset, p)]
+    parts = [softmax_parts(sset, p) for p in groups]
+    o = list(parts[0][0])                                   # F(first)
+    n = len(parts)
+    for g in range(n):
+        Fn = parts[g + 1][0] if g + 1 < n else []
+        Ap, Cp = (parts[g - 1][2], parts[g - 1][3]) if g > 0 else ([], [])
+        E = parts[g][1]
+        for k in range(4):
+            o.append(E[k])
+            if Fn:
+                o.append(Fn[k])
+            if Ap:
+                o.append(Ap[k])
+            if Cp and (k & 1):                              # the cvt of a q-block goes after BOTH of its adds (it may
+                o.append(Cp[k >> 1])                        # overwrite r0 in place)
+    o += parts[-1][2] + parts[-1][3]                        # A(last), C(last)
+    return o
 
 
 def row_max_ops(sset):
@@ -204,24 +237,24 @@ def row_max_ops(sset):
 
 
 def stats_ops(pos_sgpr, valid_sgpr, rare_label, back_label, flush_label, flush_back, inval_label=None, inval_back=None):
-    """Half-wave max exchange, true running max, skip vote (one bit per position, OR over both q-blocks), lazy-rescale test."""
+    """Half-wave max exchange, true running max, skip vote (one bit per position, OR over both q-blocks), lazy-rescale test.
+    Independent moves sit in the two-wait-state shadows of v_permlane32_swap instead of s_nops."""
     o = []
     a = o.append
     a(f"    v_mov_b32 {v(T[0])}, {v(MLOC[0])}")
     a(f"    v_mov_b32 {v(T[1])}, {v(MLOC[1])}")
-    a("    s_nop 0")
+    a(f"    v_mov_b32 {v(T[2])}, {v(MTRUE[0])}")                     # m_prev
     a(f"    v_permlane32_swap_b32 {v(MLOC[0])}, {v(T[0])}")
     a(f"    v_permlane32_swap_b32 {v(MLOC[1])}, {v(T[1])}")
-    a("    s_nop 0")
+    a(f"    v_mov_b32 {v(T[3])}, {v(MTRUE[1])}")
     a(f"    v_max_f32 {v(MLOC[0])}, {v(MLOC[0])}, {v(T[0])}")
     a(f"    v_max_f32 {v(MLOC[1])}, {v(MLOC[1])}, {v(T[1])}")
-    if valid_sgpr is not None:          # a clamped duplicate past the end of the walk must not touch the state
-        a(f"    s_cmp_lg_u32 {s(valid_sgpr)}, 0")
-        a("    s_cselect_b64 vcc, -1, 0")
-        a(f"    v_cndmask_b32 {v(MLOC[0])}, {v(NEGINF)}, {v(MLOC[0])}, vcc")
-        a(f"    v_cndmask_b32 {v(MLOC[1])}, {v(NEGINF)}, {v(MLOC[1])}, vcc")
-    a(f"    v_mov_b32 {v(T[2])}, {v(MTRUE[0])}")                     # m_prev
-    a(f"    v_mov_b32 {v(T[3])}, {v(MTRUE[1])}")
+    if valid_sgpr is not None:
+        # a clamped duplicate past the end of the walk must not touch the state: its row max becomes -inf (no vote, no
+        # new max) and -m_ref*c becomes -inf (the part of P(i+1) computed in this phase, added to the row sums, is 0)
+        a(f"    s_cmp_eq_u32 {s(valid_sgpr)}, 0")
+        a(f"    s_cbranch_scc1 {inval_label}")
+        o.append(inval_back + ":")
     a(f"    v_max_f32 {v(MTRUE[0])}, {v(MTRUE[0])}, {v(MLOC[0])}")
     a(f"    v_max_f32 {v(MTRUE[1])}, {v(MTRUE[1])}, {v(MLOC[1])}")
     # vote: (m_loc - m_prev) * c > thr   (softmax.h:194)
@@ -234,32 +267,17 @@ def stats_ops(pos_sgpr, valid_sgpr, rare_label, back_label, flush_label, flush_b
     a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")
     a("    s_cmp_lg_u64 vcc, 0")
     a(f"    s_cselect_b32 {s(S_T0)}, 1, 0")
-    if valid_sgpr is not None:
-        a(f"    s_and_b32 {s(S_T0)}, {s(S_T0)}, {s(valid_sgpr)}")
     a(f"    s_and_b32 {s(S_T1)}, {s(pos_sgpr)}, 31")
     a(f"    s_lshl_b32 {s(S_T0)}, {s(S_T0)}, {s(S_T1)}")
     a(f"    s_or_b32 {s(S_DOMASK)}, {s(S_DOMASK)}, {s(S_T0)}")
-    # lazy rescale: (m_true - m_ref) * c > tau on any lane of either q-block -> rare block
-    a(f"    v_sub_f32 {v(T[2])}, {v(MTRUE[0])}, {v(MREF[0])}")
-    a(f"    v_sub_f32 {v(T[3])}, {v(MTRUE[1])}, {v(MREF[1])}")
-    a(f"    v_mul_f32 {v(T[2])}, {s(S_C)}, {v(T[2])}")
-    a(f"    v_mul_f32 {v(T[3])}, {s(S_C)}, {v(T[3])}")
-    a(f"    v_cmp_gt_f32 {sr(S_T64)}, {v(T[2])}, {s(S_TAU)}")
-    a(f"    v_cmp_gt_f32 vcc, {v(T[3])}, {s(S_TAU)}")
+    # lazy rescale: m_true > m_ref + tau/c on any lane of either q-block -> rare block
+    a(f"    v_cmp_gt_f32 {sr(S_T64)}, {v(MTRUE[0])}, {v(MTHR[0])}")
+    a(f"    v_cmp_gt_f32 vcc, {v(MTRUE[1])}, {v(MTHR[1])}")
     a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")
     a(f"    s_cbranch_vccnz {rare_label}")
     o.append(back_label + ":")
-    if valid_sgpr is not None:
-        # past the end of the walk: the part of P(i+1) computed in this phase must be 0 (it is added to the row sums)
-        a(f"    s_cmp_eq_u32 {s(valid_sgpr)}, 0")
-        a(f"    s_cbranch_scc1 {inval_label}")
-        o.append(inval_back + ":")
-    # flush the vote word when position & 31 == 31 and the position is real
+    # flush the vote word when position & 31 == 31 (a position past the end only ever adds a zero bit)
     a(f"    s_cmp_eq_u32 {s(S_T1)}, 31")
-    a(f"    s_cselect_b32 {s(S_T0)}, 1, 0")
-    if valid_sgpr is not None:
-        a(f"    s_and_b32 {s(S_T0)}, {s(S_T0)}, {s(valid_sgpr)}")
-    a(f"    s_cmp_lg_u32 {s(S_T0)}, 0")
     a(f"    s_cbranch_scc1 {flush_label}")
     o.append(flush_back + ":")
     return o
@@ -278,6 +296,7 @@ def rare_rescale_block(rare_label, back_label):
         emit(f"v_mov_b32 {v(MREF[qb])}, {v(MTRUE[qb])}")
     for qb in (0, 1):
         emit(f"v_mul_f32 {v(NMS[qb])}, {s(S_NEGC)}, {v(MREF[qb])}")
+        emit(f"v_add_f32 {v(MTHR[qb])}, {s(S_TAU)}, {v(MREF[qb])}")
     for qb in (0, 1):
         emit(f"v_mul_f32 {v(L0[qb])}, {v(L0[qb])}, {v(ALPHA[qb])}")
         emit(f"v_mul_f32 {v(L1[qb])}, {v(L1[qb])}, {v(ALPHA[qb])}")
@@ -289,6 +308,7 @@ def inval_block(lbl, back):
     """Out of line (last step of a walk): -m_ref*c := -inf, so exp2(S*c - inf) = 0 for the tile that does not exist."""
     label(lbl)
     for qb in (0, 1):
+        emit(f"v_mov_b32 {v(MLOC[qb])}, {v(NEGINF)}")
         emit(f"v_mov_b32 {v(NMS[qb])}, {v(NEGINF)}")
     emit(f"s_branch {back}")
 
@@ -477,9 +497,7 @@ def step(variant):
     if "novread" not in OPT:
         for f in range(8):
             post[16 + 2 * f] += v_read(f, vbuf_cur, ord2[f])
-    vq = []
-    for p in range(XPAIRS, 16):
-        vq += softmax_group(cur, p)
+    vq = softmax_stream(cur, list(range(XPAIRS, 16)))
     distribute(vq, post, 0, CAP1)
     for t in range(32):
         for it in pre[t] + [mf[t]] + post[t]:
@@ -492,13 +510,13 @@ def step(variant):
     mf = []
     for t in range(32):
         f = t >> 1
-        if (t & 1) == 0 and "novread" not in OPT:
+        if (t & 1) == 0 and "novread" not in OPT and "nowaitv" not in OPT:
             pre[t].append(("WAIT", ("v", ord2[f], 1)))
         mf.append(mfma_pv(cur, f % 8, ord2[f], t & 1) if "nomfma2" not in OPT else "    s_nop 0")
         if (t & 1) == 1 and f + 8 < 16 and "novread" not in OPT:
             post[t] += v_read(f % 8, vbuf_cur, ord2[f + 8])
-        if (t & 1) == 0 and "nokread" not in OPT:
-            post[t].append(k_read(kbuf_read, ord1[f]))
+        if "nokread" not in OPT and (t < 16 if "klate" not in OPT else (t & 1) == 0):
+            post[t].append(k_read(kbuf_read, ord1[t if "klate" not in OPT else f]))
     rare, back = new_label("rare"), new_label("rare_back")
     fl, flback = new_label("flush"), new_label("flush_back")
     # next step (i+1): V tile = seq[i+2] (S_NB), K tile = seq[min(i+4, n-1)] (read here); position / has_next of this step
@@ -511,12 +529,15 @@ def step(variant):
           f"    s_add_u32 {s(S_POS)}, {s(S_I)}, 1",
           f"    s_cmp_lt_u32 {s(S_POS)}, {s(S_NTILES)}",
           f"    s_cselect_b32 {s(S_HASNEXT)}, 1, 0",
-          ("WAIT", "seq"),
-          f"    v_readfirstlane_b32 {s(S_T3)}, {v(T[7])}"]
+          ]
+    n_head = len(vq)
     if "norowmax" not in OPT:
         rm = row_max_ops(nxt)
     else:
         rm = []
+    vq += rm[:8]
+    rm = rm[8:]
+    vq += [("WAIT", "seq"), f"    v_readfirstlane_b32 {s(S_T3)}, {v(T[7])}"]
     nb = dma_bases(S_T3, S_NB, st=variant ^ 1) + [f"    s_mov_b32 {s(S_NB)}, {s(S_NC)}", f"    s_mov_b32 {s(S_NC)}, {s(S_T3)}"]
     # interleave the SALU base arithmetic with the row-max VALU (different issue ports are irrelevant for ONE wave, but
     # the SALU results are needed late and the VALU chain is latency-bound)
@@ -534,11 +555,10 @@ def step(variant):
         deferred.append(lambda: inval_block(inv, invback))
         deferred.append(lambda: rare_rescale_block(rare, back))
         deferred.append(lambda: flush_block(fl, flback, S_POS))
-    for p in range(XPAIRS):
-        vq += softmax_group(nxt, p)
+    vq += softmax_stream(nxt, list(range(XPAIRS)))
     # the first two gaps may only hold ops that do not read S_nxt (MFMA -> VALU read hazard): the SALU / seq part
-    distribute(vq[:11], post, 0, CAP2 if CAP2 > 0 else 6)
-    distribute(vq[11:], post, 2, CAP2)
+    distribute(vq[:n_head], post, 0, CAP2 if CAP2 > 0 else 6)
+    distribute(vq[n_head:], post, 2, CAP2)
     for t in range(32):
         for it in pre[t] + [mf[t]] + post[t]:
             out.append(it)
@@ -735,10 +755,10 @@ def prologue():
     for qb in (0, 1):
         emit(f"v_mov_b32 {v(MREF[qb])}, {v(MTRUE[qb])}")
         emit(f"v_mul_f32 {v(NMS[qb])}, {s(S_NEGC)}, {v(MTRUE[qb])}")
+        emit(f"v_add_f32 {v(MTHR[qb])}, {s(S_TAU)}, {v(MTRUE[qb])}")
     emit(f"s_mov_b32 {s(S_DOMASK)}, 1")
-    for p in range(XPAIRS):
-        for op in softmax_group(0, p):
-            out.append(op)
+    for op in softmax_stream(0, list(range(XPAIRS))):
+        out.append(op)
     for it in dma_bases(S_NC, S_NA, st=0):
         out.append(it)
     emit(("DRAIN",))
