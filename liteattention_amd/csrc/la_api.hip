@@ -19,16 +19,18 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 // bf16 / head_dim-128 kernel variant, fixed for the life of the process (env LA_FWD_KERNEL): the skip lists are
 // indexed by the selected kernel's tile, so la_get_tile_sizes and la_fwd must agree on it.
+// Default: x64 (one wave per SIMD, 64 rows per wave, q-tile 256). The 128-row kernels stay selectable for A/B runs:
+// v2 (hipcc-scheduled, also the head_dim-64 kernel), asm (v2 with a hand-scheduled loop), v1, w8.
 enum class Bf16Kernel { v2, v1, w8, hand, x64 };
 Bf16Kernel bf16_d128_kernel() {
     static const Bf16Kernel k = [] {
         const char* e = getenv("LA_FWD_KERNEL");
-        if (e == nullptr) return Bf16Kernel::v2;
+        if (e == nullptr || e[0] == 0) return Bf16Kernel::x64;
         if (e[0] == 'v' && e[1] == '1') return Bf16Kernel::v1;
+        if (e[0] == 'v' && e[1] == '2') return Bf16Kernel::v2;
         if (e[0] == 'w' && e[1] == '8') return Bf16Kernel::w8;
         if (e[0] == 'a' && e[1] == 's') return Bf16Kernel::hand;
-        if (e[0] == 'x' && e[1] == '6') return Bf16Kernel::x64;
-        return Bf16Kernel::v2;
+        return Bf16Kernel::x64;
     }();
     return k;
 }
@@ -66,7 +68,7 @@ const char* la_status_string(int status) {
 int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n) {
     la::TileShape t = la::tile_shape(head_dim, element_size);
     if (t.block_m == 0) return (element_size == 2 || element_size == 1) ? LA_ERR_HEAD_DIM : LA_ERR_DTYPE;
-    if (element_size == 2 && head_dim == 128 && bf16_d128_kernel() == Bf16Kernel::x64) t.block_m = 256;   // 64 rows per wave
+    if (element_size == 2 && head_dim == 128 && bf16_d128_kernel() != Bf16Kernel::x64) t.block_m = 128;   // A/B kernels: 32 rows per wave
     if (block_m) *block_m = t.block_m;
     if (block_n) *block_n = t.block_n;
     return LA_OK;
@@ -165,7 +167,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         if (e8 != hipSuccess) { g_last_hip_error = static_cast<int>(e8); return LA_ERR_LAUNCH; }
         return LA_OK;
     }
-    // LA_FWD_KERNEL selects an A/B variant for head_dim 128 (v1 register-staged, w8, asm, x64); default is the pipelined v2.
+    // head_dim 128: x64 unless LA_FWD_KERNEL names an A/B variant (v2, asm, v1, w8); head_dim 64: v2.
     const bool skipable = a->read_list != nullptr;                                      // is_skipable, flash_api.cpp:931
     const Bf16Kernel kern = a->head_dim == 128 ? bf16_d128_kernel() : Bf16Kernel::v2;
     hipError_t err;

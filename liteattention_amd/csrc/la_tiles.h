@@ -5,11 +5,12 @@
 // hand-copied Python twin (/root/reference/hopper/lite_attention.py:87-111). The reference keeps two
 // copies that must agree; here Python asks the library.
 //
-// CDNA4 derivation: one wave owns 32 query rows (one 32x32 MFMA column block), a
-// workgroup is 4 waves -> kBlockM = 128 (same q granularity as the reference at d=128). kBlockN = 64
-// keys: K 16 KiB + V 16 KiB per stage, double-buffered = 64 KiB of LDS, so two workgroups share a
-// CU's 160 KiB and each SIMD holds two waves from different workgroups (softmax VALU of one
-// overlaps MFMA of the other).
+// CDNA4 derivation. kBlockN = 64 keys: K 16 KiB + V 16 KiB per stage, double-buffered = 64 KiB
+// of LDS. bf16 head_dim 128 (the headline path): ONE wave per SIMD owning the whole 512-entry register file and 64
+// query rows (two 32x32 MFMA column blocks), a workgroup is 4 waves -> kBlockM = 256; 256 x 64 = 16 Ki scores per
+// skip decision (reference Hopper tile: 128 x 176 = 22 Ki). The other instantiations (bf16 head_dim 64, fp8) keep
+// 32 rows per wave, kBlockM = 128, two workgroups per CU. LA_FWD_KERNEL=v2|asm|v1|w8 selects a 128-row A/B kernel for
+// bf16 head_dim 128, and la_get_tile_sizes then reports 128 (la_api.hip).
 #pragma once
 
 namespace la {
@@ -22,7 +23,7 @@ struct TileShape {
 // element_size: 2 = bf16/fp16, 1 = fp8. Returns {0,0} when no kernel is instantiated.
 constexpr TileShape tile_shape(int head_dim, int element_size) {
     if (element_size == 2) {
-        if (head_dim == 128) return {128, 64};
+        if (head_dim == 128) return {256, 64};
         if (head_dim == 64) return {128, 64};   // K/V tile 8 KiB each: same key granularity, half the LDS
     }
     if (element_size == 1) {

@@ -51,7 +51,7 @@ def test_struct_layout_matches_header(tmp_path):
 
 
 def test_tile_sizes_and_status_strings():
-    assert _cabi.get_tile_sizes(128, 2) == (128, 64) and _cabi.get_tile_sizes(64, 2) == (128, 64)
+    assert _cabi.get_tile_sizes(128, 2) == (256, 64) and _cabi.get_tile_sizes(64, 2) == (128, 64)
     assert _cabi.get_tile_sizes(128, 1) == (128, 64)
     lib = _cabi.load()
     m, n = ctypes.c_int(), ctypes.c_int()
@@ -87,7 +87,7 @@ def test_argument_validation_returns_codes_without_launching():
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_HEAD_DIM        # not instantiated
     a.head_dim = a.head_dim_v = 128
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_TILE_MISMATCH
-    a.block_m, a.block_n = 128, 64
+    a.block_m, a.block_n = 256, 64
     a.read_list = 0x2000
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_LISTS
     a.write_list = 0x3000
@@ -96,10 +96,12 @@ def test_argument_validation_returns_codes_without_launching():
     # fp8: workspace contract
     a.q_row_stride = 4 * 128
     a.dtype = _cabi.LA_DTYPE_FP8_E4M3
+    a.block_m = 128                                                            # the fp8 kernel's tile
     a.read_list = a.write_list = None
     assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 1 * 4 * 4 * 8192     # B * H * Kt * 8 KiB
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_WORKSPACE
     a.dtype = _cabi.LA_DTYPE_BF16
+    a.block_m = 256
     assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 0
     assert lib.la_skip_list_stats(None, 1, 1, 1, 1, None, None) == _cabi.LA_ERR_NULL_ARG
     assert lib.la_combine(None, 0, None, None, None, 1, 1, 1, 1, 128, None) == _cabi.LA_ERR_NULL_ARG

@@ -36,7 +36,7 @@ def test_g1_reference_tile_table_is_recorded_and_build_table_comes_from_library(
     ref = {(d, es, vc): tuple(mn) for d, es, vc, mn in g["get_MN"]}
     assert ref[(128, 2, False)] == (128, 176) and ref[(128, 1, False)] == (128, 224)   # tile_size.h:35-40,54-55
     # the build's table is the kernel's (la_get_tile_sizes), not a copy of the Hopper one
-    assert L.LiteAttention.get_MN(128, 2) == L.get_tile_sizes(128, 2) == (128, 64)
+    assert L.LiteAttention.get_MN(128, 2) == L.get_tile_sizes(128, 2) == (256, 64)
     with pytest.raises(RuntimeError):
         L.get_tile_sizes(40, 2)
 
@@ -59,7 +59,7 @@ def test_g2_init_skip_list_rows_match_reference_for_same_tile_counts():
         assert torch.equal(lists, orc.init_skip_list_ref(1, qt, kt, 2))
     # product entry point with the build's own tiles
     lists = L.LiteAttention.init_skip_list(3, 1000, 2, 128, False, torch.bfloat16, "cpu")
-    assert list(lists.shape) == [2, 3, 2, 8, 17] and lists[1, 2, 1, 7, :3].tolist() == [2, 15, 0]
+    assert list(lists.shape) == [2, 3, 2, 4, 17] and lists[1, 2, 1, 3, :3].tolist() == [2, 15, 0]   # ceil(1000/256) q-tiles
 
 
 def test_g3_must_do_conversion_matches_reference():
@@ -98,11 +98,12 @@ def test_g4_call_trace_matches_reference(rec):
         assert (call["read"].data_ptr() - lo) // per == ref["read"]
         assert (call["write"].data_ptr() - lo) // per == ref["write"]
         assert call["thr"] == ref["thr"] and call["scale"] == ref["scale"]
-        # same [maxB, H, Qt, .] geometry; the k-tile count differs because the tiles differ (176 vs 64)
-        assert list(call["read"].shape[:3]) == ref["list_shape"][:3]
+        # same [maxB, H, ., .] geometry; the tile counts differ because the tiles differ (reference 128 x 176, here 256 x 64)
+        assert list(call["read"].shape[:2]) == ref["list_shape"][:2]
         assert call["must_do"][:3].tolist() == ref["must_do_head"]       # default [0,0] -> [2,0,0]
-    assert rec.calls[0]["read"].shape[3] == -(-1000 // 64) + 1
-    assert rec.calls[3]["read"].shape[3] == -(-700 // 64) + 1
+    bm, bn = L.get_tile_sizes(128, 2)
+    assert rec.calls[0]["read"].shape[2:] == (-(-1000 // bm), -(-1000 // bn) + 1)
+    assert rec.calls[3]["read"].shape[2:] == (-(-700 // bm), -(-700 // bn) + 1)
 
 
 def test_phase_and_reinit_rules(rec):
@@ -110,7 +111,7 @@ def test_phase_and_reinit_rules(rec):
     q = torch.zeros(1, 300, 2, 128, dtype=torch.bfloat16)
     att(q, q, q)
     first = att._skip_list
-    assert att._phase == 1 and first.shape == (2, 2, 2, 3, 6)
+    assert att._phase == 1 and first.shape == (2, 2, 2, -(-300 // L.get_tile_sizes(128, 2)[0]), 6)
     att(q, q, q)
     assert att._phase == 0 and att._skip_list is first
     # changing heads, dtype or key length re-initialises (lite_attention.py:179-187 + Appendix B-2)
@@ -119,7 +120,7 @@ def test_phase_and_reinit_rules(rec):
     assert att._skip_list is not first and att._phase == 1 and att._skip_list.shape[2] == 3
     kshort = torch.zeros(1, 200, 3, 128, dtype=torch.bfloat16)
     att(q3, kshort, kshort)
-    assert att._skip_list.shape == (2, 2, 3, 3, 5) and att._phase == 1     # Kt from key.shape[1]
+    assert att._skip_list.shape == (2, 2, 3, -(-300 // L.get_tile_sizes(128, 2)[0]), 5) and att._phase == 1     # Kt from key.shape[1]
     with pytest.raises(AssertionError):
         att(torch.zeros(3, 300, 3, 128, dtype=torch.bfloat16), kshort.repeat(3, 1, 1, 1), kshort.repeat(3, 1, 1, 1))
 
