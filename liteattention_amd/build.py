@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_NAME = "libliteattention_amd.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
-SOURCES = ["la_fwd_kernel.hip", "la_fwd_kernel_v2.hip", "la_fwd_kernel_asm.hip", "la_fwd_kernel_x64.hip", "la_fwd_kernel_w8.hip", "la_fwd_kernel_fp8.hip", "la_aux_kernels.hip", "la_api.hip"]
+SOURCES = ["la_fwd_kernel_v2.hip", "la_fwd_kernel_asm.hip", "la_fwd_kernel_x64.hip", "la_fwd_kernel_fp8.hip", "la_aux_kernels.hip", "la_api.hip"]
 HEADERS = ["la_kernel_params.h", "la_tiles.h", "la_fwd_common.h", "gen_fwd_asm.py", "gen_fwd_x64.py"]
 ASM_GEN = "gen_fwd_asm.py"      # writes la_fwd_asm_body.inc (the hand-scheduled main loop), included by la_fwd_kernel_asm.hip
 ASM_INC = "la_fwd_asm_body.inc"

@@ -152,6 +152,8 @@ def k_read(kbuf_imm, j):
 
 def v_read(slot, vbuf_imm, m):
     db, kk = m >> 2, m & 3
+    if "vfake" in OPT:      # pricing only: ONE b128 read per fragment, as a pre-transposed V^T image would need
+        return [("LDS", f"ds_read_b128 {vr(VF[slot], 4)}, {v(KADDR[2 * kk])} offset:{V_REGION + vbuf_imm + db * 4096}", ("v", m, 1))]
     return [("LDS", f"ds_read_b64_tr_b16 {vr(VF[slot], 2)}, {v(VADDR[db])} offset:{vbuf_imm + kk * 4096}", ("v", m, 0)),
             ("LDS", f"ds_read_b64_tr_b16 {vr(VF[slot] + 2, 2)}, {v(VADDR[db])} offset:{vbuf_imm + kk * 4096 + 2048}", ("v", m, 1))]
 

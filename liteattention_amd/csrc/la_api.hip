@@ -20,15 +20,13 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 // bf16 / head_dim-128 kernel variant, fixed for the life of the process (env LA_FWD_KERNEL): the skip lists are
 // indexed by the selected kernel's tile, so la_get_tile_sizes and la_fwd must agree on it.
 // Default: x64 (one wave per SIMD, 64 rows per wave, q-tile 256). The 128-row kernels stay selectable for A/B runs:
-// v2 (hipcc-scheduled, also the head_dim-64 kernel), asm (v2 with a hand-scheduled loop), v1, w8.
-enum class Bf16Kernel { v2, v1, w8, hand, x64 };
+// v2 (hipcc-scheduled, also the head_dim-64 kernel) and asm (v2 with a hand-scheduled loop).
+enum class Bf16Kernel { v2, hand, x64 };
 Bf16Kernel bf16_d128_kernel() {
     static const Bf16Kernel k = [] {
         const char* e = getenv("LA_FWD_KERNEL");
         if (e == nullptr || e[0] == 0) return Bf16Kernel::x64;
-        if (e[0] == 'v' && e[1] == '1') return Bf16Kernel::v1;
         if (e[0] == 'v' && e[1] == '2') return Bf16Kernel::v2;
-        if (e[0] == 'w' && e[1] == '8') return Bf16Kernel::w8;
         if (e[0] == 'a' && e[1] == 's') return Bf16Kernel::hand;
         return Bf16Kernel::x64;
     }();
@@ -167,7 +165,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         if (e8 != hipSuccess) { g_last_hip_error = static_cast<int>(e8); return LA_ERR_LAUNCH; }
         return LA_OK;
     }
-    // head_dim 128: x64 unless LA_FWD_KERNEL names an A/B variant (v2, asm, v1, w8); head_dim 64: v2.
+    // head_dim 128: x64 unless LA_FWD_KERNEL names an A/B variant (v2, asm); head_dim 64: v2.
     const bool skipable = a->read_list != nullptr;                                      // is_skipable, flash_api.cpp:931
     const Bf16Kernel kern = a->head_dim == 128 ? bf16_d128_kernel() : Bf16Kernel::v2;
     hipError_t err;
@@ -176,10 +174,6 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         err = la::launch_fwd_bf16_d128_x64(p, skipable, stream);
     } else if (kern == Bf16Kernel::hand) {
         err = la::launch_fwd_bf16_d128_asm(p, skipable, stream);
-    } else if (kern == Bf16Kernel::w8 && la::fwd_w8_lds_bytes(p.k_tiles, nullptr) <= 160 * 1024) {
-        err = la::launch_fwd_bf16_d128_w8(p, skipable, stream);
-    } else if (kern == Bf16Kernel::v1) {
-        err = la::launch_fwd_bf16_d128(p, skipable, stream);
     } else {
         err = la::launch_fwd_bf16_v2(p, a->head_dim, skipable, stream);
     }

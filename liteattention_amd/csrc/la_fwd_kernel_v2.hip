@@ -1,8 +1,32 @@
 // la_fwd_kernel_v2.hip — software-pipelined QK-Skip attention forward (gfx950, bf16, head_dim 128 and 64).
 //
-// Same algorithm, tiles (128 x 64), LDS layout and MFMA mapping as la_fwd_kernel.hip (see its header for
-// the reference lines replaced). What changes is the schedule, driven by the round-1 rocprof evidence
-// (profiles/r01a: MFMA busy 37 %, waves 32 % parked on s_waitcnt/barrier, 27 % issue-stalled):
+// Replaces the reference's Hopper kernel on the LiteAttention path:
+//   FlashAttnFwdSm90::operator()            hopper/_internal/cpp/flash_fwd_kernel_sm90.h:213-571
+//   CollectiveMainloopFwdSm90::load / mma   hopper/_internal/cpp/mainloop_fwd_sm90_tma_gmma_ws.hpp:808-1237, 1359-2101
+//   SkipListReader / SkipListWriter         mainloop_fwd_sm90_tma_gmma_ws.hpp:47-192
+//   Softmax::max_get_scale_detect_qk_skip   hopper/_internal/cpp/softmax.h:139-222
+//   Softmax::online_softmax / finalize      softmax.h:263-296
+//   Mask::apply<Seqlenk_mask>               hopper/_internal/cpp/mask.h:44-78
+//   CollectiveEpilogueFwd::store            hopper/_internal/cpp/epilogue_fwd.hpp:214-403
+//   SingleTileScheduler                     hopper/_internal/cpp/tile_scheduler.hpp:37-130
+// All forward kernels of this library are one new design for CDNA4, not a translation (no TMA / WGMMA / warp specialisation):
+//
+//   * one workgroup = one (batch, head, q-tile of 128 rows); 4 waves x 32 query rows.
+//   * S^T = K Q^T ("swapped" product) with v_mfma_f32_32x32x16_bf16: every lane then owns ONE
+//     query row (column lane&31 of the 32x32 accumulator), so row max / row sum / the skip test
+//     are in-lane plus a single half-wave exchange, and the O rescale factor is a per-lane scalar.
+//   * P^T goes straight from the S^T accumulator registers (cvt to bf16) into the B operand of
+//     O^T += V^T P^T: the contraction index is permuted consistently on the V side (the LDS
+//     transpose-read addresses), so no cross-lane shuffle of P is needed.
+//   * K and V tiles (64 keys) are double-buffered in LDS, 16-byte XOR swizzle for K
+//     (ds_read_b128 conflict-free), 64-byte XOR swizzle for V (ds_read_b64_tr_b16 conflict-free).
+//   * the read list is expanded once per workgroup into an LDS tile sequence, so the K/V prefetch
+//     follows the data-dependent walk with no per-tile global list reads.
+//   * per-tile skip votes are OR-ed into an LDS bit vector (one LDS atomic per wave per tile); the
+//     write list is serialised once in the epilogue by one lane. No extra pass, no per-tile barrier.
+//
+// v2's schedule (the first, register-staged version measured MFMA busy 37 %, waves 32 % parked on s_waitcnt/barrier,
+// 27 % issue-stalled: profiles/r01a):
 //
 //   * K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction). The DMA
 //     image is lane-linear, so the XOR swizzles move to the per-lane SOURCE address. No staging VGPRs

@@ -35,16 +35,12 @@ struct FwdParams {
     int64_t v_descale_batch_stride, v_descale_head_stride;
 };
 
-size_t fwd_lds_bytes(int k_tiles, int* seq_cap_out);
-hipError_t launch_fwd_bf16_d128(const FwdParams& p, bool skipable, hipStream_t stream);      // v1: register-staged
 size_t fwd_lds_bytes_v2(int head_dim, int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, hipStream_t stream);   // v2: LDS-DMA, pipelined; head_dim 128 / 64
 size_t fwd_lds_bytes_asm(int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_d128_asm(const FwdParams& p, bool skipable, hipStream_t stream);  // v2 with a hand-scheduled main loop
 size_t fwd_lds_bytes_x64(int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_d128_x64(const FwdParams& p, bool skipable, hipStream_t stream);  // 1 wave/SIMD, 64 rows/wave, q-tile 256
-size_t fwd_w8_lds_bytes(int k_tiles, int* seq_cap_out);
-hipError_t launch_fwd_bf16_d128_w8(const FwdParams& p, bool skipable, hipStream_t stream);   // 8 waves, 256 rows, two list tiles
 size_t fwd_lds_bytes_fp8(int k_tiles, int* seq_cap_out);
 size_t fp8_workspace_bytes(int batch, int num_heads, int k_tiles);
 hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_row_stride, int64_t v_head_stride,

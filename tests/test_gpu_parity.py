@@ -85,6 +85,39 @@ def test_dense_matches_tiled_oracle_ragged_shapes(shape):
     assert (out.float().cpu() - o_eager.float()).abs().max().item() <= tol + 2.0 ** -8 * o_eager.float().abs().max().item()
 
 
+@pytest.mark.parametrize("gain", [3.0, 8.0])
+def test_running_max_that_grows_late_in_the_walk(gain):
+    """Keys are walked from the END of the sequence; make the early keys (walked last) score far higher, so the running
+    max of every row keeps growing by many powers of two through the walk. Exercises the O / row-sum rescale — in the
+    64-rows-per-wave kernel the lazy-rescale path (m_ref follows m_true only past 2^8) and its O^T AGPR round trip — with
+    and without skip lists; the lists must still match the oracle bit for bit (votes use the true running max)."""
+    L, orc = _L(), _orc()
+    B, S, H = 1, 1536, 2
+    q, k, v = _randn(B, S, H, seed=91)
+    ramp = torch.linspace(gain, 1.0, S).view(1, S, 1, 1)                 # early keys (walked last) up to `gain` x larger
+    k = (k.float() * ramp).bfloat16()
+    o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN)
+    out, lse = L.flash_attn_func(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
+    assert (out.float().cpu() - o_ref).abs().max().item() <= _oracle_tol(o_ref)
+    assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
+    # same data through the skip path (threshold low enough that nothing is skipped: every tile raises the max)
+    Qt, Kt = -(-S // BM), -(-S // BN)
+    att = L.LiteAttention(threshold=-1.0, max_batch_size=B)
+    md_row = orc.expand_must_do_ref([0, 0], BN, Kt + 1)
+    margins = torch.empty(B, H, Qt, Kt)
+    for _ in range(2):
+        rd_idx = att._phase if att._skip_list is not None else 0
+        out, lse = att(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
+        rd, wr = att._skip_list[rd_idx].cpu(), att._skip_list[1 - rd_idx].cpu()
+        wr_orc = torch.zeros_like(wr)
+        o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN, read_list=rd, write_list=wr_orc,
+                                           must_do_list=md_row, thr=-1.0, margins=margins)
+        assert (out.float().cpu() - o_ref).abs().max().item() <= _oracle_tol(o_ref)
+        assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
+        bad, _ = _compare_lists(orc, rd, wr, wr_orc, margins, -1.0, B)
+        assert bad == 0
+
+
 def test_softmax_scale_and_strided_inputs():
     """Non-default scale; q/k/v as non-contiguous views of a packed (B,S,3,H,D) tensor."""
     L, orc = _L(), _orc()
