@@ -65,7 +65,8 @@ KADDR = list(range(160, 168))
 VADDR = list(range(168, 172))
 LK = list(range(172, 176))
 LV = list(range(176, 180))
-MTRUE, MREF, NMS, L0, L1, MLOC, MLOC2, ALPHA = ([180, 181], [182, 183], [184, 185], [186, 187], [188, 189], [190, 191],
+# (L0[qb], L1[qb]) and (NMS[0], NMS[1]) are even-aligned 64-bit pairs: operands of the packed-fp32 VALU ops
+MTRUE, MREF, NMS, L0, L1, MLOC, MLOC2, ALPHA = ([180, 181], [182, 183], [184, 185], [186, 188], [187, 189], [190, 191],
                                                 [192, 193], [194, 195])
 T = list(range(196, 212))                 # temporaries; (T[4],T[5]) even-aligned 64-bit pair
 NEGINF, HH4, LANE, RIPROW = 212, 213, 214, 215
@@ -80,6 +81,7 @@ S_TB, S_VB, S_EXEC, S_T64, S_T64B = 42, 44, 46, 48, 50   # 64-bit temps
  S_NA, S_NB, S_NC, S_LDS, S_T0, S_T1, S_T2, S_T3, S_NM1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_PARAM, S_HASNEXT, S_NEGC,
  S_SAFEROW, S_DMAW, S_RAG, S_TAU, S_RESC, S_NCUR) = range(52, 87)
 S_RAG2, S_TB2, S_VB2, S_POS = 87, 88, 90, 92     # second set of DMA bases / ragged flags (the loop is unrolled by two)
+S_CC = 94                                        # s[94:95] = (c, c): scalar operand of v_pk_fma_f32
 TBS, VBS, RAGS = [S_TB, S_TB2], [S_VB, S_VB2], [S_RAG, S_RAG2]
 
 KV_TILE = 16384
@@ -171,8 +173,14 @@ def mfma_pv(sset, slot, m, qb):
     return f"    v_mfma_f32_32x32x16_bf16 {ar(O_(qb, db), 16)}, {vr(VF[slot], 4)}, {vr(pf, 4)}, {ar(O_(qb, db), 16)}"
 
 
+PK = "pk" in OPT           # packed-fp32 VALU (v_pk_fma_f32 / v_pk_add_f32). MEASURED ANTI-LEVER beside MFMAs: -64 issue slots
+                           # per step but +300 quad-cycles of issue stall (1163 vs 1316 TFLOP/s); kept for A/B only
+
+
 def softmax_parts(sset, p):
-    """Pair p (elements 2p, 2p+1 of the 32 per lane) of BOTH q-blocks: (4 fma, 4 exp, 4 add, 2 cvt)."""
+    """Pair p (elements 2p, 2p+1 of the 32 per lane) of BOTH q-blocks: per q-block (fma(s), 2 exp, add(s), cvt).
+    Packed form: ONE v_pk_fma_f32 (c from s[S_CC:S_CC+1], -m_ref*c broadcast from one half of v[NMS0:NMS1] by op_sel)
+    and ONE v_pk_add_f32 into the (L0, L1) pair do the work of two fmas / two adds."""
     F, E, A, C = [], [], [], []
     for qb in (0, 1):
         e0 = 2 * p
@@ -181,10 +189,15 @@ def softmax_parts(sset, p):
         r1 = r0 + 1
         dst = S_(sset, kb, qb) + 8 * (r >> 3) + ((r & 7) >> 1)
         ta, tb = T[8 + 2 * qb], T[9 + 2 * qb]
-        F += [f"    v_fma_f32 {v(ta)}, {v(r0)}, {s(S_C)}, {v(NMS[qb])}", f"    v_fma_f32 {v(tb)}, {v(r1)}, {s(S_C)}, {v(NMS[qb])}"]
-        E += [f"    v_exp_f32 {v(r0)}, {v(ta)}", f"    v_exp_f32 {v(r1)}, {v(tb)}"]
-        A += [f"    v_add_f32 {v(L0[qb])}, {v(L0[qb])}, {v(r0)}", f"    v_add_f32 {v(L1[qb])}, {v(L1[qb])}, {v(r1)}"]
-        C += [f"    v_cvt_pk_bf16_f32 {v(dst)}, {v(r0)}, {v(r1)}"]
+        if PK:
+            sel = "op_sel_hi:[1,0,0]" if qb == 0 else "op_sel:[0,0,1] op_sel_hi:[1,0,1]"
+            F.append([f"    v_pk_fma_f32 {vr(ta, 2)}, {vr(r0, 2)}, {sr(S_CC)}, {vr(NMS[0], 2)} {sel}"])
+            A.append([f"    v_pk_add_f32 {vr(L0[qb], 2)}, {vr(L0[qb], 2)}, {vr(r0, 2)}"])
+        else:
+            F.append([f"    v_fma_f32 {v(ta)}, {v(r0)}, {s(S_C)}, {v(NMS[qb])}", f"    v_fma_f32 {v(tb)}, {v(r1)}, {s(S_C)}, {v(NMS[qb])}"])
+            A.append([f"    v_add_f32 {v(L0[qb])}, {v(L0[qb])}, {v(r0)}", f"    v_add_f32 {v(L1[qb])}, {v(L1[qb])}, {v(r1)}"])
+        E.append([f"    v_exp_f32 {v(r0)}, {v(ta)}", f"    v_exp_f32 {v(r1)}, {v(tb)}"])
+        C.append([f"    v_cvt_pk_bf16_f32 {v(dst)}, {v(r0)}, {v(r1)}"])
     return F, E, A, C
 
 
@@ -192,7 +205,7 @@ def softmax_group(sset, p):
     if "nosoftmax" in OPT:
         return []
     F, E, A, C = softmax_parts(sset, p)
-    return F + E + A + C
+    return [op for part in (F, E, A, C) for per_qb in part for op in per_qb]
 
 
 def softmax_stream(sset, groups):
@@ -204,21 +217,25 @@ def softmax_stream(sset, groups):
     if "expblock" in OPT:
         return [op for p in groups for op in softmax_group(sset, p)]
     parts = [softmax_parts(sset, p) for p in groups]
-    o = list(parts[0][0])                                   # F(first)
+    o = parts[0][0][0] + parts[0][0][1]                     # F(first), both q-blocks
     n = len(parts)
     for g in range(n):
-        Fn = parts[g + 1][0] if g + 1 < n else []
-        Ap, Cp = (parts[g - 1][2], parts[g - 1][3]) if g > 0 else ([], [])
+        Fn = parts[g + 1][0] if g + 1 < n else None
+        Ap, Cp = (parts[g - 1][2], parts[g - 1][3]) if g > 0 else (None, None)
         E = parts[g][1]
-        for k in range(4):
-            o.append(E[k])
-            if Fn:
-                o.append(Fn[k])
-            if Ap:
-                o.append(Ap[k])
-            if Cp and (k & 1):                              # the cvt of a q-block goes after BOTH of its adds (it may
-                o.append(Cp[k >> 1])                        # overwrite r0 in place)
-    o += parts[-1][2] + parts[-1][3]                        # A(last), C(last)
+        for qb in (0, 1):
+            # between / after the two exps of a q-block: the add(s) and the cvt of group g-1 (the cvt after BOTH of its
+            # adds: it may overwrite r0 in place), and the fma(s) of group g+1 (their temporaries were just consumed)
+            fill0 = list(Ap[qb][:1]) if Ap else []
+            fill1 = (list(Ap[qb][1:]) if Ap else []) + (list(Fn[qb]) if Fn else []) + (list(Cp[qb]) if Cp else [])
+            if Fn and not PK:                               # scalar form: fma of temp a right after exp a
+                fill0 = [Fn[qb][0]] + fill0
+                fill1 = [x for x in fill1 if x is not Fn[qb][0]]
+            o += [E[qb][0]] + fill0 + [E[qb][1]] + fill1
+    for qb in (0, 1):
+        o += parts[-1][2][qb]
+    for qb in (0, 1):
+        o += parts[-1][3][qb]
     return o
 
 
@@ -606,6 +623,8 @@ def prologue():
     for idx, sg in enumerate(plist):
         emit(f"v_readfirstlane_b32 {s(sg)}, {v(idx)}")
     emit("s_nop 4")
+    emit(f"s_mov_b32 {s(S_CC)}, {s(S_C)}")
+    emit(f"s_mov_b32 {s(S_CC + 1)}, {s(S_C)}")
     emit(f"s_sub_u32 {s(S_NM1)}, {s(S_NTILES)}, 1")
     emit(f"s_sub_u32 {s(S_SAFEROW)}, {s(S_LASTROW)}, 63")
     emit(f"s_max_i32 {s(S_SAFEROW)}, {s(S_SAFEROW)}, 0")
