@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LA_ABI_VERSION 2
+#define LA_ABI_VERSION 3
 
 typedef enum la_status {
     LA_OK = 0,
@@ -47,11 +47,17 @@ typedef enum la_status {
     LA_ERR_STRIDE = -6,          /* last dim must be contiguous (flash_api.cpp:726-728) / 16-byte rows  */
     LA_ERR_TILE_MISMATCH = -7,   /* block_m/block_n echo != la_get_tile_sizes (list indexing would be wrong) */
     LA_ERR_LISTS = -8,           /* read list without write list, or vice versa                   */
-    LA_ERR_UNSUPPORTED = -9,     /* feature outside the hot path (causal, GQA, dv != d, ...)      */
+    LA_ERR_UNSUPPORTED = -9,     /* feature outside the hot path (causal, dv != d, ...)           */
     LA_ERR_LAUNCH = -10,         /* hipLaunchKernel failed; see la_last_hip_error()               */
     LA_ERR_SEQLEN = -11,         /* sequence too long for the per-workgroup list staging in LDS   */
-    LA_ERR_WORKSPACE = -12       /* fp8: workspace missing or smaller than la_fwd_workspace_bytes() */
+    LA_ERR_WORKSPACE = -12,      /* fp8: workspace missing or smaller than la_fwd_workspace_bytes() */
+    LA_ERR_Q_WINDOW = -13        /* q_tile_begin/q_tile_count outside [0, ceil(seqlen_q/block_m)]  */
 } la_status;
+
+/* la_fwd_args.flags */
+#define LA_FLAG_V_PREPARED 1u    /* fp8: `workspace` already holds the prepared V^T tiles of THIS v (an earlier
+                                  * la_fwd call on the same v/workspace): skip the prepare pass. Lets a caller
+                                  * split one attention into several q-tile windows (below) and pay for it once. */
 
 typedef enum la_dtype {
     LA_DTYPE_BF16 = 0,
@@ -62,6 +68,8 @@ typedef enum la_dtype {
 /*
  * Forward arguments. Strides are in ELEMENTS (as Flash_fwd_params, flash_api.cpp:84-103).
  * Tensors: q (B,Sq,H,D)  k (B,Sk,Hk,D)  v (B,Sk,Hk,Dv)  o (B,Sq,H,Dv)  lse (B,H,Sq) fp32 contiguous.
+ * GQA / MQA: H % Hk == 0, query head h reads K/V head h / (H/Hk) (flash_api.cpp:777; the reference's
+ * non-packed GQA path); fp8 descales are per (batch, K/V head) for q, k AND v (flash_api.cpp:689-691).
  *
  * Skip lists (reader/writer semantics of
  * hopper/_internal/cpp/mainloop_fwd_sm90_tma_gmma_ws.hpp:47-192):
@@ -112,6 +120,16 @@ typedef struct la_fwd_args {
      * Size from la_fwd_workspace_bytes(); 16-byte aligned; contents are scratch, valid during the call. */
     void*    workspace;
     uint64_t workspace_bytes;
+
+    /* q-tile window (ABI 3). The launch computes q-tiles [q_tile_begin, q_tile_begin + q_tile_count) of every
+     * (batch, head) of the SAME problem: q/o/lse/lists are still the full tensors and are indexed by the global
+     * q-tile, rows outside the window are not touched. q_tile_count == 0 means "all" (begin must then be 0).
+     * Use: several launches on one stream whose outputs leave early (e.g. the head-sharded driver all-gathers
+     * window i over xGMI while window i+1 computes). The reference has no equivalent (one launch per call,
+     * flash_fwd_launch_template.h:359). */
+    int32_t  q_tile_begin, q_tile_count;
+    uint32_t flags;              /* LA_FLAG_* */
+    uint32_t reserved0;          /* must be 0 */
 } la_fwd_args;
 
 /* Tile sizes (kBlockM, kBlockN) of the kernel that la_fwd will run for (head_dim, element size).

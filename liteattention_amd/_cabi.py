@@ -13,7 +13,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # LITEATTENTION_AMD_LIB overrides the in-tree location (deployment / tests of the failure path)
 LIB_PATH = os.environ.get("LITEATTENTION_AMD_LIB") or os.path.join(_PKG_DIR, "libliteattention_amd.so")
 
-LA_ABI_VERSION = 2
+LA_ABI_VERSION = 3
 LA_DTYPE_BF16, LA_DTYPE_FP16, LA_DTYPE_FP8_E4M3 = 0, 1, 2
 
 LA_OK = 0
@@ -21,6 +21,7 @@ LA_ERR_NULL_ARG, LA_ERR_STRUCT_SIZE, LA_ERR_DTYPE, LA_ERR_HEAD_DIM, LA_ERR_SHAPE
 LA_ERR_STRIDE, LA_ERR_TILE_MISMATCH, LA_ERR_LISTS, LA_ERR_UNSUPPORTED, LA_ERR_LAUNCH, LA_ERR_SEQLEN = (
     -6, -7, -8, -9, -10, -11)
 LA_ERR_WORKSPACE = -12
+LA_ERR_Q_WINDOW = -13
 
 EXPORTED_SYMBOLS = (
     "la_abi_version", "la_get_tile_sizes", "la_fwd", "la_fwd_workspace_bytes", "la_skip_list_stats", "la_combine",
@@ -50,7 +51,12 @@ class LaFwdArgs(ctypes.Structure):
         ("must_do_is_1d", ctypes.c_int32), ("thr", ctypes.c_float),
         ("block_m", ctypes.c_int32), ("block_n", ctypes.c_int32),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64),
+        ("q_tile_begin", ctypes.c_int32), ("q_tile_count", ctypes.c_int32),
+        ("flags", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
     ]
+
+
+LA_FLAG_V_PREPARED = 1
 
 
 class NativeLibraryError(RuntimeError):

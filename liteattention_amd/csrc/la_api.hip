@@ -55,10 +55,11 @@ const char* la_status_string(int status) {
         case LA_ERR_STRIDE: return "Input tensor must have contiguous last dimension and 16-byte aligned rows";
         case LA_ERR_TILE_MISMATCH: return "block_m/block_n do not match la_get_tile_sizes(): skip lists would be mis-indexed";
         case LA_ERR_LISTS: return "attn_read_list and attn_write_list must be given together";
-        case LA_ERR_UNSUPPORTED: return "feature outside the QK-Skip hot path (GQA/MQA, head_dim_v != head_dim)";
+        case LA_ERR_UNSUPPORTED: return "feature outside the QK-Skip hot path (head_dim_v != head_dim)";
         case LA_ERR_LAUNCH: return "HIP kernel launch failed (see la_last_hip_error)";
         case LA_ERR_SEQLEN: return "seqlen_k too long: expanded skip list does not fit in LDS";
         case LA_ERR_WORKSPACE: return "fp8 needs a 16-byte aligned workspace of la_fwd_workspace_bytes() bytes";
+        case LA_ERR_Q_WINDOW: return "q_tile_begin/q_tile_count outside the q-tiles of this problem";
         default: return "unknown la_status";
     }
 }
@@ -80,8 +81,8 @@ int64_t la_fwd_workspace_bytes(const la_fwd_args* a) {
     int bm = 0, bn = 0;
     const int trc = la_get_tile_sizes(a->head_dim, 1, &bm, &bn);
     if (trc != LA_OK) return trc;
-    if (a->batch <= 0 || a->num_heads <= 0 || a->seqlen_k < 0) return LA_ERR_SHAPE;
-    return static_cast<int64_t>(la::fp8_workspace_bytes(a->batch, a->num_heads, (a->seqlen_k + bn - 1) / bn));
+    if (a->batch <= 0 || a->num_heads <= 0 || a->num_heads_k <= 0 || a->seqlen_k < 0) return LA_ERR_SHAPE;
+    return static_cast<int64_t>(la::fp8_workspace_bytes(a->batch, a->num_heads_k, (a->seqlen_k + bn - 1) / bn));
 }
 
 int la_fwd(const la_fwd_args* a, void* stream_) {
@@ -97,7 +98,8 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         return LA_ERR_SHAPE;                                                             // flash_api.cpp:776-778
     if (a->num_heads % a->num_heads_k != 0) return LA_ERR_SHAPE;                          // flash_api.cpp:777
     if (a->head_dim % (fp8 ? 16 : 8) != 0) return LA_ERR_HEAD_DIM;                         // flash_api.cpp:854-856
-    if (a->num_heads_k != a->num_heads || a->head_dim_v != a->head_dim) return LA_ERR_UNSUPPORTED;
+    if (a->head_dim_v != a->head_dim) return LA_ERR_UNSUPPORTED;
+    if (a->reserved0 != 0 || (a->flags & ~LA_FLAG_V_PREPARED) != 0) return LA_ERR_UNSUPPORTED;
     int bm = 0, bn = 0;
     const int trc = la_get_tile_sizes(a->head_dim, esize, &bm, &bn);
     if (trc != LA_OK) return trc;
@@ -123,7 +125,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
 
     la::FwdParams p{};
     if (fp8) {
-        const size_t need = la::fp8_workspace_bytes(a->batch, a->num_heads, (a->seqlen_k + bn - 1) / bn);
+        const size_t need = la::fp8_workspace_bytes(a->batch, a->num_heads_k, (a->seqlen_k + bn - 1) / bn);
         if (a->workspace == nullptr || a->workspace_bytes < need || !aligned16(a->workspace)) return LA_ERR_WORKSPACE;
     }
     p.q = static_cast<const uint16_t*>(a->q);
@@ -136,8 +138,16 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     p.v_batch_stride = a->v_batch_stride; p.v_row_stride = a->v_row_stride; p.v_head_stride = a->v_head_stride;
     p.o_batch_stride = a->o_batch_stride; p.o_row_stride = a->o_row_stride; p.o_head_stride = a->o_head_stride;
     p.batch = a->batch; p.seqlen_q = a->seqlen_q; p.seqlen_k = a->seqlen_k; p.num_heads = a->num_heads;
+    p.h_ratio = a->num_heads / a->num_heads_k;
     p.q_tiles = (a->seqlen_q + bm - 1) / bm;
     p.k_tiles = (a->seqlen_k + bn - 1) / bn;
+    if (a->q_tile_count == 0) {
+        if (a->q_tile_begin != 0) return LA_ERR_Q_WINDOW;
+        p.q_tile_begin = 0; p.q_tile_count = p.q_tiles;
+    } else {
+        if (a->q_tile_begin < 0 || a->q_tile_count < 0 || a->q_tile_begin > p.q_tiles - a->q_tile_count) return LA_ERR_Q_WINDOW;
+        p.q_tile_begin = a->q_tile_begin; p.q_tile_count = a->q_tile_count;
+    }
     p.scale_log2 = static_cast<float>(static_cast<double>(a->softmax_scale) * 1.4426950408889634);  // flash_api.cpp:125-126
     p.thr = a->thr;                                                                      // flash_api.cpp:930
     p.rescale_tau = rescale_tau();
@@ -156,8 +166,10 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     if (fp8) {
         if (la::fwd_lds_bytes_fp8(p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
         // 1) V -> pre-transposed, pre-swizzled V^T tiles in the caller's workspace; 2) forward on (Q, K, V^T)
-        hipError_t e8 = la::launch_prep_v_fp8(a->v, a->v_batch_stride, a->v_row_stride, a->v_head_stride, a->workspace,
-                                              a->batch, a->seqlen_k, a->num_heads, p.k_tiles, stream);
+        hipError_t e8 = hipSuccess;
+        if (!(a->flags & LA_FLAG_V_PREPARED))
+            e8 = la::launch_prep_v_fp8(a->v, a->v_batch_stride, a->v_row_stride, a->v_head_stride, a->workspace,
+                                       a->batch, a->seqlen_k, a->num_heads_k, p.k_tiles, stream);
         if (e8 == hipSuccess) {
             p.v = static_cast<const uint16_t*>(a->workspace);
             e8 = la::launch_fwd_fp8_d128(p, a->read_list != nullptr, stream);

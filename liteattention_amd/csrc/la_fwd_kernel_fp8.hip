@@ -130,11 +130,12 @@ la_fwd_fp8_d128_kernel(const FwdParams p) {
     const int l31 = lane & 31;
 
     const int vid = xcd_work_id();
-    const int m_block = vid % p.q_tiles;
-    const int bh = vid / p.q_tiles;
+    const int m_block = p.q_tile_begin + vid % p.q_tile_count;
+    const int bh = vid / p.q_tile_count;
     const int h = bh % p.num_heads;
     const int b = bh / p.num_heads;
     const int k_tiles = p.k_tiles;
+    const int hk = h / p.h_ratio;                      // K/V head (GQA/MQA: h_ratio query heads share one)
     const int64_t list_off = (static_cast<int64_t>(bh) * p.q_tiles + m_block) * (k_tiles + 1);
 
     if (SKIPABLE) {
@@ -146,10 +147,11 @@ la_fwd_fp8_d128_kernel(const FwdParams p) {
         }
     }
 
-    // ---- descales (per batch, per head; NULL = 1). c folds softmax_scale*log2(e) with q and k descales.
-    const float qd = p.q_descale ? p.q_descale[b * p.q_descale_batch_stride + h * p.q_descale_head_stride] : 1.f;
-    const float kd = p.k_descale ? p.k_descale[b * p.k_descale_batch_stride + h * p.k_descale_head_stride] : 1.f;
-    const float vd = p.v_descale ? p.v_descale[b * p.v_descale_batch_stride + h * p.v_descale_head_stride] : 1.f;
+    // ---- descales (per batch, per K/V head — all three, flash_api.cpp:689-691, flash_fwd_kernel_sm90.h:509-510;
+    // NULL = 1). c folds softmax_scale*log2(e) with q and k descales.
+    const float qd = p.q_descale ? p.q_descale[b * p.q_descale_batch_stride + hk * p.q_descale_head_stride] : 1.f;
+    const float kd = p.k_descale ? p.k_descale[b * p.k_descale_batch_stride + hk * p.k_descale_head_stride] : 1.f;
+    const float vd = p.v_descale ? p.v_descale[b * p.v_descale_batch_stride + hk * p.v_descale_head_stride] : 1.f;
     const float c = p.scale_log2 * qd * kd;
 
     // ---- Q fragments: lane holds query row l31, d = 32*j + 16*hh + [0,16) for j = 0..3 (two k-steps each)
@@ -170,8 +172,9 @@ la_fwd_fp8_d128_kernel(const FwdParams p) {
     // ---- LDS-DMA. K tile: 8 pieces of 1 KiB = 8 rows of 128 bytes; wave w stages rows 16w..16w+15 (pieces 2w, 2w+1);
     // lane: row rip = lane>>3, chunk position cpos = lane&7, source chunk cpos ^ f8_k_swz(row).
     // V^T tile: 8 KiB contiguous and pre-swizzled in the workspace: a linear copy.
-    const uint8_t* const kg = reinterpret_cast<const uint8_t*>(p.k) + b * p.k_batch_stride + h * p.k_head_stride;
-    const uint8_t* const vtg = reinterpret_cast<const uint8_t*>(p.v) + static_cast<int64_t>(bh) * k_tiles * F8_TILE;
+    const uint8_t* const kg = reinterpret_cast<const uint8_t*>(p.k) + b * p.k_batch_stride + hk * p.k_head_stride;
+    const uint8_t* const vtg = reinterpret_cast<const uint8_t*>(p.v) +
+                               (static_cast<int64_t>(b) * (p.num_heads / p.h_ratio) + hk) * k_tiles * F8_TILE;
     const int k_rs = static_cast<int>(p.k_row_stride);   // bytes (1-byte elements)
     const int rip = lane >> 3;
     const int cpos = lane & 7;
@@ -392,7 +395,7 @@ size_t fp8_workspace_bytes(int batch, int num_heads, int k_tiles) {
 
 // p.v must already point at the V^T workspace written by launch_prep_v_fp8.
 hipError_t launch_fwd_fp8_d128(const FwdParams& p, bool skipable, hipStream_t stream) {
-    const int total = p.batch * p.num_heads * p.q_tiles;
+    const int total = p.batch * p.num_heads * p.q_tile_count;
     FwdParams pp = p;
     const size_t lds = fwd_lds_bytes_fp8(p.k_tiles, &pp.seq_cap);
     hipError_t err;

@@ -96,11 +96,12 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
     const int l31 = lane & 31;
 
     const int vid = xcd_work_id();
-    const int m_block = vid % p.q_tiles;
-    const int bh = vid / p.q_tiles;
+    const int m_block = p.q_tile_begin + vid % p.q_tile_count;
+    const int bh = vid / p.q_tile_count;
     const int h = bh % p.num_heads;
     const int b = bh / p.num_heads;
     const int k_tiles = p.k_tiles;
+    const int hk = h / p.h_ratio;                      // K/V head (GQA/MQA: h_ratio query heads share one)
     const int64_t list_off = (static_cast<int64_t>(bh) * p.q_tiles + m_block) * (k_tiles + 1);
 
     if (SKIPABLE) {
@@ -131,8 +132,8 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
     // 16w .. 16w+15 = pieces PPW*w .. PPW*w+PPW-1. Lane: row rip = lane / CPR inside the piece, LDS chunk
     // position cpos = lane % CPR. The DMA image is lane-linear, so the swizzles go on the SOURCE address:
     // LDS position c' of row r holds data chunk c' ^ swz(r).
-    const unsigned char* const kg = reinterpret_cast<const unsigned char*>(p.k + b * p.k_batch_stride + h * p.k_head_stride);
-    const unsigned char* const vg = reinterpret_cast<const unsigned char*>(p.v + b * p.v_batch_stride + h * p.v_head_stride);
+    const unsigned char* const kg = reinterpret_cast<const unsigned char*>(p.k + b * p.k_batch_stride + hk * p.k_head_stride);
+    const unsigned char* const vg = reinterpret_cast<const unsigned char*>(p.v + b * p.v_batch_stride + hk * p.v_head_stride);
     const int k_rs = static_cast<int>(p.k_row_stride * 2), v_rs = static_cast<int>(p.v_row_stride * 2);   // bytes (< 2^31, checked on the host)
     const int rip = lane / CPR;
     const int cpos = lane % CPR;
@@ -386,7 +387,7 @@ size_t fwd_lds_bytes_v2(int head_dim, int k_tiles, int* seq_cap_out) {
 
 template <int D, bool SKIPABLE>
 static hipError_t launch_v2(const FwdParams& p, hipStream_t stream) {
-    const int total = p.batch * p.num_heads * p.q_tiles;
+    const int total = p.batch * p.num_heads * p.q_tile_count;
     FwdParams pp = p;
     const size_t lds = fwd_lds_bytes_v2(D, p.k_tiles, &pp.seq_cap);
     (void)hipGetLastError();   // drop any stale sticky error of this thread: only OUR launch is reported

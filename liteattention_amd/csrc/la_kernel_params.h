@@ -17,7 +17,10 @@ struct FwdParams {
     int64_t v_batch_stride, v_row_stride, v_head_stride;
     int64_t o_batch_stride, o_row_stride, o_head_stride;
     int batch, seqlen_q, seqlen_k, num_heads;
+    int h_ratio;            // num_heads / num_heads_k: query heads per K/V head (GQA/MQA; kv head = h / h_ratio)
     int q_tiles, k_tiles;
+    int q_tile_begin;       // this launch covers q-tiles [q_tile_begin, q_tile_begin + q_tile_count) of every (batch, head):
+    int q_tile_count;       // a window of the SAME problem (tensors, LSE and lists are indexed by the global q-tile)
     int seq_cap;            // int32 slots reserved in LDS for the expanded tile sequence
     float scale_log2;       // softmax_scale * log2(e)   (flash_api.cpp:125-126)
     float rescale_tau;      // x64 kernel: O/l follow the running max only when it grew by more than this (log2 units)
@@ -42,9 +45,9 @@ hipError_t launch_fwd_bf16_d128_asm(const FwdParams& p, bool skipable, hipStream
 size_t fwd_lds_bytes_x64(int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_d128_x64(const FwdParams& p, bool skipable, hipStream_t stream);  // 1 wave/SIMD, 64 rows/wave, q-tile 256
 size_t fwd_lds_bytes_fp8(int k_tiles, int* seq_cap_out);
-size_t fp8_workspace_bytes(int batch, int num_heads, int k_tiles);
+size_t fp8_workspace_bytes(int batch, int num_heads_k, int k_tiles);
 hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_row_stride, int64_t v_head_stride,
-                             void* vt, int batch, int seqlen_k, int num_heads, int k_tiles, hipStream_t stream);
+                             void* vt, int batch, int seqlen_k, int num_heads_k, int k_tiles, hipStream_t stream);
 hipError_t launch_fwd_fp8_d128(const FwdParams& p, bool skipable, hipStream_t stream);   // p.v = V^T workspace
 hipError_t launch_skip_list_stats(const int32_t* list, int rows, int k_tiles, int64_t* out, hipStream_t stream);
 hipError_t launch_combine(const void* o_partial, bool partial_is_bf16, const float* lse_partial, uint16_t* o,

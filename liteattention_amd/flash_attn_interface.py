@@ -96,9 +96,15 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
             is_causal=False, window_size_left=-1, window_size_right=-1, attention_chunk=0, softcap=0.0,
             is_rotary_interleaved=False, scheduler_metadata=None, num_splits=0, pack_gqa=None, sm_margin=0,
             attn_read_list=None, attn_must_do_list=None, attn_write_list=None, thr=-3.0,
-            _must_do_is_1d: bool = False):
-    """Host half of the op (flash_api.cpp:667-1249) for the non-causal, fixed-length, MHA subset that
-    ``LiteAttention.__call__`` reaches. Returns ``(out, softmax_lse, out_accum, softmax_lse_accum)``."""
+            _must_do_is_1d: bool = False, _q_windows=None, _window_hook=None):
+    """Host half of the op (flash_api.cpp:667-1249) for the non-causal, fixed-length subset (MHA / GQA / MQA) that
+    ``LiteAttention.__call__`` reaches. Returns ``(out, softmax_lse, out_accum, softmax_lse_accum)``.
+
+    Extensions outside the reference schema (direct callers only): ``_must_do_is_1d`` (one shared must-do row) and
+    ``_q_windows`` = [(first q-tile, q-tile count), ...]: the call becomes one launch per window on the current
+    stream, ``_window_hook(i, out, row_begin, row_end)`` runs after window i has been enqueued (rows
+    [row_begin, row_end) of ``out`` are complete once that launch is; used to all-gather early rows while later
+    windows compute)."""
     if not q.is_cuda:
         raise RuntimeError("lite_attention::fwd has no CPU implementation (HIP device tensors required)")
     if q.dtype not in (torch.bfloat16, torch.float8_e4m3fn):
@@ -149,8 +155,6 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
         if t.dtype != torch.float32 or tuple(t.shape) != (B, Hk) or t.device != q.device:          # :1003-1022
             raise RuntimeError(f"{name} must be a float32 tensor of shape (batch_size, nheads_k) on the input device")
         descales.append(t)
-    if Hk != H:
-        raise NotImplementedError("GQA/MQA (nheads_k != nheads) is outside the QK-Skip hot path in this build")
     if Dv != D:
         raise NotImplementedError("head_dim_v != head_dim is outside the QK-Skip hot path in this build")
     if softmax_scale is None:
@@ -218,16 +222,25 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
             raise RuntimeError(f"lite_attention::fwd: {_cabi.status_string(int(need))}")
         workspace = torch.empty(int(need), dtype=torch.uint8, device=q.device)
         a.workspace, a.workspace_bytes = workspace.data_ptr(), int(need)
+    windows = [(0, 0)] if _q_windows is None else [(int(b0), int(c0)) for b0, c0 in _q_windows]
+    if _q_windows is not None and any(c0 <= 0 or b0 < 0 or b0 + c0 > q_tiles for b0, c0 in windows):
+        raise RuntimeError(f"q-tile windows must lie inside [0, {q_tiles}) with positive counts; got {windows}")
+    lib = _cabi.load()
     with torch.cuda.device(q.device):                                                             # CUDAGuard :885
-        stream = torch.cuda.current_stream(q.device).cuda_stream                                  # :1219
-        rc = _cabi.load().la_fwd(ctypes.byref(a), ctypes.c_void_p(stream))
-    if rc != _cabi.LA_OK:
-        msg = _cabi.status_string(rc)
-        if rc == _cabi.LA_ERR_UNSUPPORTED:
-            raise NotImplementedError(msg)
-        if rc == _cabi.LA_ERR_LAUNCH:
-            msg += f" (hipError {_cabi.load().la_last_hip_error()})"
-        raise RuntimeError(f"lite_attention::fwd: {msg}")
+        for i, (w_begin, w_count) in enumerate(windows):
+            a.q_tile_begin, a.q_tile_count = w_begin, w_count
+            a.flags = _cabi.LA_FLAG_V_PREPARED if (is_fp8 and i > 0) else 0     # V^T tiles prepared by window 0
+            stream = torch.cuda.current_stream(q.device).cuda_stream                              # :1219
+            rc = lib.la_fwd(ctypes.byref(a), ctypes.c_void_p(stream))
+            if rc != _cabi.LA_OK:
+                msg = _cabi.status_string(rc)
+                if rc == _cabi.LA_ERR_UNSUPPORTED:
+                    raise NotImplementedError(msg)
+                if rc == _cabi.LA_ERR_LAUNCH:
+                    msg += f" (hipError {lib.la_last_hip_error()})"
+                raise RuntimeError(f"lite_attention::fwd: {msg}")
+            if _window_hook is not None:
+                _window_hook(i, out, w_begin * block_m, min(Sq, (w_begin + w_count) * block_m) if w_count else Sq)
     return out, softmax_lse, empty, empty
 
 

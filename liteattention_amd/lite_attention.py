@@ -140,6 +140,27 @@ class LiteAttention:
             print(f"[Info]: Percentage of tiles skipped: {1.0 - self._last_percentage:.2%}")
         return output
 
+    def call_windowed(self, query: Tensor, key: Tensor, value: Tensor, q_windows, window_hook=None,
+                      scale: Optional[float] = None, return_softmax_lse: bool = False, must_do_list: list = None,
+                      must_skip_list: list = None, q_descale=None, k_descale=None, v_descale=None
+                      ) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+        """``__call__`` as several launches, one per q-tile window ``(first q-tile, count)`` (C-ABI ``q_tile_begin`` /
+        ``q_tile_count``; tiles of ``get_MN``). Same lists, same ping-pong step, same results; rows of a window are
+        final when its launch completes, and ``window_hook(i, out, row_begin, row_end)`` is called right after window i
+        is enqueued — the head-sharded driver starts the xGMI all-gather of those rows there. The reference has one
+        launch per call (flash_fwd_launch_template.h:359) and no such entry point."""
+        from .flash_attn_interface import mha_fwd
+        read_list, write_list = self._get_read_write_lists(query, key, must_skip_list)
+        must_do = None
+        if read_list is not None:
+            must_do = self._must_do_device_row(must_do_list, query, read_list.shape[3])
+        q, k, v = [x if x.stride(-1) == 1 else x.contiguous() for x in (query, key, value)]
+        out, lse, *_ = mha_fwd(q, k, v, q_descale=q_descale, k_descale=k_descale, v_descale=v_descale,
+                               softmax_scale=scale, attn_read_list=read_list, attn_must_do_list=must_do,
+                               attn_write_list=write_list, thr=self.threshold, _must_do_is_1d=True,
+                               _q_windows=q_windows, _window_hook=window_hook)
+        return (out, lse) if return_softmax_lse else out
+
     # ---- state control ------------------------------------------------------------------------
     def reset_skip_state(self):
         """Forget the lists; the next call starts from "all tiles listed" (:293-304)."""

@@ -101,7 +101,15 @@ def qkskip_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, block_m: in
     qf, kf, vf = _f32c(q), _f32c(k), _f32c(v)
     B, Sq, H, D = qf.shape
     Sk, Dv = kf.shape[1], vf.shape[3]
-    assert kf.shape == (B, Sk, H, D) and vf.shape == (B, Sk, H, Dv), "oracle is MHA-only"
+    if kf.shape[2] != H:
+        # GQA / MQA: query head h uses K/V head h // g — restated as the reference's oracle does it, by repeating the
+        # K/V heads (and the per-K/V-head descales) g times (hopper/tests/test_util.py:275-284)
+        g = H // kf.shape[2]
+        assert kf.shape[2] * g == H and vf.shape[2] == kf.shape[2], "nheads_k must divide nheads"
+        kf, vf = kf.repeat_interleave(g, dim=2).contiguous(), vf.repeat_interleave(g, dim=2).contiguous()
+        q_descale, k_descale, v_descale = [None if t is None else t.detach().cpu().repeat_interleave(g, dim=1)
+                                           for t in (q_descale, k_descale, v_descale)]
+    assert kf.shape == (B, Sk, H, D) and vf.shape == (B, Sk, H, Dv)
     if softmax_scale is None:
         softmax_scale = D ** -0.5
     o = torch.empty(B, Sq, H, Dv, dtype=torch.float32)
@@ -163,6 +171,9 @@ def attention_dense_ref(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
     dtype_og = q.dtype
     if upcast:
         q, k, v = q.float(), k.float(), v.float()
+    if k.shape[2] != q.shape[2]:                       # GQA / MQA (test_util.py:283-284)
+        g = q.shape[2] // k.shape[2]
+        k, v = k.repeat_interleave(g, dim=2), v.repeat_interleave(g, dim=2)
     d = q.shape[-1]
     if softmax_scale is None:
         softmax_scale = 1.0 / math.sqrt(d)

@@ -36,12 +36,13 @@ def load_reference():
     return mod, test_util
 
 
-def dense_inputs(seed, B, Sq, Sk, H, D, dtype):
-    """Input recipe of hopper/tests/test_flash_attn.py:204-210: randn fp32 -> dtype -> fp32."""
+def dense_inputs(seed, B, Sq, Sk, H, D, dtype, Hk=None):
+    """Input recipe of hopper/tests/test_flash_attn.py:204-210: randn fp32 -> dtype -> fp32. Hk = K/V heads (GQA)."""
+    Hk = H if Hk is None else Hk
     g = torch.Generator().manual_seed(seed)
     q = torch.randn(B, Sq, H, D, generator=g).to(dtype).float()
-    k = torch.randn(B, Sk, H, D, generator=g).to(dtype).float()
-    v = torch.randn(B, Sk, H, D, generator=g).to(dtype).float()
+    k = torch.randn(B, Sk, Hk, D, generator=g).to(dtype).float()
+    v = torch.randn(B, Sk, Hk, D, generator=g).to(dtype).float()
     return q, k, v
 
 
@@ -160,6 +161,37 @@ def main():
             input_checksum=np.float64(q.double().sum().item() + 2 * k.double().sum().item() + 3 * v.double().sum().item()),
             meta=np.array([seed, B, Sq, Sk, H, D]), dtype=np.array("float8_e4m3fn"),
             q_descale=qd.numpy(), k_descale=kd.numpy(), v_descale=vd.numpy())
+        print(name, "pt_maxerr", (out_pt.float() - out_ref).abs().max().item())
+    # G5-GQA: nheads_k < nheads (attention_ref repeats the K/V heads, test_util.py:283-284; the fp8 descales are per
+    # K/V head, test_flash_attn.py:219). meta carries Hk as a 7th entry.
+    for name, seed, B, Sq, Sk, H, Hk, D, dt in [("gqa_bf16_b2_s300_h6_hk2_d128", 21, 2, 300, 300, 6, 2, 128, "bfloat16"),
+                                                ("mqa_bf16_sq130_sk517_h4_hk1_d64", 22, 1, 130, 517, 4, 1, 64, "bfloat16"),
+                                                ("gqa_fp8_b2_s260_h4_hk2_d128", 23, 2, 260, 260, 4, 2, 128, "float8_e4m3fn")]:
+        dtype = getattr(torch, dt)
+        q, k, v = dense_inputs(seed, B, Sq, Sk, H, D, dtype, Hk)
+        extra = {}
+        if dt == "float8_e4m3fn":
+            g = torch.Generator().manual_seed(1000 + seed)
+            qd, kd, vd = [torch.rand(B, Hk, generator=g) * 2 for _ in range(3)]
+            out_ref, _ = test_util.attention_ref(q, k, v, None, None, q_descale=qd, k_descale=kd, v_descale=vd)
+            out_pt, _ = test_util.attention_ref(q, k, v, None, None, q_descale=qd, k_descale=kd, v_descale=vd,
+                                                upcast=False, reorder_ops=True, intermediate_dtype=torch.float8_e4m3fn)
+            sc = (qd * kd).repeat_interleave(H // Hk, dim=1)[:, :, None, None]
+            extra = dict(q_descale=qd.numpy(), k_descale=kd.numpy(), v_descale=vd.numpy())
+        else:
+            out_ref, _ = test_util.attention_ref(q, k, v, None, None)
+            out_pt, _ = test_util.attention_ref(q.to(dtype), k.to(dtype), v.to(dtype), None, None, upcast=False,
+                                                reorder_ops=True)
+            sc = 1.0
+        kr = k.repeat_interleave(H // Hk, dim=2)
+        scores = torch.einsum("bthd,bshd->bhts", q, kr) * sc * (1.0 / D ** 0.5)
+        lse_ref = torch.logsumexp(scores, dim=-1)
+        np.savez_compressed(
+            os.path.join(HERE, f"dense_{name}.npz"),
+            out_ref=out_ref.numpy().astype(np.float32), lse_ref=lse_ref.numpy().astype(np.float32),
+            pt_maxerr=np.float32((out_pt.float() - out_ref).abs().max().item()),
+            input_checksum=np.float64(q.double().sum().item() + 2 * k.double().sum().item() + 3 * v.double().sum().item()),
+            meta=np.array([seed, B, Sq, Sk, H, D, Hk]), dtype=np.array(dt), **extra)
         print(name, "pt_maxerr", (out_pt.float() - out_ref).abs().max().item())
     print("wrote", sorted(os.listdir(HERE)))
 

@@ -9,22 +9,26 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 DENSE_CASES = ["cfg0_fp32_s2048_d64", "bf16_b2_s333_h3_d128", "bf16_s512_h2_d128", "bf16_sq113_sk203_h2_d128"]
 FP8_CASES = ["fp8_b2_s333_h3_d128", "fp8_sq200_sk777_h2_d128"]
+GQA_CASES = ["gqa_bf16_b2_s300_h6_hk2_d128", "mqa_bf16_sq130_sk517_h4_hk1_d64"]     # nheads_k < nheads
+GQA_FP8_CASES = ["gqa_fp8_b2_s260_h4_hk2_d128"]
 
 
-def dense_inputs(seed, B, Sq, Sk, H, D, dtype):
-    """randn fp32 -> dtype -> fp32 (hopper/tests/test_flash_attn.py:204-210), CPU generator."""
+def dense_inputs(seed, B, Sq, Sk, H, D, dtype, Hk=None):
+    """randn fp32 -> dtype -> fp32 (hopper/tests/test_flash_attn.py:204-210), CPU generator. Hk = K/V heads."""
+    Hk = H if Hk is None else Hk
     g = torch.Generator().manual_seed(seed)
     q = torch.randn(B, Sq, H, D, generator=g).to(dtype).float()
-    k = torch.randn(B, Sk, H, D, generator=g).to(dtype).float()
-    v = torch.randn(B, Sk, H, D, generator=g).to(dtype).float()
+    k = torch.randn(B, Sk, Hk, D, generator=g).to(dtype).float()
+    v = torch.randn(B, Sk, Hk, D, generator=g).to(dtype).float()
     return q, k, v
 
 
 def load_dense_case(name):
     z = np.load(os.path.join(GOLDEN, f"dense_{name}.npz"))
-    seed, B, Sq, Sk, H, D = [int(x) for x in z["meta"]]
+    seed, B, Sq, Sk, H, D = [int(x) for x in z["meta"][:6]]
+    Hk = int(z["meta"][6]) if len(z["meta"]) > 6 else H
     dtype = getattr(torch, str(z["dtype"]))
-    q, k, v = dense_inputs(seed, B, Sq, Sk, H, D, dtype)
+    q, k, v = dense_inputs(seed, B, Sq, Sk, H, D, dtype, Hk)
     chk = q.double().sum().item() + 2 * k.double().sum().item() + 3 * v.double().sum().item()
     assert abs(chk - float(z["input_checksum"])) < 1e-6, "torch CPU generator drifted: regenerate tests/golden"
     case = {"q": q, "k": k, "v": v, "dtype": dtype, "out_ref": torch.from_numpy(z["out_ref"]),

@@ -57,7 +57,7 @@ def test_tile_sizes_and_status_strings():
     m, n = ctypes.c_int(), ctypes.c_int()
     assert lib.la_get_tile_sizes(48, 2, ctypes.byref(m), ctypes.byref(n)) == _cabi.LA_ERR_HEAD_DIM
     assert lib.la_get_tile_sizes(128, 4, ctypes.byref(m), ctypes.byref(n)) == _cabi.LA_ERR_DTYPE
-    for code in range(0, -13, -1):
+    for code in range(0, -14, -1):
         s = _cabi.status_string(code)
         assert s and s != "unknown la_status", code
     assert _cabi.status_string(-99) == "unknown la_status"
@@ -78,9 +78,16 @@ def test_argument_validation_returns_codes_without_launching():
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_SHAPE
     a.batch, a.seqlen_q, a.seqlen_k, a.num_heads, a.num_heads_k, a.head_dim, a.head_dim_v = 1, 256, 256, 4, 3, 128, 128
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_SHAPE           # heads_k must divide heads
-    a.num_heads_k = 2
-    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_UNSUPPORTED     # GQA outside the hot path
-    a.num_heads_k = 4
+    a.num_heads_k = 2                                                          # GQA is built (ABI 3): passes this check
+    a.head_dim_v = 64
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_UNSUPPORTED     # head_dim_v != head_dim
+    a.head_dim_v = 128
+    a.reserved0 = 7
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_UNSUPPORTED     # reserved field must be 0
+    a.reserved0 = 0
+    a.flags = 0x80
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_UNSUPPORTED     # unknown flag
+    a.flags = 0
     a.head_dim = a.head_dim_v = 100
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_HEAD_DIM        # % 8 (flash_api.cpp:854)
     a.head_dim = a.head_dim_v = 96
@@ -93,12 +100,18 @@ def test_argument_validation_returns_codes_without_launching():
     a.write_list = 0x3000
     a.q_row_stride = 4 * 128 + 4
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_STRIDE
+    # q-tile window (ABI 3): Sq = 256 with 256-row tiles is ONE q-tile
+    a.q_row_stride = 4 * 128
+    for begin, count in ((1, 0), (0, 2), (1, 1), (-1, 1), (0, -1)):
+        a.q_tile_begin, a.q_tile_count = begin, count
+        assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_Q_WINDOW, (begin, count)
+    a.q_tile_begin = a.q_tile_count = 0
     # fp8: workspace contract
     a.q_row_stride = 4 * 128
     a.dtype = _cabi.LA_DTYPE_FP8_E4M3
     a.block_m = 128                                                            # the fp8 kernel's tile
     a.read_list = a.write_list = None
-    assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 1 * 4 * 4 * 8192     # B * H * Kt * 8 KiB
+    assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 1 * 2 * 4 * 8192     # B * Hk * Kt * 8 KiB
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_WORKSPACE
     a.dtype = _cabi.LA_DTYPE_BF16
     a.block_m = 256

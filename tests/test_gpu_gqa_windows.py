@@ -1,0 +1,140 @@
+"""GPU: GQA / MQA (nheads_k < nheads) and q-tile windows (C-ABI 3) on every forward kernel.
+
+Tolerances are those stated in test_gpu_parity.py / test_gpu_fp8.py (reference rule vs `out_ref`; 2^-8 max|O| + 1e-3 vs the
+tiled oracle; LSE 1e-3; lists bit-exact up to borderline tiles)."""
+import math
+
+import pytest
+import torch
+
+from helpers import GQA_CASES, GQA_FP8_CASES, load_dense_case, ref_tolerance, structured_qkv
+from test_gpu_parity import _compare_lists, _oracle_tol
+
+pytestmark = pytest.mark.gpu
+F8 = torch.float8_e4m3fn
+
+
+def _L():
+    import liteattention_amd as L
+    return L
+
+
+def _orc():
+    from oracle import oracle as orc
+    return orc
+
+
+@pytest.mark.parametrize("name", GQA_CASES)
+def test_gqa_dense_matches_reference_outputs(name):
+    """bf16 d128 (x64 kernel) and d64 (v2 kernel) with nheads_k < nheads against the reference's attention_ref outputs."""
+    L, orc = _L(), _orc()
+    c = load_dense_case(name)
+    D = c["D"]
+    bm, bn = L.get_tile_sizes(D, 2)
+    q, k, v = [x.to(torch.bfloat16).cuda() for x in (c["q"], c["k"], c["v"])]
+    out, lse = L.flash_attn_func(q, k, v, return_softmax_lse=True)
+    assert out.shape == q.shape and lse.shape == (q.shape[0], q.shape[2], q.shape[1])
+    err = (out.float().cpu() - c["out_ref"]).abs().max().item()
+    assert err <= ref_tolerance(c["out_ref"], c["pt_maxerr"]), (err, ref_tolerance(c["out_ref"], c["pt_maxerr"]))
+    assert (lse.cpu() - c["lse_ref"]).abs().max().item() <= 1e-3
+    o_t, lse_t, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=bm, block_n=bn)
+    assert (out.float().cpu() - o_t).abs().max().item() <= _oracle_tol(o_t)
+
+
+@pytest.mark.parametrize("name", GQA_FP8_CASES)
+def test_gqa_fp8_matches_reference_outputs(name):
+    """fp8 with nheads_k < nheads: descales are (batch, nheads_k) for q, k and v (flash_api.cpp:689-691); the V^T
+    workspace holds nheads_k heads."""
+    L, orc = _L(), _orc()
+    c = load_dense_case(name)
+    q, k, v = [x.to(F8).cuda() for x in (c["q"], c["k"], c["v"])]
+    qd, kd, vd = [c[n].cuda() for n in ("q_descale", "k_descale", "v_descale")]
+    out, lse = L.flash_attn_func(q, k, v, q_descale=qd, k_descale=kd, v_descale=vd, return_softmax_lse=True)
+    err = (out.float().cpu() - c["out_ref"]).abs().max().item()
+    assert err <= ref_tolerance(c["out_ref"], c["pt_maxerr"]), (err, ref_tolerance(c["out_ref"], c["pt_maxerr"]))
+    assert (lse.cpu() - c["lse_ref"]).abs().max().item() <= 1e-3
+    o8, lse8, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=128, block_n=64, p_round="fp8",
+                                 q_descale=c["q_descale"], k_descale=c["k_descale"], v_descale=c["v_descale"])
+    assert (out.float().cpu() - o8).abs().max().item() <= 0.05 * o8.abs().max().item() + 2e-2
+    assert (lse.cpu() - lse8).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("D", [128, 64])
+def test_gqa_skip_lists_match_oracle_over_steps(D):
+    """QK-Skip with GQA: lists are per QUERY head ([B, H, Qt, Kt+1]); 4 steps, same read list fed to the oracle."""
+    L, orc = _L(), _orc()
+    B, S, H, Hk, thr = 1, 1536, 4, 2, -3.0
+    bm, bn = L.get_tile_sizes(D, 2)
+    Qt, Kt = math.ceil(S / bm), math.ceil(S / bn)
+    att = L.LiteAttention(threshold=thr, max_batch_size=B)
+    margins = torch.empty(B, H, Qt, Kt)
+    listed = []
+    for step in range(4):
+        qk, k, v = structured_qkv(B, S, Hk, D, seed=31)
+        # query heads 2j, 2j+1 read K/V head j: give them that head's frame centroids so attention stays structured
+        q = qk.repeat_interleave(H // Hk, dim=2)
+        g = torch.Generator().manual_seed(500 + step)
+        q = (q.float() + 0.3 * torch.randn(q.shape, generator=g)).bfloat16()
+        rd_idx = att._phase if att._skip_list is not None else 0
+        out, lse = att(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
+        rd, wr = att._skip_list[rd_idx].cpu(), att._skip_list[1 - rd_idx].cpu()
+        assert tuple(rd.shape) == (B, H, Qt, Kt + 1)
+        wr_orc = torch.zeros_like(wr)
+        o_ref, lse_ref, n_tiles = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=rd, write_list=wr_orc, thr=thr,
+                                                 margins=margins)
+        assert (out.float().cpu() - o_ref).abs().max().item() <= _oracle_tol(o_ref)
+        assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
+        bad, _ = _compare_lists(orc, rd, wr, wr_orc, margins, thr, B)
+        assert bad == 0
+        listed.append(orc.listed_tiles(wr[:B]))
+    assert listed[-1] < 0.9 * B * H * Qt * Kt
+
+
+# ------------------------------------------------------------------------------------------ q-tile windows
+@pytest.mark.parametrize("dtype,D", [("bf16", 128), ("bf16", 64), ("fp8", 128)])
+def test_q_tile_windows_equal_one_launch_bit_exactly(dtype, D):
+    """`LiteAttention.call_windowed` (one launch per q-tile window, C-ABI q_tile_begin/q_tile_count) must reproduce the
+    single launch bit for bit: output, LSE and the written list, over several steps; the hook sees each window in order."""
+    L = _L()
+    B, S, H = 2, 1700, 3                      # ragged last q-tile
+    es = 1 if dtype == "fp8" else 2
+    bm, bn = L.get_tile_sizes(D, es)
+    Qt = math.ceil(S / bm)
+    q, k, v = structured_qkv(B, S, H, D, seed=9)
+    if dtype == "fp8":
+        q, k, v = [(x.float() * 0.25).to(F8) for x in (q, k, v)]
+    q, k, v = q.cuda(), k.cuda(), v.cuda()
+    cuts = sorted({0, 1, Qt // 2, Qt})
+    windows = [(a, b - a) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert len(windows) >= 2
+    one = L.LiteAttention(threshold=-2.0, max_batch_size=B)
+    win = L.LiteAttention(threshold=-2.0, max_batch_size=B)
+    for step in range(3):
+        seen = []
+        o1, l1 = one.call_windowed(q, k, v, [(0, Qt)], return_softmax_lse=True)
+        o2, l2 = win.call_windowed(q, k, v, windows, lambda i, out, r0, r1: seen.append((i, r0, r1)),
+                                   return_softmax_lse=True)
+        o0, l0 = (L.LiteAttention(threshold=-2.0, max_batch_size=B)(q, k, v, return_softmax_lse=True) if step == 0
+                  else (o1, l1))
+        assert torch.equal(o1, o2) and torch.equal(l1, l2) and torch.equal(o0, o1) and torch.equal(l0, l1)
+        assert torch.equal(one._skip_list, win._skip_list)
+        assert seen == [(i, a * bm, min(S, (a + n) * bm)) for i, (a, n) in enumerate(windows)]
+    assert one.get_skip_fraction() > 0.02
+
+
+def test_q_tile_window_leaves_other_rows_untouched_and_rejects_bad_windows():
+    L = _L()
+    from liteattention_amd.flash_attn_interface import mha_fwd
+    B, S, H, D = 1, 1024, 2, 128
+    bm, _ = L.get_tile_sizes(D, 2)
+    Qt = S // bm
+    g = torch.Generator().manual_seed(3)
+    q, k, v = [torch.randn(B, S, H, D, generator=g).bfloat16().cuda() for _ in range(3)]
+    full = L.flash_attn_func(q, k, v)
+    out = torch.full_like(full, 7.0)
+    mha_fwd(q, k, v, out=out, _q_windows=[(1, 1)])
+    assert torch.equal(out[:, bm:2 * bm], full[:, bm:2 * bm])
+    assert (out[:, :bm] == 7.0).all() and (out[:, 2 * bm:] == 7.0).all()
+    for bad in ([(0, Qt + 1)], [(Qt, 1)], [(-1, 1)], [(0, 0)]):
+        with pytest.raises(RuntimeError):
+            mha_fwd(q, k, v, _q_windows=bad)

@@ -203,3 +203,25 @@ def test_e4m3_rounding_matches_torch():
     mine = (torch.round(x / q) * q)
     # ties: torch.round is half-to-even, like rintf
     assert torch.equal(mine.clamp_max(448.0), ref)
+
+
+# ------------------------------------------------------------------------------------------- GQA / MQA
+from helpers import GQA_CASES, GQA_FP8_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("name", GQA_CASES + GQA_FP8_CASES)
+def test_gqa_oracle_matches_reference_outputs(name):
+    """nheads_k < nheads: query head h reads K/V head h // g (the reference's oracle repeats the K/V heads,
+    test_util.py:283-284; fp8 descales per K/V head, test_flash_attn.py:219)."""
+    c = load_dense_case(name)
+    assert c["k"].shape[2] < c["q"].shape[2]
+    fp8 = "q_descale" in c
+    kw = dict(q_descale=c["q_descale"], k_descale=c["k_descale"], v_descale=c["v_descale"]) if fp8 else {}
+    o32, lse32, n_tiles = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=128, block_n=64, p_round=False, **kw)
+    assert (o32 - c["out_ref"]).abs().max().item() <= 2e-5
+    assert (lse32 - c["lse_ref"]).abs().max().item() <= 5e-5
+    o_r, _, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=128, block_n=64, p_round="fp8" if fp8 else True, **kw)
+    assert (o_r - c["out_ref"]).abs().max().item() <= ref_tolerance(c["out_ref"], c["pt_maxerr"])
+    if not fp8:
+        out, lse = orc.attention_dense_ref(c["q"], c["k"], c["v"])
+        assert (out - c["out_ref"]).abs().max().item() <= 1e-6 and (lse - c["lse_ref"]).abs().max().item() <= 2e-5
