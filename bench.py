@@ -11,8 +11,10 @@ one self-attention call of Wan2.1-14B's video shape — B=1, S=75600, H=40, D=12
 every q-tile keeps the first walked tile plus a contiguous band of (1-s)*Kt key tiles centred on its
 diagonal; thr=-inf so the list is a fixed point and every step does identical work). A "step" is one such
 call. With N GPUs the 40 heads are sharded (40/N per rank, one skip state per rank, no data-path
-collective inside the attention) and the step ends with ONE RCCL all-gather of the bf16 output shard
-("scaling": "strong" — total work is fixed).
+collective inside the attention) and the step delivers the all-gathered bf16 output on every rank over RCCL
+("scaling": "strong" — total work is fixed). By default (--overlap-windows 3) the attention is issued as 3 launches over
+q-tile windows of whole workgroup rounds and the all-gather of window i's rows runs while window i+1 computes
+(liteattention_amd/parallel.py); --overlap-windows 1 is the plain "kernel, then one all-gather" step.
 
 `value` = executed TFLOP/s of the whole job = FLOPs of the LISTED tiles (4*rows*cols*D per tile, summed
 over all ranks) / step time; skipped tiles are never counted as work. The same JSON line carries the
@@ -140,6 +142,8 @@ def main():
     ap.add_argument("--heads", type=int, default=40)
     ap.add_argument("--no-sweep", action="store_true", help="skip the 1-GPU sparsity sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap-windows", type=int, default=3,
+                    help="N > 1: q-tile windows per step whose all-gathers overlap the next window's compute (1 = off)")
     ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
                     help="bf16 = headline (BASELINE.json configs[2,3]); fp8 = configs[4] (e4m3 Q/K/V, bf16 out)")
     args = ap.parse_args()
@@ -177,7 +181,8 @@ def main():
                for _ in range(3)]
 
     att = HeadShardedLiteAttention(num_heads=H, threshold=-10.0, max_batch_size=B,
-                                   process_group=None if world == 1 else dist.group.WORLD)
+                                   process_group=None if world == 1 else dist.group.WORLD,
+                                   overlap_windows=args.overlap_windows if world > 1 else 1)
     att.local.threshold = float("-inf")     # imposed lists are a fixed point: identical work every step
 
     def set_sparsity(s):
@@ -212,6 +217,21 @@ def main():
 
     # ---- headline: 42 % imposed sparsity
     rows = set_sparsity(HEADLINE_SPARSITY)
+    overlap_note = None
+    if world > 1 and att.overlap_windows > 1:
+        # one trial step of the overlapped form; every rank must agree to keep it (a rank-local failure would
+        # otherwise leave the others inside a collective), else all fall back to kernel-then-gather
+        ok = 1
+        try:
+            att(q, k, v)
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            ok, overlap_note = 0, f"overlapped all-gather failed ({e!r}); fell back to one all-gather after the kernel"
+        flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() == 0:
+            att.overlap_windows = 1
+            overlap_note = overlap_note or "another rank failed the overlapped all-gather; fell back"
     flops_rank = executed_flops(rows, Hl, B, S, S, bm, bn, D)
     step_s, kern_s = timed(args.steps, args.warmup)
     flops_job = flops_rank * world
@@ -228,7 +248,10 @@ def main():
         "config": {"workload": f"QK-Skip self-attention fwd, B={B} S={S} H={H} D={D} {args.dtype}, imposed "
                                f"{HEADLINE_SPARSITY:.0%} sparsity (banded lists, thr=-inf), tiles {bm}x{bn}",
                    "sparsity": round(1 - listed_frac, 4),
-                   "parallelism": f"heads sharded {world}x{Hl}" + (" + 1 RCCL all-gather of O per step" if world > 1 else ""),
+                   "parallelism": f"heads sharded {world}x{Hl}" + (
+                       "" if world == 1 else
+                       (f" + RCCL all-gather of O in {len(att.q_windows(q))} q-tile windows overlapped with compute"
+                        if att.overlap_windows > 1 else " + 1 RCCL all-gather of O per step")),
                    "dense_equiv_tflops": round(4.0 * B * H * S * S * D / step_s / 1e12, 2)},
         "roofline": {"bound": "mfma", "achieved": round(flops_rank / kern_s / 1e12, 2),
                      "peak": MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -238,6 +261,8 @@ def main():
                      "kernel_ms": round(kern_s * 1e3, 3),
                      "algorithmic_tflop_per_launch": round(flops_rank / 1e12, 3)},
     }
+    if overlap_note:
+        result["config"]["overlap_note"] = overlap_note
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
     if os.path.exists(pmc) and not fp8:
         try:

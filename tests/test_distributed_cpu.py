@@ -46,6 +46,31 @@ def _worker(rank, world, port, tmpdir):
         assert torch.allclose(full, ref, atol=1e-6), (full - ref).abs().max()
         local = att(att.shard(q), att.shard(k), att.shard(v), gather=False)
         assert torch.equal(local, ref[:, :, att.h0:att.h1])
+        # ---- overlapped form: q-tile windows, one async all-gather per window, row-chunked result
+        from liteattention_amd.parallel import plan_q_windows
+        hooks = []
+
+        def windowed_stand_in(q, k, v, windows, hook, scale=None, **kw):
+            out = orc.attention_dense_ref(q, k, v, softmax_scale=scale)[0]
+            for i, (t0, n) in enumerate(windows):      # the device op finalises rows window by window, in stream order
+                hooks.append((i, t0 * 16, min(q.shape[1], (t0 + n) * 16)))
+                hook(i, out, t0 * 16, min(q.shape[1], (t0 + n) * 16))
+            return out
+
+        att2 = HeadShardedLiteAttention(num_heads=H, max_batch_size=2, process_group=dist.group.WORLD,
+                                        overlap_windows=3, windowed_attention_fn=windowed_stand_in, q_tile_rows=16)
+        att2.q_windows = lambda q: [(0, 2), (2, 3), (5, 1)]              # 6 q-tiles of 16 rows, uneven windows
+        blocks = att2(att2.shard(q), att2.shard(k), att2.shard(v))
+        assert [tuple(b.shape) for b in blocks] == [(world, 2, 32, 3, 32), (world, 2, 48, 3, 32), (world, 2, 16, 3, 32)]
+        assert hooks == [(0, 0, 32), (1, 32, 80), (2, 80, 96)]
+        assert torch.allclose(HeadShardedLiteAttention.to_bshd(blocks), ref, atol=1e-6)
+        # window planning: whole rounds of 256 workgroups, last window takes the remainder
+        assert plan_q_windows(296, 5, 3) == [(0, 102), (102, 102), (204, 92)]       # 8 GPUs: 5 heads x 296 q-tiles
+        assert plan_q_windows(296, 20, 3) == [(0, 102), (102, 102), (204, 92)]      # 2 GPUs: 8 rounds of 256 = 102 q-tiles
+        assert plan_q_windows(296, 40, 1) == [(0, 296)] and plan_q_windows(1, 40, 4) == [(0, 1)]
+        for qt, wg, n in [(296, 5, 3), (296, 10, 4), (591, 5, 3), (7, 3, 5), (128, 40, 2)]:
+            w = plan_q_windows(qt, wg, n)
+            assert w[0][0] == 0 and all(a + c == b for (a, c), (b, _) in zip(w[:-1], w[1:])) and sum(c for _, c in w) == qt
         with pytest.raises(AssertionError):
             att(q, k, v)                               # full tensors are not a local shard
         with pytest.raises(ValueError):

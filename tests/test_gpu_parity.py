@@ -348,8 +348,11 @@ def test_error_behaviour():
         L.flash_attn_func(q, q, q, window_size=(16, 0))
     with pytest.raises(NotImplementedError):
         L.flash_attn_func(q, q, q, softcap=1.0)
+    with pytest.raises(RuntimeError, match="must divide"):
+        q3 = torch.randn(1, 256, 3, 128, device="cuda").bfloat16()
+        L.flash_attn_func(q3, q3[:, :, :2], q3[:, :, :2])                      # nheads_k must divide nheads (:777)
     with pytest.raises(NotImplementedError):
-        L.flash_attn_func(q, q[:, :, :1], q[:, :, :1])                         # GQA
+        L.flash_attn_func(q, q, q[..., :64])                                   # head_dim_v != head_dim
     q96 = torch.randn(1, 256, 2, 96, device="cuda").bfloat16()
     with pytest.raises(RuntimeError):
         L.flash_attn_func(q96, q96, q96)                                       # head_dim not instantiated
