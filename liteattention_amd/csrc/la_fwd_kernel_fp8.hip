@@ -10,9 +10,14 @@
 //
 // Same schedule as la_fwd_kernel_v2.hip (LDS-DMA staging, QK^T(i+1) under softmax(i), exact rescale skip, skip
 // votes and write list fused), with the fp8 specifics designed for CDNA4:
-//   * both GEMMs use v_mfma_f32_32x32x16_fp8_fp8 (8-byte A/B operands). The contraction index of QK^T is
-//     permuted so that ONE ds_read_b128 of a K row feeds two MFMAs: lane-half hh, k-step pair j holds
-//     d = 32j + 16hh + [0,16); first 8 bytes = k-step 2j, next 8 = k-step 2j+1 (Q fragments use the same map).
+//   * both GEMMs use the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 with every E8M0 scale = 127 (2^0): numerically
+//     a plain e4m3 x e4m3 -> fp32 MFMA, but the ONLY fp8 form that runs at twice the bf16 rate on gfx950 (the non-scaled
+//     v_mfma_f32_32x32x16_fp8_fp8 runs at the bf16 rate; MI355X_MICROARCH.md MFMA table). One instruction contracts 64
+//     indices: 32 bytes of A and of B per lane (two ds_read_b128). Per tile and wave: 4 MFMAs for S^T = K Q^T (2 key
+//     blocks x 2 halves of d) and 4 for O^T += V^T P^T (4 d-blocks x all 64 keys) instead of 16 + 16.
+//     (-DLA_FP8_PLAIN_MFMA builds the non-scaled form on the same operand bytes for A/B runs.)
+//   * the contraction index is permuted freely — A and B only have to agree: lane-half hh, 16-byte chunk j of QK^T
+//     holds d = 32j + 16hh + [0,16) for K rows and Q fragments alike; MFMA s uses chunks 2s, 2s+1.
 //   * no 8-bit transpose read: a prepare kernel (la_prep_v_fp8) rewrites V once per call into V^T tiles
 //     [B, H, Kt][128 d][64 keys] whose 64-byte rows already hold the keys in the order the PV operand wants
 //     (k-step pair j, lane-half hh, k-step parity, accumulator slot e <-> key 16kk + 4hh + (e&3) + 8(e>>2)) and are
@@ -37,6 +42,27 @@ constexpr int F8_VROW = F8_BN;                // bytes per V^T row (64 keys)
 typedef const __attribute__((address_space(1))) void* f8_gptr_t;
 typedef __attribute__((address_space(3))) void* f8_lptr_t;
 typedef long i64x2 __attribute__((ext_vector_type(2)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef long i64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int F8_SCALE_ONE = 0x7f7f7f7f;      // four E8M0 exponents of 127 = 2^0, whichever byte op_sel picks
+
+// acc += A(32 x 64 e4m3) * B(64 x 32 e4m3): lane-half hh carries 32 of the 64 contraction indices as 32 bytes, given here
+// as two 16-byte halves (lo = first 16 bytes). Unit block scales: exactly the fp32-accumulated e4m3 products.
+__device__ __forceinline__ f32x16 f8_mfma_k64(const i64x2 a_lo, const i64x2 a_hi, const i64x2 b_lo, const i64x2 b_hi, f32x16 acc) {
+#ifdef LA_FP8_PLAIN_MFMA
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a_lo[0], b_lo[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a_lo[1], b_lo[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a_hi[0], b_hi[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a_hi[1], b_hi[1], acc, 0, 0, 0);
+    return acc;
+#else
+    const i64x4 a4 = {a_lo[0], a_lo[1], a_hi[0], a_hi[1]};
+    const i64x4 b4 = {b_lo[0], b_lo[1], b_hi[0], b_hi[1]};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_bit_cast(i32x8, a4), __builtin_bit_cast(i32x8, b4), acc,
+                                                           0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, F8_SCALE_ONE, 0, F8_SCALE_ONE);
+#endif
+}
 
 __device__ __forceinline__ void f8_dma16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((f8_gptr_t)gsrc, (f8_lptr_t)lds_dst, 16, 0, 0);
@@ -232,10 +258,10 @@ la_fwd_fp8_d128_kernel(const FwdParams p) {
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
             const unsigned char* kt = k_lds + kbuf * F8_TILE + kb * 32 * F8_KROW + k_rd;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const i64x2 kf = *reinterpret_cast<const i64x2*>(kt + (((2 * j + hh) ^ k_rd_sw) << 4));
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(kf[0], qf[j][0], s[kb], 0, 0, 0);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(kf[1], qf[j][1], s[kb], 0, 0, 0);
+            for (int sx = 0; sx < 2; ++sx) {                 // d = 64*sx + {16hh + [0,16), 32 + 16hh + [0,16)}
+                const i64x2 k_lo = *reinterpret_cast<const i64x2*>(kt + (((4 * sx + hh) ^ k_rd_sw) << 4));
+                const i64x2 k_hi = *reinterpret_cast<const i64x2*>(kt + (((4 * sx + 2 + hh) ^ k_rd_sw) << 4));
+                s[kb] = f8_mfma_k64(k_lo, k_hi, qf[2 * sx], qf[2 * sx + 1], s[kb]);
             }
         }
     };
@@ -310,14 +336,12 @@ la_fwd_fp8_d128_kernel(const FwdParams p) {
 
         // ---- phase 2: O^T += V^T P^T of tile i  ||  stats of tile i+1
         const unsigned char* vt = v_lds + cur * F8_TILE + v_rd;
+        const i64x2 p_lo = {pf[0], pf[1]}, p_hi = {pf[2], pf[3]};      // all 64 keys of the tile: one MFMA per d-block
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const i64x2 vf = *reinterpret_cast<const i64x2*>(vt + db * 32 * F8_VROW + (((2 * j + hh) ^ v_rd_sw) << 4));
-                o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf[0], pf[2 * j], o_acc[db], 0, 0, 0);
-                o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf[1], pf[2 * j + 1], o_acc[db], 0, 0, 0);
-            }
+            const i64x2 v_lo = *reinterpret_cast<const i64x2*>(vt + db * 32 * F8_VROW + ((hh ^ v_rd_sw) << 4));
+            const i64x2 v_hi = *reinterpret_cast<const i64x2*>(vt + db * 32 * F8_VROW + (((2 + hh) ^ v_rd_sw) << 4));
+            o_acc[db] = f8_mfma_k64(v_lo, v_hi, p_lo, p_hi, o_acc[db]);
         }
         alpha = stats(s_nxt, i + 1, has_next);
         if (!__all(alpha == 1.0f)) {

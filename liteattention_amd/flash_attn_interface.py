@@ -69,9 +69,22 @@ _FWD_SCHEMA = (
 )
 
 
+def kernel_head_dim(head_dim: int, element_size: int) -> int:
+    """The instantiated head_dim that serves ``head_dim``: itself for 64 / 128 (bf16) and 128 (fp8), else the next
+    instantiated size up — the host zero-pads q, k, v to it (``mha_fwd``), which is exact: zero columns add 0 to
+    every score and give zero output columns, which are sliced away. The reference instantiates 64/96/128/192/256
+    (hopper/setup.py:57-61) and picks the next size up the same way (flash_api.cpp round_up_headdim); above 128
+    nothing is built here and the library's typed error is raised."""
+    if head_dim <= 0 or head_dim % (16 if element_size == 1 else 8) != 0:
+        return head_dim                                      # la_get_tile_sizes / mha_fwd report the error
+    if element_size == 2 and head_dim <= 64:
+        return 64
+    return 128 if head_dim <= 128 else head_dim
+
+
 def get_tile_sizes(head_dim: int, element_size: int) -> Tuple[int, int]:
-    """(kBlockM, kBlockN) of the gfx950 kernel — the single source for skip-list geometry."""
-    return _cabi.get_tile_sizes(head_dim, element_size)
+    """(kBlockM, kBlockN) of the gfx950 kernel that serves this head_dim — the single source for skip-list geometry."""
+    return _cabi.get_tile_sizes(kernel_head_dim(head_dim, element_size), element_size)
 
 
 def _check_list(t: Optional[torch.Tensor], name: str, q: torch.Tensor) -> Optional[int]:
@@ -159,6 +172,26 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
         raise NotImplementedError("head_dim_v != head_dim is outside the QK-Skip hot path in this build")
     if softmax_scale is None:
         softmax_scale = D ** -0.5
+
+    D_kernel = kernel_head_dim(D, q.element_size())
+    if D_kernel != D:
+        # head_dim between the instantiated sizes: zero-pad the last dim (one extra pass over q, k, v; exact, see
+        # kernel_head_dim), run the D_kernel kernel with the ORIGINAL softmax scale, slice the output
+        def pad_last(t):                                     # fp8: pad the bytes (0x00 is +0.0 in e4m3)
+            if is_fp8:
+                return torch.nn.functional.pad(t.view(torch.uint8), (0, D_kernel - D)).view(t.dtype)
+            return torch.nn.functional.pad(t, (0, D_kernel - D))
+        qp, kp, vp = pad_last(q), pad_last(k), pad_last(v)
+        res = mha_fwd(qp, kp, vp, q_descale=q_descale, k_descale=k_descale, v_descale=v_descale,
+                      softmax_scale=softmax_scale, attn_read_list=attn_read_list, attn_must_do_list=attn_must_do_list,
+                      attn_write_list=attn_write_list, thr=thr, _must_do_is_1d=_must_do_is_1d, _q_windows=_q_windows,
+                      _window_hook=None if _window_hook is None else
+                      (lambda i, o, r0, r1: _window_hook(i, o[..., :D], r0, r1)))
+        o = res[0][..., :D]
+        if out is not None:
+            out.copy_(o)
+            o = out
+        return (o, *res[1:])
 
     if out is None:
         out = torch.empty((B, Sq, H, Dv), dtype=torch.bfloat16, device=q.device)                 # :872-886

@@ -90,6 +90,9 @@ def test_fp8_errors():
     qb = torch.randn(1, 256, 2, 128, device="cuda").bfloat16()
     with pytest.raises(RuntimeError, match="only supported for fp8"):
         L.flash_attn_func(qb, qb, qb, q_descale=torch.ones(1, 2, device="cuda"))
-    q64 = torch.randn(1, 256, 2, 64, device="cuda").to(F8)
-    with pytest.raises(RuntimeError):
-        L.flash_attn_func(q64, q64, q64)                                                    # fp8 head_dim 64 not built
+    q192 = torch.randn(1, 256, 2, 192, device="cuda").to(F8)
+    with pytest.raises(RuntimeError, match="head_size"):
+        L.flash_attn_func(q192, q192, q192)                                                 # fp8 head_dim > 128 not built
+    q72 = torch.randn(1, 256, 2, 72, device="cuda").bfloat16().view(torch.int16)[..., :72].view(torch.bfloat16)
+    with pytest.raises(RuntimeError, match="multiple of 16"):
+        L.flash_attn_func(q72.to(F8), q72.to(F8), q72.to(F8))                               # fp8: head_size % 16 (:854-856)

@@ -138,3 +138,36 @@ def test_q_tile_window_leaves_other_rows_untouched_and_rejects_bad_windows():
     for bad in ([(0, Qt + 1)], [(Qt, 1)], [(-1, 1)], [(0, 0)]):
         with pytest.raises(RuntimeError):
             mha_fwd(q, k, v, _q_windows=bad)
+
+
+# ------------------------------------------------------------------------------------------ head dims between instantiations
+@pytest.mark.parametrize("D,dtype", [(96, "bf16"), (40, "bf16"), (72, "bf16"), (96, "fp8")])
+def test_other_head_dims_run_on_the_next_instantiated_kernel(D, dtype):
+    """head_dim 96 (instantiated by the reference, hopper/setup.py:58) and other multiples of 8 below 128 run the next
+    kernel up on zero-padded operands; results must match the oracle at the ORIGINAL head_dim (scale D^-0.5) and the lists
+    use the serving kernel's tiles."""
+    L, orc = _L(), _orc()
+    from liteattention_amd.flash_attn_interface import kernel_head_dim
+    es = 1 if dtype == "fp8" else 2
+    B, S, H = 1, 700, 2
+    bm, bn = L.get_tile_sizes(D, es)
+    assert (bm, bn) == L.get_tile_sizes(kernel_head_dim(D, es), es)
+    q, k, v = structured_qkv(B, S, H, D, seed=D)
+    if dtype == "fp8":
+        q, k, v = [x.float().to(F8) for x in (q, k, v)]
+    att = L.LiteAttention(threshold=-3.0, max_batch_size=B)
+    Qt, Kt = math.ceil(S / bm), math.ceil(S / bn)
+    margins = torch.empty(B, H, Qt, Kt)
+    for step in range(2):
+        rd_idx = att._phase if att._skip_list is not None else 0
+        out, lse = att(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
+        assert out.shape == (B, S, H, D)
+        rd, wr = att._skip_list[rd_idx].cpu(), att._skip_list[1 - rd_idx].cpu()
+        wr_orc = torch.zeros_like(wr)
+        o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=rd, write_list=wr_orc, thr=-3.0,
+                                           margins=margins, p_round="fp8" if dtype == "fp8" else True)
+        tol = (0.05 * o_ref.abs().max().item() + 2e-2) if dtype == "fp8" else _oracle_tol(o_ref)
+        assert (out.float().cpu() - o_ref).abs().max().item() <= tol
+        assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
+        bad, _ = _compare_lists(orc, rd, wr, wr_orc, margins, -3.0, B)
+        assert bad == 0

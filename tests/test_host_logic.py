@@ -37,8 +37,14 @@ def test_g1_reference_tile_table_is_recorded_and_build_table_comes_from_library(
     assert ref[(128, 2, False)] == (128, 176) and ref[(128, 1, False)] == (128, 224)   # tile_size.h:35-40,54-55
     # the build's table is the kernel's (la_get_tile_sizes), not a copy of the Hopper one
     assert L.LiteAttention.get_MN(128, 2) == L.get_tile_sizes(128, 2) == (256, 64)
+    # like the reference table (d <= 64, <= 96, <= 128, ... tile_size.h:17-61) a head_dim between two instantiated sizes
+    # gets the tiles of the next one up — the kernel that serves it on zero-padded operands
+    assert L.get_tile_sizes(40, 2) == L.get_tile_sizes(64, 2) and L.get_tile_sizes(96, 2) == L.get_tile_sizes(128, 2)
+    assert L.get_tile_sizes(96, 1) == L.get_tile_sizes(128, 1)
     with pytest.raises(RuntimeError):
-        L.get_tile_sizes(40, 2)
+        L.get_tile_sizes(192, 2)                           # above 128: nothing instantiated
+    with pytest.raises(RuntimeError):
+        L.get_tile_sizes(100, 2)                           # not a multiple of 8 (flash_api.cpp:854)
 
 
 def test_g2_init_skip_list_rows_match_reference_for_same_tile_counts():
