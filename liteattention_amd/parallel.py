@@ -163,3 +163,125 @@ class HeadShardedLiteAttention:
 
     def set_threshold(self, threshold: float):
         self.local.set_threshold(threshold)
+
+
+class UlyssesLiteAttention:
+    """Sequence-sharded in, sequence-sharded out; heads sharded inside (the DeepSpeed-Ulysses scheme, which is what
+    Wan2.x multi-GPU inference uses around its attention). Rank r holds rows [r*S/G, (r+1)*S/G) of q, k, v for ALL heads;
+    one all-to-all turns that into all rows of heads [r*H/G, (r+1)*H/G), the QK-Skip attention runs there on this rank's
+    own skip state (as in ``HeadShardedLiteAttention``), and a second all-to-all returns the rows. Compared with the
+    all-gather driver each rank moves (G-1)/G of ONE shard per direction instead of receiving G-1 shards, and the
+    output lands where a sequence-parallel transformer block wants it.
+
+    ``__call__(q, k, v)``: (B, S/G, H, D) each -> (B, S/G, H, D). All ranks must hold the same number of rows."""
+
+    def __init__(self, num_heads: int, enable_skipping: bool = True, threshold: float = -10.0, max_batch_size: int = 4,
+                 process_group=None, attention_fn: Optional[Callable[..., torch.Tensor]] = None):
+        self.inner = HeadShardedLiteAttention(num_heads, enable_skipping, threshold, max_batch_size, process_group,
+                                              attention_fn=attention_fn)
+        self.group, self.world, self.rank = process_group, self.inner.world, self.inner.rank
+        self.num_heads = num_heads
+
+    @property
+    def local(self) -> LiteAttention:
+        return self.inner.local
+
+    def _all_to_all(self, x: torch.Tensor) -> torch.Tensor:
+        import torch.distributed as dist
+        out = torch.empty_like(x)
+        dist.all_to_all_single(out, x, group=self.group)
+        return out
+
+    def seq_to_head(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, S/G, H, D) on every rank -> (B, S, H/G, D): block g of the send buffer = my rows of rank g's heads."""
+        G = self.world
+        if G == 1:
+            return x
+        B, Sl, H, D = x.shape
+        send = x.reshape(B, Sl, G, H // G, D).permute(2, 0, 1, 3, 4).contiguous()       # (G, B, Sl, Hl, D)
+        recv = self._all_to_all(send)                                                    # block g = rows of rank g
+        return recv.permute(1, 0, 2, 3, 4).reshape(B, G * Sl, H // G, D)
+
+    def head_to_seq(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, S, H/G, D) -> (B, S/G, H, D): the inverse exchange."""
+        G = self.world
+        if G == 1:
+            return x
+        B, S, Hl, D = x.shape
+        send = x.reshape(B, G, S // G, Hl, D).permute(1, 0, 2, 3, 4).contiguous()        # (G, B, Sl, Hl, D): rows of rank g
+        recv = self._all_to_all(send)                                                    # block g = heads of rank g
+        return recv.permute(1, 2, 0, 3, 4).reshape(B, S // G, G * Hl, D)
+
+    def __call__(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None, **kw) -> torch.Tensor:
+        assert q.shape[2] == self.num_heads and k.shape[2] == self.num_heads, "pass all heads of the local rows"
+        qh, kh, vh = self.seq_to_head(q), self.seq_to_head(k), self.seq_to_head(v)
+        out = self.inner(qh, kh, vh, scale, gather=False, **kw)
+        return self.head_to_seq(out)
+
+    def reset_skip_state(self):
+        self.inner.reset_skip_state()
+
+    def set_threshold(self, threshold: float):
+        self.inner.set_threshold(threshold)
+
+
+class RingSeqParallelLiteAttention:
+    """Ring (context-parallel) attention over sequence shards with the reference's ``SeqParallelLiteAttention`` state
+    layout: rank r keeps its query rows; the K/V shards travel round the ring (RCCL send/recv to the next rank, receive
+    from the previous one, posted BEFORE the attention on the block in hand so the transfer hides under it), every
+    (local Q x K/V shard j) pair owns skip state j (hopper/lite_attention.py:322-345: one LiteAttention per split,
+    selected by ``split_idx``), and the G partial results are merged by their LSE (``flash_attn_combine`` — the merge the
+    reference's README leaves to the caller, README.md:222-250; oracle hopper/tests/test_flash_attn.py:1178-1187).
+
+    ``__call__(q, k, v)``: (B, S/G, H, D) each -> (B, S/G, H, D)."""
+
+    def __init__(self, enable_skipping: bool = True, threshold: float = -10.0, max_batch_size: int = 4, process_group=None,
+                 attention_fn: Optional[Callable[..., Tuple[torch.Tensor, torch.Tensor]]] = None,
+                 combine_fn: Optional[Callable[..., torch.Tensor]] = None):
+        from .lite_attention import SeqParallelLiteAttention
+        self.group = process_group
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+        else:
+            self.world, self.rank = 1, 0
+        self.states = SeqParallelLiteAttention(self.world, enable_skipping, threshold, max_batch_size)
+        # test seams (CPU/gloo): attention_fn(q, k, v, split_idx, scale) -> (out, lse); combine_fn(outs, lses) -> out
+        self._attention = attention_fn if attention_fn is not None else (
+            lambda q, k, v, j, scale: self.states(q, k, v, j, scale, return_softmax_lse=True))
+        if combine_fn is None:
+            from .flash_attn_interface import flash_attn_combine
+            combine_fn = lambda outs, lses: flash_attn_combine(outs, lses, return_lse=False)   # noqa: E731
+        self._combine = combine_fn
+
+    def __call__(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None) -> torch.Tensor:
+        G, r = self.world, self.rank
+        if G == 1:
+            out, _ = self._attention(q, k, v, 0, scale)
+            return out
+        import torch.distributed as dist
+        nxt, prv = (r + 1) % G, (r - 1) % G
+        k_cur, v_cur = k.contiguous(), v.contiguous()
+        outs, lses = [], []
+        for step in range(G):
+            src = (r - step) % G                       # the rank whose K/V shard is in hand = the skip state to use
+            reqs = []
+            if step + 1 < G:                           # pass the block on while it is being used (read-only here)
+                k_nxt, v_nxt = torch.empty_like(k_cur), torch.empty_like(v_cur)
+                ops = [dist.P2POp(dist.isend, k_cur, nxt, group=self.group), dist.P2POp(dist.isend, v_cur, nxt, group=self.group),
+                       dist.P2POp(dist.irecv, k_nxt, prv, group=self.group), dist.P2POp(dist.irecv, v_nxt, prv, group=self.group)]
+                reqs = dist.batch_isend_irecv(ops)
+            out, lse = self._attention(q, k_cur, v_cur, src, scale)
+            outs.append(out)
+            lses.append(lse)
+            for req in reqs:
+                req.wait()
+            if step + 1 < G:
+                k_cur, v_cur = k_nxt, v_nxt
+        return self._combine(torch.stack(outs), torch.stack(lses))
+
+    def reset_skip_state(self):
+        self.states.reset_skip_state()
+
+    def set_threshold(self, threshold: float):
+        self.states.set_threshold(threshold)

@@ -71,6 +71,35 @@ def _worker(rank, world, port, tmpdir):
         for qt, wg, n in [(296, 5, 3), (296, 10, 4), (591, 5, 3), (7, 3, 5), (128, 40, 2)]:
             w = plan_q_windows(qt, wg, n)
             assert w[0][0] == 0 and all(a + c == b for (a, c), (b, _) in zip(w[:-1], w[1:])) and sum(c for _, c in w) == qt
+        # ---- Ulysses: sequence shards in and out, two all-to-alls, heads sharded inside
+        from liteattention_amd.parallel import RingSeqParallelLiteAttention, UlyssesLiteAttention
+        Sl = q.shape[1] // world
+        rows = slice(rank * Sl, (rank + 1) * Sl)
+        calls.clear()
+        uly = UlyssesLiteAttention(num_heads=H, max_batch_size=2, process_group=dist.group.WORLD, attention_fn=stand_in)
+        qh = uly.seq_to_head(q[:, rows].contiguous())
+        assert torch.equal(qh, q[:, :, rank * 3: rank * 3 + 3])             # all rows of my heads
+        assert torch.equal(uly.head_to_seq(qh), q[:, rows])                  # and back
+        o_u = uly(q[:, rows].contiguous(), k[:, rows].contiguous(), v[:, rows].contiguous())
+        assert calls == [(2, 96, 3, 32)] and o_u.shape == (2, Sl, H, 32)
+        assert torch.allclose(o_u, ref[:, rows], atol=1e-6)
+        # ---- ring: K/V shards travel, state j for (my Q x shard j), LSE merge of the partial results
+        used = []
+
+        def partial_attention(qq, kk, vv, split_idx, scale=None):
+            used.append(split_idx)
+            o, l = orc.attention_dense_ref(qq, kk, vv, softmax_scale=scale)
+            return o, l
+
+        def combine(outs, lses):                                             # (G,B,Sl,H,D), (G,B,H,Sl)
+            return orc.attention_combine_ref(outs, lses.transpose(2, 3))[0]
+
+        ring = RingSeqParallelLiteAttention(max_batch_size=2, process_group=dist.group.WORLD,
+                                            attention_fn=partial_attention, combine_fn=combine)
+        o_r = ring(q[:, rows].contiguous(), k[:, rows].contiguous(), v[:, rows].contiguous())
+        assert used == [rank, (rank - 1) % world]                            # own shard first, then the previous rank's
+        assert torch.allclose(o_r, ref[:, rows], atol=1e-5), (o_r - ref[:, rows]).abs().max()
+        assert len(ring.states.lite_attention) == world
         with pytest.raises(AssertionError):
             att(q, k, v)                               # full tensors are not a local shard
         with pytest.raises(ValueError):
