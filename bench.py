@@ -128,9 +128,29 @@ def cpu_baseline(S, D, bm, bn, rows, target_seconds=15.0):
     while dt < 10.0 and reps < 8:               # many-core hosts finish one head quickly: repeat the sample
         d2, f2 = run(n_qt)
         dt, fl, reps = dt + d2, fl + f2, reps + 1
-    return {"value": round(fl / dt / 1e12, 5), "unit": "TFLOP/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x [1 head x {n_qt} q-tiles ({n_qt * bm} query rows) x all {S} keys at the 42% list], "
-                      f"{fl / 1e9:.1f} GFLOP in {dt:.1f} s (oracle/qkskip_oracle.c, OpenMP)"}
+    res = {"value": round(fl / dt / 1e12, 5), "unit": "TFLOP/s", "cores": threads, "kind": "port",
+           "sample": f"{reps} x [1 head x {n_qt} q-tiles ({n_qt * bm} query rows) x all {S} keys at the 42% list], "
+                     f"{fl / 1e9:.1f} GFLOP in {dt:.1f} s (oracle/qkskip_oracle.c, OpenMP)"}
+    # beside it: the reference's EAGER PyTorch path (attention_ref of hopper/tests/test_util.py:226-348 as restated in
+    # oracle.attention_dense_ref: fp32 einsum -> softmax -> einsum) on the same host cores. It has no skip lists: dense,
+    # one head, 2048-row query chunks against all S keys (0.6 GB of scores per chunk), a few seconds.
+    try:
+        torch.set_num_threads(threads)
+        chunk, n_chunks, t_e = 2048, 0, 0.0
+        qe = torch.randn(1, chunk, 1, D, generator=g).bfloat16()
+        orc.attention_dense_ref(qe[:, :256], k, v)                       # warm-up (thread pool, allocator)
+        while t_e < 4.0 and n_chunks < 16:
+            t0 = time.perf_counter()
+            orc.attention_dense_ref(qe, k, v)
+            t_e += time.perf_counter() - t0
+            n_chunks += 1
+        fl_e = 4.0 * chunk * S * D * n_chunks
+        res["eager_torch"] = {"value": round(fl_e / t_e / 1e12, 5), "unit": "TFLOP/s (dense)", "cores": threads,
+                              "sample": f"{n_chunks} x [1 head x {chunk} query rows x all {S} keys, dense], "
+                                        f"{fl_e / 1e9:.1f} GFLOP in {t_e:.1f} s (torch {torch.__version__} CPU eager)"}
+    except Exception as e:  # noqa: BLE001
+        res["eager_torch"] = {"value": None, "sample": f"failed: {e!r}"}
+    return res
 
 
 def main():

@@ -205,11 +205,27 @@ la_fwd_fp8_d128_kernel(const FwdParams p) {
     const int rip = lane >> 3;
     const int cpos = lane & 7;
     const int last_row = p.seqlen_k - 1;
+    // per-lane byte offsets inside a full tile (row 16w + 8j + rip, swizzled source chunk): the per-step address is a
+    // wave-uniform tile base + this 32-bit offset (saddr + voffset form: no per-step VALU address arithmetic)
+    unsigned k_lane_off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 16 * wave + 8 * j + rip;
+        k_lane_off[j] = static_cast<unsigned>(r) * static_cast<unsigned>(k_rs) + ((cpos ^ f8_k_swz(r)) << 4);
+    }
     auto dma_k = [&](int n, int kbuf) {
+        const int row0 = n * F8_BN;
+        if (__builtin_expect(row0 + F8_BN - 1 <= last_row, 1)) {         // wave-uniform: every tile but a ragged last one
+            const uint8_t* base = kg + static_cast<int64_t>(row0) * k_rs;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                f8_dma16(base + k_lane_off[j], k_lds + kbuf * F8_TILE + (2 * wave + j) * 1024);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int r = 16 * wave + 8 * j + rip;
-            const int grow = min(n * F8_BN + r, last_row);              // rows past seqlen_k: clamp (masked / P = 0)
+            const int grow = min(row0 + r, last_row);                    // rows past seqlen_k: clamp (masked / P = 0)
             f8_dma16(kg + static_cast<int64_t>(grow) * k_rs + ((cpos ^ f8_k_swz(r)) << 4),
                      k_lds + kbuf * F8_TILE + (2 * wave + j) * 1024);
         }
@@ -323,7 +339,9 @@ la_fwd_fp8_d128_kernel(const FwdParams p) {
             }
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                int w0 = 0, w1 = 0;
+                // `old` of the first convert is a value that dies here (the convert works in place on its register):
+                // both halves are overwritten, so no zero has to be materialised per word
+                int w0 = __float_as_int(s_cur[kb][8 * hf + 0]), w1 = __float_as_int(s_cur[kb][8 * hf + 4]);
                 w0 = __builtin_amdgcn_cvt_pk_fp8_f32(s_cur[kb][8 * hf + 0], s_cur[kb][8 * hf + 1], w0, false);
                 w0 = __builtin_amdgcn_cvt_pk_fp8_f32(s_cur[kb][8 * hf + 2], s_cur[kb][8 * hf + 3], w0, true);
                 w1 = __builtin_amdgcn_cvt_pk_fp8_f32(s_cur[kb][8 * hf + 4], s_cur[kb][8 * hf + 5], w1, false);
