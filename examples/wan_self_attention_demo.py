@@ -78,6 +78,9 @@ def run(frames=5, height=16, width=16, heads=4, steps=6, threshold=-6.0, seed=0,
     dim, grid = heads * 128, (frames, height, width)
     S = frames * height * width
     sparse = WanLikeSelfAttention(dim, heads, threshold=threshold).to(device)
+    # random q and k projections give unstructured scores (nothing to skip); tie them, as a stand-in for trained weights
+    # under which tokens of the same frame attend to each other
+    sparse.k.load_state_dict(sparse.q.state_dict())
     dense = WanLikeSelfAttention(dim, heads, enable_skipping=False).to(device)
     dense.load_state_dict(sparse.state_dict())
     # a latent with frame-to-frame structure, denoised over `steps` steps (noise level 0.5 -> 0.05)

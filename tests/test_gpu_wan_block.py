@@ -20,3 +20,34 @@ def test_wan_style_block_runs_and_skipping_stays_close_to_dense():
     # threshold very negative: nothing may be skipped and the block equals the dense block to bf16 round-off
     rows = demo.run(frames=4, height=16, width=20, heads=3, steps=2, threshold=-60.0, verbose=False)
     assert rows[-1][1] == 0.0 and rows[-1][2] < 1e-6
+
+
+def test_two_steps_capture_into_a_hip_graph_and_replay():
+    """HIP graphs instead of a tracing compiler: `LiteAttention.__call__` makes no host sync and allocates only through
+    torch's allocator, so a PAIR of denoising steps (one per ping-pong phase) captures into one graph; every replay
+    advances the skip state by two steps exactly as two eager calls do."""
+    import liteattention_amd as L
+    from helpers import structured_qkv
+    q, k, v = [x.cuda() for x in structured_qkv(1, 1536, 2, 128, seed=11)]
+    eager = L.LiteAttention(threshold=-3.0, max_batch_size=1)
+    graphed = L.LiteAttention(threshold=-3.0, max_batch_size=1)
+    # side stream warm-up (allocates the lists), then rewind the state so both objects start equal
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        graphed(q, k, v)
+    torch.cuda.current_stream().wait_stream(s)
+    graphed._skip_list.copy_(L.LiteAttention.init_skip_list(1, 1536, 2, 128, False, torch.bfloat16, "cuda"))
+    graphed._phase = 0
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        o_a = graphed(q, k, v)
+        o_b = graphed(q, k, v)
+    graphed._skip_list.copy_(L.LiteAttention.init_skip_list(1, 1536, 2, 128, False, torch.bfloat16, "cuda"))
+    for rep in range(3):
+        g.replay()
+        e_a = eager(q, k, v)
+        e_b = eager(q, k, v)
+        torch.cuda.synchronize()
+        assert torch.equal(o_a, e_a) and torch.equal(o_b, e_b), rep
+        assert torch.equal(graphed._skip_list, eager._skip_list), rep
+    assert eager.get_skip_fraction() > 0.02
