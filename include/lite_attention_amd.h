@@ -116,8 +116,13 @@ typedef struct la_fwd_args {
 
     int32_t block_m, block_n;    /* echo of la_get_tile_sizes(); checked                          */
 
-    /* fp8 only: caller-owned scratch for the pre-transposed V tiles (the library allocates nothing).
-     * Size from la_fwd_workspace_bytes(); 16-byte aligned; contents are scratch, valid during the call. */
+    /* Caller-owned scratch (the library allocates nothing). Size from la_fwd_workspace_bytes(); 16-byte aligned;
+     * contents are scratch, valid during the call (stream-ordered).
+     *   fp8: REQUIRED — the pre-transposed V tiles.
+     *   bf16 head_dim 128 with skip lists: OPTIONAL, 256 bytes — a ticket counter. With it the launch uses one
+     *   persistent workgroup per CU and distributes the (batch, head, q-tile) items dynamically, which removes the
+     *   cross-XCD imbalance real skip lists cause (items differ 2-3x in length; the hardware's workgroup->XCD
+     *   assignment is static). Without it: one workgroup per item, static map. Results are identical. */
     void*    workspace;
     uint64_t workspace_bytes;
 
@@ -136,7 +141,8 @@ typedef struct la_fwd_args {
  * Skip-list geometry depends on them, so host code must take them from here. */
 int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n);
 
-/* Bytes of `workspace` la_fwd needs for these arguments (0 for bf16). Negative la_status on bad arguments. */
+/* Bytes of `workspace` la_fwd wants for these arguments (fp8: required; bf16 with lists: optional, see la_fwd_args;
+ * 0 otherwise). Negative la_status on bad arguments. */
 int64_t la_fwd_workspace_bytes(const la_fwd_args* args);
 
 /* The forward pass. `stream` is a hipStream_t. */

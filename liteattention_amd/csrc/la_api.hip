@@ -32,6 +32,12 @@ Bf16Kernel bf16_d128_kernel() {
     }();
     return k;
 }
+// LA_SCHED=static disables the dynamic (ticket) work distribution of the x64 kernel for A/B runs.
+bool dynamic_sched_enabled() {
+    static const bool on = [] { const char* e = getenv("LA_SCHED"); return !(e && e[0] == 's'); }();
+    return on;
+}
+constexpr uint64_t kSchedWorkspaceBytes = 256;
 float rescale_tau() {
     static const float t = [] { const char* e = getenv("LA_RESCALE_TAU"); return e ? static_cast<float>(atof(e)) : 8.0f; }();
     return t;
@@ -76,13 +82,16 @@ int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n
 int64_t la_fwd_workspace_bytes(const la_fwd_args* a) {
     if (a == nullptr) return LA_ERR_NULL_ARG;
     if (a->struct_size != sizeof(la_fwd_args)) return LA_ERR_STRUCT_SIZE;
-    if (a->dtype == LA_DTYPE_BF16) return 0;
+    if (a->dtype == LA_DTYPE_BF16)      // ticket counter of the dynamic work distribution (launches with lists)
+        return (a->read_list != nullptr && bf16_d128_kernel() != Bf16Kernel::hand && dynamic_sched_enabled())
+                   ? static_cast<int64_t>(kSchedWorkspaceBytes) : 0;
     if (a->dtype != LA_DTYPE_FP8_E4M3) return LA_ERR_DTYPE;
     int bm = 0, bn = 0;
     const int trc = la_get_tile_sizes(a->head_dim, 1, &bm, &bn);
     if (trc != LA_OK) return trc;
     if (a->batch <= 0 || a->num_heads <= 0 || a->num_heads_k <= 0 || a->seqlen_k < 0) return LA_ERR_SHAPE;
-    return static_cast<int64_t>(la::fp8_workspace_bytes(a->batch, a->num_heads_k, (a->seqlen_k + bn - 1) / bn));
+    // V^T tiles, then the ticket counter of the dynamic work distribution
+    return static_cast<int64_t>(la::fp8_workspace_bytes(a->batch, a->num_heads_k, (a->seqlen_k + bn - 1) / bn) + kSchedWorkspaceBytes);
 }
 
 int la_fwd(const la_fwd_args* a, void* stream_) {
@@ -125,8 +134,11 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
 
     la::FwdParams p{};
     if (fp8) {
-        const size_t need = la::fp8_workspace_bytes(a->batch, a->num_heads_k, (a->seqlen_k + bn - 1) / bn);
-        if (a->workspace == nullptr || a->workspace_bytes < need || !aligned16(a->workspace)) return LA_ERR_WORKSPACE;
+        const size_t tiles = la::fp8_workspace_bytes(a->batch, a->num_heads_k, (a->seqlen_k + bn - 1) / bn);
+        if (a->workspace == nullptr || a->workspace_bytes < tiles + kSchedWorkspaceBytes || !aligned16(a->workspace))
+            return LA_ERR_WORKSPACE;
+        if (a->read_list != nullptr && dynamic_sched_enabled())
+            p.work_counter = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(a->workspace) + tiles);
     }
     p.q = static_cast<const uint16_t*>(a->q);
     p.k = static_cast<const uint16_t*>(a->k);
@@ -181,6 +193,11 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     const bool skipable = a->read_list != nullptr;                                      // is_skipable, flash_api.cpp:931
     const Bf16Kernel kern = a->head_dim == 128 ? bf16_d128_kernel() : Bf16Kernel::v2;
     hipError_t err;
+    // optional workspace (la_fwd_workspace_bytes): with it, launches that walk lists use persistent workgroups and a
+    // ticket counter; without it, the static one-workgroup-per-item map (same results either way)
+    if (skipable && kern != Bf16Kernel::hand && a->workspace != nullptr && a->workspace_bytes >= kSchedWorkspaceBytes &&
+        aligned16(a->workspace) && dynamic_sched_enabled())
+        p.work_counter = static_cast<unsigned*>(a->workspace);
     if (kern == Bf16Kernel::x64) {
         if (la::fwd_lds_bytes_x64(p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
         err = la::launch_fwd_bf16_d128_x64(p, skipable, stream);

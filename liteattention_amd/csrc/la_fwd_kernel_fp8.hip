@@ -155,7 +155,20 @@ la_fwd_fp8_d128_kernel(const FwdParams p) {
     const int hh = lane >> 5;
     const int l31 = lane & 31;
 
-    const int vid = xcd_work_id();
+    // Work distribution: static (one workgroup per item, XCD-aware map) or, with a ticket counter in the caller's workspace,
+    // persistent workgroups that take the next (batch, head, q-tile) item until none is left — see la_fwd_kernel_x64.hip.
+    const bool dynamic = p.work_counter != nullptr;
+    const int total_work = p.batch * p.num_heads * p.q_tile_count;
+  for (;;) {
+    int vid;
+    if (dynamic) {
+        if (tid == 0) meta[1] = static_cast<int>(atomicAdd(p.work_counter, 1u));
+        __syncthreads();
+        vid = meta[1];
+        if (vid >= total_work) return;
+    } else {
+        vid = xcd_work_id();
+    }
     const int m_block = p.q_tile_begin + vid % p.q_tile_count;
     const int bh = vid / p.q_tile_count;
     const int h = bh % p.num_heads;
@@ -423,6 +436,9 @@ la_fwd_fp8_d128_kernel(const FwdParams p) {
             write_skip_list_wave(seq, endflags, doflags, n_tiles, p.write_list + list_off, md, k_tiles, lane);
         }
     }
+    if (!dynamic) return;
+    __syncthreads();   // every wave is done with this item's LDS before the next one is set up
+  }
 }
 
 size_t fwd_lds_bytes_fp8(int k_tiles, int* seq_cap_out) {
@@ -447,12 +463,16 @@ hipError_t launch_fwd_fp8_d128(const FwdParams& p, bool skipable, hipStream_t st
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   static_cast<int>(lds));
         if (err != hipSuccess) return err;
-        hipLaunchKernelGGL(kfn, dim3(total), dim3(256), lds, stream, pp);
+        int grid = total;
+        err = prepare_work_queue(pp, true, total, 2, stream, &grid);                       // two workgroups per CU
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, pp);
     } else {
         auto kfn = la_fwd_fp8_d128_kernel<false>;
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   static_cast<int>(lds));
         if (err != hipSuccess) return err;
+        pp.work_counter = nullptr;
         hipLaunchKernelGGL(kfn, dim3(total), dim3(256), lds, stream, pp);
     }
     return hipGetLastError();

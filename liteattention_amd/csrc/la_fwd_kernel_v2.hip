@@ -95,7 +95,20 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
     const int hh = lane >> 5;
     const int l31 = lane & 31;
 
-    const int vid = xcd_work_id();
+    // Work distribution: static (one workgroup per item, XCD-aware map) or, with a ticket counter in the caller's workspace,
+    // persistent workgroups that take the next (batch, head, q-tile) item until none is left — see la_fwd_kernel_x64.hip.
+    const bool dynamic = p.work_counter != nullptr;
+    const int total_work = p.batch * p.num_heads * p.q_tile_count;
+  for (;;) {
+    int vid;
+    if (dynamic) {
+        if (tid == 0) meta[1] = static_cast<int>(atomicAdd(p.work_counter, 1u));
+        __syncthreads();
+        vid = meta[1];
+        if (vid >= total_work) return;
+    } else {
+        vid = xcd_work_id();
+    }
     const int m_block = p.q_tile_begin + vid % p.q_tile_count;
     const int bh = vid / p.q_tile_count;
     const int h = bh % p.num_heads;
@@ -376,6 +389,9 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
 #endif
         }
     }
+    if (!dynamic) return;
+    __syncthreads();   // every wave is done with this item's LDS before the next one is set up
+  }
 }
 
 size_t fwd_lds_bytes_v2(int head_dim, int k_tiles, int* seq_cap_out) {
@@ -395,7 +411,10 @@ static hipError_t launch_v2(const FwdParams& p, hipStream_t stream) {
     const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(kfn, dim3(total), dim3(256), lds, stream, pp);
+    int grid = total;
+    const hipError_t qerr = prepare_work_queue(pp, SKIPABLE, total, 2, stream, &grid);     // two workgroups per CU
+    if (qerr != hipSuccess) return qerr;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, pp);
     return hipGetLastError();
 }
 

@@ -25,6 +25,8 @@ struct FwdParams {
     float scale_log2;       // softmax_scale * log2(e)   (flash_api.cpp:125-126)
     float rescale_tau;      // x64 kernel: O/l follow the running max only when it grew by more than this (log2 units)
     float thr;
+    unsigned* work_counter; // x64 + lists: zeroed ticket counter in caller workspace -> persistent workgroups take work items
+                            // dynamically (skip lists make items unequal); nullptr -> one workgroup per item, static XCD map
     const int* read_list;
     int* write_list;
     const int* must_do_list;
@@ -37,6 +39,20 @@ struct FwdParams {
     int64_t k_descale_batch_stride, k_descale_head_stride;
     int64_t v_descale_batch_stride, v_descale_head_stride;
 };
+
+// Dynamic work distribution: zero the ticket counter on `stream` and return the persistent grid (workgroups per CU x CUs,
+// capped by the number of items). work_counter == nullptr -> static: one workgroup per item.
+int compute_units();
+inline hipError_t prepare_work_queue(FwdParams& p, bool skipable, int total, int wg_per_cu, hipStream_t stream, int* grid) {
+    *grid = total;
+    if (!skipable) p.work_counter = nullptr;        // dense: every item costs the same, the static map is balanced
+    if (p.work_counter == nullptr) return hipSuccess;
+    const hipError_t err = hipMemsetAsync(p.work_counter, 0, sizeof(unsigned), stream);
+    if (err != hipSuccess) return err;
+    const int slots = wg_per_cu * compute_units();
+    *grid = total < slots ? total : slots;
+    return hipSuccess;
+}
 
 size_t fwd_lds_bytes_v2(int head_dim, int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, hipStream_t stream);   // v2: LDS-DMA, pipelined; head_dim 128 / 64

@@ -246,13 +246,13 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     a.must_do_is_1d = 1 if _must_do_is_1d else 0
     a.thr = float(thr)
     a.block_m, a.block_n = block_m, block_n
+    # caller-owned scratch (the C side allocates nothing): fp8 = the pre-transposed V tiles; bf16 with lists = the ticket
+    # counter of the dynamic work distribution. Freed after the launch by the caching allocator's stream-ordered reuse.
     workspace = None
-    if is_fp8:
-        # scratch for the pre-transposed V tiles: caller-owned (the C side allocates nothing); freed after the
-        # launch by the caching allocator's stream-ordered reuse
-        need = _cabi.load().la_fwd_workspace_bytes(ctypes.byref(a))
-        if need < 0:
-            raise RuntimeError(f"lite_attention::fwd: {_cabi.status_string(int(need))}")
+    need = _cabi.load().la_fwd_workspace_bytes(ctypes.byref(a))
+    if need < 0:
+        raise RuntimeError(f"lite_attention::fwd: {_cabi.status_string(int(need))}")
+    if need > 0:
         workspace = torch.empty(int(need), dtype=torch.uint8, device=q.device)
         a.workspace, a.workspace_bytes = workspace.data_ptr(), int(need)
     windows = [(0, 0)] if _q_windows is None else [(int(b0), int(c0)) for b0, c0 in _q_windows]
