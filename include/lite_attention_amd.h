@@ -55,6 +55,10 @@ typedef enum la_status {
 } la_status;
 
 /* la_fwd_args.flags */
+#define LA_FLAG_STATIC_SCHED 2u  /* keep one workgroup per item (static XCD map) even when a workspace is given. For
+                                  * launches that must share the GPU with another kernel while they run — e.g. an RCCL
+                                  * collective on another stream: persistent workgroups would hold every CU until the
+                                  * launch ends, per-item workgroups release a CU every item. */
 #define LA_FLAG_V_PREPARED 1u    /* fp8: `workspace` already holds the prepared V^T tiles of THIS v (an earlier
                                   * la_fwd call on the same v/workspace): skip the prepare pass. Lets a caller
                                   * split one attention into several q-tile windows (below) and pay for it once. */

@@ -57,6 +57,7 @@ class LaFwdArgs(ctypes.Structure):
 
 
 LA_FLAG_V_PREPARED = 1
+LA_FLAG_STATIC_SCHED = 2
 
 
 class NativeLibraryError(RuntimeError):

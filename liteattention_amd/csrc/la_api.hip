@@ -108,7 +108,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     if (a->num_heads % a->num_heads_k != 0) return LA_ERR_SHAPE;                          // flash_api.cpp:777
     if (a->head_dim % (fp8 ? 16 : 8) != 0) return LA_ERR_HEAD_DIM;                         // flash_api.cpp:854-856
     if (a->head_dim_v != a->head_dim) return LA_ERR_UNSUPPORTED;
-    if (a->reserved0 != 0 || (a->flags & ~LA_FLAG_V_PREPARED) != 0) return LA_ERR_UNSUPPORTED;
+    if (a->reserved0 != 0 || (a->flags & ~(LA_FLAG_V_PREPARED | LA_FLAG_STATIC_SCHED)) != 0) return LA_ERR_UNSUPPORTED;
     int bm = 0, bn = 0;
     const int trc = la_get_tile_sizes(a->head_dim, esize, &bm, &bn);
     if (trc != LA_OK) return trc;
@@ -137,7 +137,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         const size_t tiles = la::fp8_workspace_bytes(a->batch, a->num_heads_k, (a->seqlen_k + bn - 1) / bn);
         if (a->workspace == nullptr || a->workspace_bytes < tiles + kSchedWorkspaceBytes || !aligned16(a->workspace))
             return LA_ERR_WORKSPACE;
-        if (a->read_list != nullptr && dynamic_sched_enabled())
+        if (a->read_list != nullptr && dynamic_sched_enabled() && !(a->flags & LA_FLAG_STATIC_SCHED))
             p.work_counter = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(a->workspace) + tiles);
     }
     p.q = static_cast<const uint16_t*>(a->q);
@@ -196,7 +196,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     // optional workspace (la_fwd_workspace_bytes): with it, launches that walk lists use persistent workgroups and a
     // ticket counter; without it, the static one-workgroup-per-item map (same results either way)
     if (skipable && kern != Bf16Kernel::hand && a->workspace != nullptr && a->workspace_bytes >= kSchedWorkspaceBytes &&
-        aligned16(a->workspace) && dynamic_sched_enabled())
+        aligned16(a->workspace) && dynamic_sched_enabled() && !(a->flags & LA_FLAG_STATIC_SCHED))
         p.work_counter = static_cast<unsigned*>(a->workspace);
     if (kern == Bf16Kernel::x64) {
         if (la::fwd_lds_bytes_x64(p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;

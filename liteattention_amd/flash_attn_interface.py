@@ -109,7 +109,7 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
             is_causal=False, window_size_left=-1, window_size_right=-1, attention_chunk=0, softcap=0.0,
             is_rotary_interleaved=False, scheduler_metadata=None, num_splits=0, pack_gqa=None, sm_margin=0,
             attn_read_list=None, attn_must_do_list=None, attn_write_list=None, thr=-3.0,
-            _must_do_is_1d: bool = False, _q_windows=None, _window_hook=None):
+            _must_do_is_1d: bool = False, _q_windows=None, _window_hook=None, _static_sched: bool = False):
     """Host half of the op (flash_api.cpp:667-1249) for the non-causal, fixed-length subset (MHA / GQA / MQA) that
     ``LiteAttention.__call__`` reaches. Returns ``(out, softmax_lse, out_accum, softmax_lse_accum)``.
 
@@ -117,7 +117,8 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     ``_q_windows`` = [(first q-tile, q-tile count), ...]: the call becomes one launch per window on the current
     stream, ``_window_hook(i, out, row_begin, row_end)`` runs after window i has been enqueued (rows
     [row_begin, row_end) of ``out`` are complete once that launch is; used to all-gather early rows while later
-    windows compute)."""
+    windows compute). ``_static_sched`` sets LA_FLAG_STATIC_SCHED (per-item workgroups instead of persistent ones: a
+    collective running beside the launch gets CUs as items retire)."""
     if not q.is_cuda:
         raise RuntimeError("lite_attention::fwd has no CPU implementation (HIP device tensors required)")
     if q.dtype not in (torch.bfloat16, torch.float8_e4m3fn):
@@ -185,6 +186,7 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
         res = mha_fwd(qp, kp, vp, q_descale=q_descale, k_descale=k_descale, v_descale=v_descale,
                       softmax_scale=softmax_scale, attn_read_list=attn_read_list, attn_must_do_list=attn_must_do_list,
                       attn_write_list=attn_write_list, thr=thr, _must_do_is_1d=_must_do_is_1d, _q_windows=_q_windows,
+                      _static_sched=_static_sched,
                       _window_hook=None if _window_hook is None else
                       (lambda i, o, r0, r1: _window_hook(i, o[..., :D], r0, r1)))
         o = res[0][..., :D]
@@ -262,7 +264,8 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     with torch.cuda.device(q.device):                                                             # CUDAGuard :885
         for i, (w_begin, w_count) in enumerate(windows):
             a.q_tile_begin, a.q_tile_count = w_begin, w_count
-            a.flags = _cabi.LA_FLAG_V_PREPARED if (is_fp8 and i > 0) else 0     # V^T tiles prepared by window 0
+            a.flags = (_cabi.LA_FLAG_V_PREPARED if (is_fp8 and i > 0) else 0) | \
+                      (_cabi.LA_FLAG_STATIC_SCHED if _static_sched else 0)       # V^T tiles prepared by window 0
             stream = torch.cuda.current_stream(q.device).cuda_stream                              # :1219
             rc = lib.la_fwd(ctypes.byref(a), ctypes.c_void_p(stream))
             if rc != _cabi.LA_OK:

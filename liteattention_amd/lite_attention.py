@@ -142,8 +142,8 @@ class LiteAttention:
 
     def call_windowed(self, query: Tensor, key: Tensor, value: Tensor, q_windows, window_hook=None,
                       scale: Optional[float] = None, return_softmax_lse: bool = False, must_do_list: list = None,
-                      must_skip_list: list = None, q_descale=None, k_descale=None, v_descale=None
-                      ) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+                      must_skip_list: list = None, q_descale=None, k_descale=None, v_descale=None,
+                      static_sched: bool = False) -> Union[Tensor, Tuple[Tensor, Tensor]]:
         """``__call__`` as several launches, one per q-tile window ``(first q-tile, count)`` (C-ABI ``q_tile_begin`` /
         ``q_tile_count``; tiles of ``get_MN``). Same lists, same ping-pong step, same results; rows of a window are
         final when its launch completes, and ``window_hook(i, out, row_begin, row_end)`` is called right after window i
@@ -158,7 +158,7 @@ class LiteAttention:
         out, lse, *_ = mha_fwd(q, k, v, q_descale=q_descale, k_descale=k_descale, v_descale=v_descale,
                                softmax_scale=scale, attn_read_list=read_list, attn_must_do_list=must_do,
                                attn_write_list=write_list, thr=self.threshold, _must_do_is_1d=True,
-                               _q_windows=q_windows, _window_hook=window_hook)
+                               _q_windows=q_windows, _window_hook=window_hook, _static_sched=static_sched)
         return (out, lse) if return_softmax_lse else out
 
     # ---- state control ------------------------------------------------------------------------

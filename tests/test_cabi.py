@@ -85,7 +85,7 @@ def test_argument_validation_returns_codes_without_launching():
     a.reserved0 = 7
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_UNSUPPORTED     # reserved field must be 0
     a.reserved0 = 0
-    a.flags = 0x80
+    a.flags = 0x84
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_UNSUPPORTED     # unknown flag
     a.flags = 0
     a.head_dim = a.head_dim_v = 100
