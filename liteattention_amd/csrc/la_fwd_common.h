@@ -150,6 +150,33 @@ __device__ __forceinline__ int xcd_work_id() {
     return ((idx / C) * 8 + xcd) * C + (idx % C);
 }
 
+// Work item of a virtual id / ticket: (batch*head index, q-tile).
+//  * q-tiles of a head are taken in the order [last, 0, 1, 2, ...]: under the descending key walk a tile can only be
+//    flagged against the running max SO FAR, so query rows whose dominant keys come late in the walk (low q-tiles of a
+//    self-attention) keep the longest lists, and the zero-padded last q-tile never skips anything (zero rows vote "do"):
+//    long items first is the list-scheduling rule (LPT).
+//  * dynamic (ticket) mode deals GROUPS OF 4 HEADS with their q-tiles interleaved: the final group then has 4x as many
+//    items to pack into the last round (makespan / ideal 1.088 -> 1.008 in a list-scheduling simulation on the per-row
+//    counts of a real 78 % list, tools/frag_bench.py), while the K/V live set stays at 4 heads (155 MB at S = 75 600, inside the
+//    256 MB Infinity Cache).
+__device__ __forceinline__ void work_item(const FwdParams& p, int vid, bool dynamic, int& bh, int& m_block) {
+    const int cnt = p.q_tile_count;
+    int qi;
+    if (dynamic) {
+        constexpr int G = 4;
+        const int grp = vid / (G * cnt);
+        const int bh0 = grp * G;
+        const int g = min(G, p.batch * p.num_heads - bh0);        // heads in this group (only the last group can be short)
+        const int i = vid - grp * G * cnt;
+        qi = i / g;
+        bh = bh0 + i % g;
+    } else {
+        qi = vid % cnt;
+        bh = vid / cnt;
+    }
+    m_block = p.q_tile_begin + (qi + cnt - 1) % cnt;
+}
+
 // Expand one read-list row into the LDS tile sequence (one wave, 64 ranges per pass). Returns the number of
 // tiles (wave-uniform). Real lists hold hundreds of short ranges per row, so the ranges are handled in parallel:
 // lane r takes range 64*pass + r, an exclusive wave scan of the range sizes gives its first position, then every

@@ -169,8 +169,8 @@ la_fwd_fp8_d128_kernel(const FwdParams p) {
     } else {
         vid = xcd_work_id();
     }
-    const int m_block = p.q_tile_begin + vid % p.q_tile_count;
-    const int bh = vid / p.q_tile_count;
+    int bh, m_block;
+    work_item(p, vid, dynamic, bh, m_block);
     const int h = bh % p.num_heads;
     const int b = bh / p.num_heads;
     const int k_tiles = p.k_tiles;
