@@ -165,7 +165,7 @@ la_fwd_fp8_d128_kernel(const FwdParams p) {
         if (tid == 0) meta[1] = static_cast<int>(atomicAdd(p.work_counter, 1u));
         __syncthreads();
         vid = meta[1];
-        if (vid >= total_work) return;
+        if (static_cast<unsigned>(vid) >= static_cast<unsigned>(total_work)) return;     // also a corrupted counter ends the loop
     } else {
         vid = xcd_work_id();
     }
