@@ -195,6 +195,7 @@ __device__ __forceinline__ int expand_read_list(const int* __restrict__ row, int
             start = min(max(row[1 + 2 * r], 0), k_tiles - 1);
             const int end = min(max(row[2 + 2 * r], 0), k_tiles - 1);
             cnt = max(start - end + 1, 0);
+            if (r == 0) cnt = max(cnt, 1);        // the first tile of the first range is always walked (mainloop...:1614-1660)
         }
         int incl = cnt;                                       // inclusive scan over the wave
 #pragma unroll

@@ -171,3 +171,42 @@ def test_other_head_dims_run_on_the_next_instantiated_kernel(D, dtype):
         assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
         bad, _ = _compare_lists(orc, rd, wr, wr_orc, margins, -3.0, B)
         assert bad == 0
+
+
+# ------------------------------------------------------------------------------------------ malformed lists
+@pytest.mark.parametrize("dtype,D", [("bf16", 128), ("bf16", 64), ("fp8", 128)])
+def test_malformed_read_lists_are_memory_safe(dtype, D):
+    """Caller-owned lists can hold anything. Indices are clamped to [0, Kt), the number of walked tiles to Kt, the first
+    tile of the first range is always walked (as the reference's prologue does, mainloop...:1614-1660): garbage lists must
+    neither fault nor hang, and an inverted first range behaves as in the oracle."""
+    L, orc = _L(), _orc()
+    es = 1 if dtype == "fp8" else 2
+    B, S, H = 1, 1000, 2
+    bm, bn = L.get_tile_sizes(D, es)
+    Qt, Kt = math.ceil(S / bm), math.ceil(S / bn)
+    q, k, v = structured_qkv(B, S, H, D, seed=5)
+    if dtype == "fp8":
+        q, k, v = [x.float().to(F8) for x in (q, k, v)]
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    g = torch.Generator().manual_seed(99)
+    for trial in range(6):
+        lists = torch.randint(-2 ** 31, 2 ** 31 - 1, (2, B, H, Qt, Kt + 1), generator=g, dtype=torch.int64).to(torch.int32)
+        if trial % 2:
+            lists = lists % 23 - 3                             # small values: plausible-looking but inconsistent rows
+        lists = lists.cuda()
+        out, lse = L.flash_attn_func(qd, kd, vd, attn_read_list=lists[0], attn_write_list=lists[1], thr=-3.0,
+                                     return_softmax_lse=True)
+        torch.cuda.synchronize()
+        assert out.shape == qd.shape and bool(torch.isfinite(out.float()).all())
+        w = lists[1]
+        assert bool((w[..., 0] >= 0).all()) and bool((w[..., 0] <= Kt).all())      # the writer stays inside its row
+    # inverted first range [2, 3, 7]: start < end -> exactly tile 3 is computed, by the kernel and by the oracle
+    rows = torch.zeros(2, B, H, Qt, Kt + 1, dtype=torch.int32)
+    rows[..., 0], rows[..., 1], rows[..., 2] = 2, 3, 7
+    out = L.flash_attn_func(qd, kd, vd, attn_read_list=rows[0].cuda(), attn_write_list=rows[1].cuda(), thr=-3.0)
+    wr = torch.zeros_like(rows[1])
+    o_ref, _, n_tiles = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=rows[0], write_list=wr, thr=-3.0,
+                                       p_round="fp8" if dtype == "fp8" else True)
+    assert n_tiles == B * H * Qt
+    tol = (0.05 * o_ref.abs().max().item() + 2e-2) if dtype == "fp8" else _oracle_tol(o_ref)
+    assert (out.float().cpu() - o_ref).abs().max().item() <= tol
