@@ -283,8 +283,8 @@ def main():
     }
     if overlap_note:
         result["config"]["overlap_note"] = overlap_note
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if os.path.exists(pmc) and not fp8:
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary_fp8.json" if fp8 else "r01_pmc_summary.json")
+    if os.path.exists(pmc):
         try:
             with open(pmc) as f:
                 p = json.load(f)

@@ -123,7 +123,7 @@ typedef struct la_fwd_args {
     /* Caller-owned scratch (the library allocates nothing). Size from la_fwd_workspace_bytes(); 16-byte aligned;
      * contents are scratch, valid during the call (stream-ordered).
      *   fp8: REQUIRED — the pre-transposed V tiles.
-     *   bf16 head_dim 128 with skip lists: OPTIONAL, 256 bytes — a ticket counter. With it the launch uses one
+     *   bf16 with skip lists: OPTIONAL, 1 KiB — eight ticket counters (one queue per XCD). With it the launch uses one
      *   persistent workgroup per CU and distributes the (batch, head, q-tile) items dynamically, which removes the
      *   cross-XCD imbalance real skip lists cause (items differ 2-3x in length; the hardware's workgroup->XCD
      *   assignment is static). Without it: one workgroup per item, static map. Results are identical. */

@@ -37,7 +37,7 @@ bool dynamic_sched_enabled() {
     static const bool on = [] { const char* e = getenv("LA_SCHED"); return !(e && e[0] == 's'); }();
     return on;
 }
-constexpr uint64_t kSchedWorkspaceBytes = 256;
+constexpr uint64_t kSchedWorkspaceBytes = 1024;   // 8 ticket counters of 64 bytes (+ slack)
 float rescale_tau() {
     static const float t = [] { const char* e = getenv("LA_RESCALE_TAU"); return e ? static_cast<float>(atof(e)) : 8.0f; }();
     return t;

@@ -150,31 +150,95 @@ __device__ __forceinline__ int xcd_work_id() {
     return ((idx / C) * 8 + xcd) * C + (idx % C);
 }
 
-// Work item of a virtual id / ticket: (batch*head index, q-tile).
-//  * q-tiles of a head are taken in the order [last, 0, 1, 2, ...]: under the descending key walk a tile can only be
-//    flagged against the running max SO FAR, so query rows whose dominant keys come late in the walk (low q-tiles of a
-//    self-attention) keep the longest lists, and the zero-padded last q-tile never skips anything (zero rows vote "do"):
-//    long items first is the list-scheduling rule (LPT).
-//  * dynamic (ticket) mode deals GROUPS OF 4 HEADS with their q-tiles interleaved: the final group then has 4x as many
-//    items to pack into the last round (makespan / ideal 1.088 -> 1.008 in a list-scheduling simulation on the per-row
-//    counts of a real 78 % list, tools/frag_bench.py), while the K/V live set stays at 4 heads (155 MB at S = 75 600, inside the
-//    256 MB Infinity Cache).
-__device__ __forceinline__ void work_item(const FwdParams& p, int vid, bool dynamic, int& bh, int& m_block) {
+// Work item of a static virtual id: (batch*head index, q-tile). q-tiles of a head are taken in the order
+// [last, 0, 1, 2, ...]: under the descending key walk a tile can only be flagged against the running max SO FAR, so query
+// rows whose dominant keys come late in the walk (low q-tiles of a self-attention) keep the longest lists, and the
+// zero-padded last q-tile never skips anything (zero rows vote "do"): long items first is the list-scheduling rule (LPT).
+__device__ __forceinline__ void work_item(const FwdParams& p, int vid, int& bh, int& m_block) {
     const int cnt = p.q_tile_count;
-    int qi;
-    if (dynamic) {
-        constexpr int G = 4;
-        const int grp = vid / (G * cnt);
-        const int bh0 = grp * G;
-        const int g = min(G, p.batch * p.num_heads - bh0);        // heads in this group (only the last group can be short)
-        const int i = vid - grp * G * cnt;
-        qi = i / g;
-        bh = bh0 + i % g;
-    } else {
-        qi = vid % cnt;
-        bh = vid / cnt;
+    bh = vid / cnt;
+    m_block = p.q_tile_begin + (vid % cnt + cnt - 1) % cnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dynamic work distribution (launches with skip lists; persistent workgroups). ONE thread calls next_work_item().
+//
+// Items differ 2-3x in length (real lists), and the hardware never moves a workgroup between XCDs, so a static map
+// leaves the kernel waiting for the XCD that drew the most tiles. Tickets fix that - but ONE global ticket stream
+// scatters the q-tiles of a head over all XCDs and the K/V tiles lose their L2 sharing (measured: L2 hit rate 83 % ->
+// 50 %, 46 -> 138 GB of L2 fills per launch). So there are EIGHT ticket queues, one per XCD (HW_REG_XCC_ID), each a
+// sequence of CHUNKS of C consecutive q-tiles of one head (C = the workgroups co-resident on an XCD): the CUs of an XCD
+// walk the same K/V in the same order, as under the static map. Chunks are dealt to the queues round-robin from a chunk
+// order that interleaves groups of 4 heads (the last round then has 4x as many chunks to pack; K/V live set 4 heads =
+// 155 MB at S = 75 600, inside the 256 MB Infinity Cache) and takes each head's q-tiles in the order [last, 0, 1, ...]
+// (long items first, see work_item). A workgroup whose own queue is empty STEALS from the queue with the most tickets
+// left, so the XCDs finish together (list-scheduling simulation on the per-row counts of a real 78 % list: makespan /
+// ideal 1.09 for a head-major global stream, 1.01-1.03 here; tools/frag_bench.py).
+// Counters: 8 x 64 bytes in the caller's workspace, zeroed on the launch stream. Every ticket of a queue goes to exactly
+// one caller (atomicAdd), and a workgroup leaves only after it has seen all eight queues empty: every item is taken.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSchedQueues = 8;
+constexpr int kSchedCounterStride = 16;      // uints: one 64-byte line per counter
+
+struct SchedGeom {
+    int cnt, nbh, C, nch, nv;                // q-tiles per head in this launch, batch*heads, chunk size, chunks/head, chunks
+    __device__ SchedGeom(const FwdParams& p, int chunk) : cnt(p.q_tile_count), nbh(p.batch * p.num_heads), C(chunk) {
+        nch = (cnt + C - 1) / C;
+        nv = nbh * nch;
     }
-    m_block = p.q_tile_begin + (qi + cnt - 1) % cnt;
+    __device__ int queue_tickets(int x) const { return x < nv ? ((nv - x + kSchedQueues - 1) / kSchedQueues) * C : 0; }
+    // ticket t of queue x -> item (bh * cnt + q-tile offset), or -2 for a padding slot of a head's last chunk
+    __device__ int item(int x, unsigned t) const {
+        constexpr int G = 4;
+        const int J = x + kSchedQueues * static_cast<int>(t / C);      // virtual chunk
+        const int grp = J / (G * nch);
+        const int g = min(G, nbh - grp * G);                           // heads in this group (only the last can be short)
+        const int r = J - grp * G * nch;
+        const int ci = r / g, bh = grp * G + r % g;
+        const int qi = ci * C + static_cast<int>(t % C);
+        if (qi >= cnt) return -2;
+        return bh * cnt + (qi + cnt - 1) % cnt;
+    }
+};
+
+// Returns the next item for this workgroup (bh * cnt + q-tile offset) or -1 when all queues are empty.
+// *own_empty (workgroup state, kept in LDS by the caller) remembers that the XCD's own queue has run dry.
+__device__ __noinline__ int next_work_item(const FwdParams& p, int chunk, int* own_empty) {
+    const SchedGeom geo(p, chunk);
+    unsigned* const ctr = p.work_counter;
+    const int xcd = static_cast<int>(__builtin_amdgcn_s_getreg((3 << 11) | 20)) & (kSchedQueues - 1);   // HW_REG_XCC_ID[3:0]
+    auto take = [&](int x) -> int {          // -1: queue x is empty
+        const int n = geo.queue_tickets(x);
+        for (;;) {
+            const unsigned t = atomicAdd(&ctr[x * kSchedCounterStride], 1u);
+            if (t >= static_cast<unsigned>(n)) return -1;
+            const int it = geo.item(x, t);
+            if (it >= 0) return it;          // -2: padding slot, take the next ticket
+        }
+    };
+    if (!*own_empty) {
+        const int it = take(xcd);
+        if (it >= 0) return it;
+        *own_empty = 1;
+    }
+    for (int round = 0; round < 4 * kSchedQueues; ++round) {           // bounded: every failed take() means one more empty queue
+        int best = -1, best_left = 0;
+        for (int x = 0; x < kSchedQueues; ++x) {
+            const int n = geo.queue_tickets(x);
+            const unsigned done = atomicAdd(&ctr[x * kSchedCounterStride], 0u);      // coherent read (the L2s are per XCD)
+            const int left = done < static_cast<unsigned>(n) ? n - static_cast<int>(done) : 0;
+            if (left > best_left) { best_left = left; best = x; }
+        }
+        if (best < 0) return -1;
+        const int it = take(best);
+        if (it >= 0) return it;
+    }
+    // not reached in practice (queues only empty out); finish any remaining queue in order rather than leave items behind
+    for (int x = 0; x < kSchedQueues; ++x) {
+        const int it = take(x);
+        if (it >= 0) return it;
+    }
+    return -1;
 }
 
 // Expand one read-list row into the LDS tile sequence (one wave, 64 ranges per pass). Returns the number of

@@ -159,18 +159,24 @@ la_fwd_fp8_d128_kernel(const FwdParams p) {
     // persistent workgroups that take the next (batch, head, q-tile) item until none is left — see la_fwd_kernel_x64.hip.
     const bool dynamic = p.work_counter != nullptr;
     const int total_work = p.batch * p.num_heads * p.q_tile_count;
+    if (dynamic && tid == 0) meta[2] = 0;            // "own queue is empty": workgroup state of next_work_item()
   for (;;) {
     int vid;
     if (dynamic) {
-        if (tid == 0) meta[1] = static_cast<int>(atomicAdd(p.work_counter, 1u));
+        if (tid == 0) meta[1] = next_work_item(p, 64, &meta[2]);     // 64 = workgroups co-resident on an XCD
         __syncthreads();
         vid = meta[1];
-        if (static_cast<unsigned>(vid) >= static_cast<unsigned>(total_work)) return;     // also a corrupted counter ends the loop
+        if (static_cast<unsigned>(vid) >= static_cast<unsigned>(total_work)) return;     // -1: no work left
     } else {
         vid = xcd_work_id();
     }
     int bh, m_block;
-    work_item(p, vid, dynamic, bh, m_block);
+    if (dynamic) {
+        bh = vid / p.q_tile_count;
+        m_block = p.q_tile_begin + vid % p.q_tile_count;
+    } else {
+        work_item(p, vid, bh, m_block);
+    }
     const int h = bh % p.num_heads;
     const int b = bh / p.num_heads;
     const int k_tiles = p.k_tiles;

@@ -111,13 +111,13 @@ def test_argument_validation_returns_codes_without_launching():
     a.dtype = _cabi.LA_DTYPE_FP8_E4M3
     a.block_m = 128                                                            # the fp8 kernel's tile
     a.read_list = a.write_list = None
-    assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 1 * 2 * 4 * 8192 + 256   # B * Hk * Kt * 8 KiB + ticket counter
+    assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 1 * 2 * 4 * 8192 + 1024  # B * Hk * Kt * 8 KiB + ticket counter
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_WORKSPACE
     a.dtype = _cabi.LA_DTYPE_BF16
     a.block_m = 256
     assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 0                     # bf16 dense: nothing
     a.read_list, a.write_list = 0x2000, 0x3000
-    assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 256                   # bf16 with lists: the optional ticket counter
+    assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 1024                  # bf16 with lists: the optional ticket counter
     assert lib.la_skip_list_stats(None, 1, 1, 1, 1, None, None) == _cabi.LA_ERR_NULL_ARG
     assert lib.la_combine(None, 0, None, None, None, 1, 1, 1, 1, 128, None) == _cabi.LA_ERR_NULL_ARG
 

@@ -97,5 +97,5 @@ if "derived" in summary and "hbm_bytes_per_launch" in summary["derived"]:
     json.dump({"hbm_bytes_per_launch": summary["derived"]["hbm_bytes_per_launch"],
                "source": f"profiles/{tag}_rocprof_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
                          "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)"},
-              open(os.path.join(out_dir, "r01_pmc_summary.json"), "w"), indent=1)
+              open(os.path.join(out_dir, "r01_pmc_summary_fp8.json" if "fp8" in tag else "r01_pmc_summary.json"), "w"), indent=1)
 print("\n".join(lines))
