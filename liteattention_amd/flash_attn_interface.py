@@ -118,7 +118,8 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     stream, ``_window_hook(i, out, row_begin, row_end)`` runs after window i has been enqueued (rows
     [row_begin, row_end) of ``out`` are complete once that launch is; used to all-gather early rows while later
     windows compute). ``_static_sched`` sets LA_FLAG_STATIC_SCHED (per-item workgroups instead of persistent ones: a
-    collective running beside the launch gets CUs as items retire)."""
+    collective running beside the launch gets CUs as items retire); "after_first" sets it on every window but the first
+    (no collective is in flight beside window 0)."""
     if not q.is_cuda:
         raise RuntimeError("lite_attention::fwd has no CPU implementation (HIP device tensors required)")
     if q.dtype not in (torch.bfloat16, torch.float8_e4m3fn):
@@ -265,7 +266,8 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
         for i, (w_begin, w_count) in enumerate(windows):
             a.q_tile_begin, a.q_tile_count = w_begin, w_count
             a.flags = (_cabi.LA_FLAG_V_PREPARED if (is_fp8 and i > 0) else 0) | \
-                      (_cabi.LA_FLAG_STATIC_SCHED if _static_sched else 0)       # V^T tiles prepared by window 0
+                      (_cabi.LA_FLAG_STATIC_SCHED if (_static_sched is True or (_static_sched == "after_first" and i > 0))
+                       else 0)                                                   # V^T tiles prepared by window 0
             stream = torch.cuda.current_stream(q.device).cuda_stream                              # :1219
             rc = lib.la_fwd(ctypes.byref(a), ctypes.c_void_p(stream))
             if rc != _cabi.LA_OK:

@@ -85,7 +85,7 @@ class HeadShardedLiteAttention:
             # static_sched: per-item workgroups release a CU every item, so RCCL's kernels get in beside the next window;
             # persistent workgroups would hold every CU until their window ends and push each gather one window late
             (lambda q, k, v, windows, hook, scale, **kw: self.local.call_windowed(q, k, v, windows, hook, scale,
-                                                                                 static_sched=True, **kw)))
+                                                                                 static_sched="after_first", **kw)))
         self.overlap_windows = int(overlap_windows)
         self._q_tile_rows = q_tile_rows                # test seam (CPU stand-ins have no kernel tile); None = ask the library
 
