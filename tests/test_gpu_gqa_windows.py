@@ -109,6 +109,7 @@ def test_q_tile_windows_equal_one_launch_bit_exactly(dtype, D):
     assert len(windows) >= 2
     one = L.LiteAttention(threshold=-2.0, max_batch_size=B)
     win = L.LiteAttention(threshold=-2.0, max_batch_size=B)
+    sta = L.LiteAttention(threshold=-2.0, max_batch_size=B)      # the multi-GPU driver's mix: window 0 tickets, later static
     for step in range(3):
         seen = []
         o1, l1 = one.call_windowed(q, k, v, [(0, Qt)], return_softmax_lse=True)
@@ -118,6 +119,8 @@ def test_q_tile_windows_equal_one_launch_bit_exactly(dtype, D):
                   else (o1, l1))
         assert torch.equal(o1, o2) and torch.equal(l1, l2) and torch.equal(o0, o1) and torch.equal(l0, l1)
         assert torch.equal(one._skip_list, win._skip_list)
+        o3, l3 = sta.call_windowed(q, k, v, windows, return_softmax_lse=True, static_sched="after_first")
+        assert torch.equal(o3, o1) and torch.equal(l3, l1) and torch.equal(sta._skip_list, one._skip_list)
         assert seen == [(i, a * bm, min(S, (a + n) * bm)) for i, (a, n) in enumerate(windows)]
     assert one.get_skip_fraction() > 0.02
 
