@@ -1,0 +1,706 @@
+#!/usr/bin/env python
+"""Generates la_fwd_x64_fp8_body.inc: hand-scheduled gfx950 main loop of the fp8 (e4m3) / head_dim-128 QK-Skip forward with
+ONE wave per SIMD and 64 query rows per wave (q-tile 256 x k-tile 64) - the structure of gen_fwd_x64.py (bf16) on the
+block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales (2x the bf16 MFMA rate; la_fwd_kernel_fp8.hip explains
+the operand layout, which is kept: K rows / Q fragments as 2 x 16-byte chunks per 64-wide contraction step, V^T tiles
+pre-transposed by la_prep_v_fp8 so that the PV operand is two plain ds_read_b128).
+
+Why: the 128-row fp8 kernel (two 32-row waves per SIMD, hipcc-scheduled) is VALU-issue-bound at 38 % MFMA utilisation
+(profiles/r01f_fp8): per 64 query rows it pays the per-tile statistics / SALU / waits twice and stalls 30 % of its cycles on
+dependencies. Here one wave does 64 rows with ONE set of per-tile overhead, and every filler is placed by hand.
+
+Register file (per lane):  AGPR  a[0:127]   O^T  (2 q-blocks x 4 d-blocks x 16)
+                                 a[128:159] Q    (2 q-blocks x 2 contraction steps x 8: B operand of S^T = K Q^T)
+                                 a[160:191] K    fragments of the NEXT tile (2 key blocks x 2 steps x 8: A operand)
+                           VGPR  v[0:63] / v[64:127]  S^T ping / pong, q-block major: (q-block, key block, 16). P (e4m3) is
+                                 compacted IN PLACE into the first 8 registers of a q-block's 32 = the B operand of PV
+                                 v[128:159] the four V^T fragments of the tile (A operand of PV, 8 registers each)
+Step i:  phase 1   8 MFMA  S_nxt = K(i+1) Q^T  ||  rest of P(i) = exp2(S c - m_ref c + OFF), row sums, e4m3 compaction;
+                                                    LDS-DMA of V^T(i+1), K(i+3); the 8 V^T fragment reads
+         phase 2   8 MFMA  O^T += V^T(i) P(i)^T ||  K(i+2) fragment reads -> AGPRs; next step's tile lookup / DMA bases;
+                                                    row max of S_nxt, running max, skip vote, lazy-rescale test; start of P(i+1)
+P offset: the reference scales P by 2^8 before the e4m3 cast (softmax.h:85-87). With the lazy rescale P can reach 2^tau, so
+OFF = 8 - tau with tau = 2: P 2^6 <= 256 < 448 (e4m3 max). e4m3 rounding is scale-invariant away from the subnormal end, so
+results equal the offset-8 ones except for P < 2^-12 (absolute 2.4e-4 of a weight <= 1).
+"""
+import os
+import sys
+
+OPT = set(x for x in os.environ.get("LA_X64F8_OPT", "").split(",") if x)
+
+
+def opt_val(key, default):
+    for o in OPT:
+        if o.startswith(key + ":"):
+            return o[len(key) + 1:]
+    return default
+
+
+XPAIRS = int(opt_val("x", "5"))          # pair-groups (of 16) done in phase 2
+NG = 8                                    # MFMAs (gaps) per phase
+TAU = 2.0                                 # lazy-rescale slack in log2 units (must match the shell: param[22] = TAU / c)
+P_OFFSET = 8.0 - TAU
+DMA_GAPS = [int(x) for x in opt_val("dmagaps", "0,1,1,2,3,3").split(",")]   # m0K,K0,K1,m0V,V0,V1 (phase 1 gaps; an M0 write is never adjacent to its first use)
+
+
+# ---------------------------------------------------------------- AGPR map
+def O_(qb, db):
+    return 64 * qb + 16 * db
+
+
+def QA(qb, sx):
+    return 128 + 16 * qb + 8 * sx
+
+
+def KA(j):          # j = 2*kb + sx
+    return 160 + 8 * j
+
+
+# ---------------------------------------------------------------- VGPR map
+def S_(sset, qb, kb):
+    return 64 * sset + 32 * qb + 16 * kb
+
+
+VF = [128 + 8 * i for i in range(4)]
+KADDR = list(range(160, 164))             # [2*sx + t]
+VADDR = [164, 165]                        # [t]
+LK = [166, 167]
+LV = 168
+VSC = 169                                 # 0x7f7f7f7f: four E8M0 exponents of 127 (= 2^0)
+MTRUE, MREF, NMS, L0, L1, MLOC, MLOC2, ALPHA = ([180, 181], [182, 183], [184, 185], [186, 188], [187, 189], [190, 191],
+                                                [192, 193], [194, 195])
+T = list(range(196, 212))
+NEGINF, HH4, LANE = 212, 213, 214
+QROW = [216, 217]
+MTHR = [220, 221]
+
+# ---------------------------------------------------------------- SGPR map (s32-s34 are ABI-reserved: unused)
+S_KBASE, S_VBASE, S_QBASE = 36, 38, 40
+S_TB, S_VB, S_EXEC, S_T64, S_T64B = 42, 44, 46, 48, 50
+(S_KRS, S_VRS, S_LASTROW, S_NTILES, S_C, S_THR, S_TAILVALID, S_KTM1, S_SEQ, S_DOFLAGS, S_WAVE, S_I, S_DOMASK,
+ S_NA, S_NB, S_NC, S_LDS, S_T0, S_T1, S_T2, S_T3, S_NM1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_PARAM, S_HASNEXT, S_NEGC,
+ S_SAFEROW, S_DMAW, S_RAG, S_TAU, S_RESC, S_NCUR) = range(52, 87)
+S_RAG2, S_TB2, S_VB2, S_POS = 87, 88, 90, 92
+TBS, VBS = [S_TB, S_TB2], [S_VB, S_VB2]
+
+KV_TILE = 8192
+V_REGION = 16384
+
+out = []
+
+
+def emit(x):
+    out.append(x if isinstance(x, tuple) else "    " + x)
+
+
+def label(s):
+    out.append(s + ":")
+
+
+def v(i):
+    return f"v{i}"
+
+
+def vr(a, n):
+    return f"v[{a}:{a + n - 1}]"
+
+
+def ar(a, n):
+    return f"a[{a}:{a + n - 1}]"
+
+
+def s(i):
+    return f"s{i}"
+
+
+def sr(a, n=2):
+    return f"s[{a}:{a + n - 1}]"
+
+
+uid = [0]
+
+
+def new_label(prefix):
+    uid[0] += 1
+    return f".LF{prefix}_{uid[0]}_%="
+
+
+def finalize(items):
+    """Counted lgkmcnt waits: LDS operations of one wave return in order."""
+    lines, q = [], []
+    for it in items:
+        if isinstance(it, str):
+            lines.append(it)
+        elif it[0] == "LDS":
+            lines.append("    " + it[1])
+            q.append(it[2])
+        elif it[0] == "WAIT":
+            if it[1] in q:
+                idx = max(i for i, t in enumerate(q) if t == it[1])
+                lines.append(f"    s_waitcnt lgkmcnt({min(len(q) - 1 - idx, 15)})")
+                q = q[idx + 1:]
+        elif it[0] == "DRAIN":
+            lines.append("    s_waitcnt vmcnt(0) lgkmcnt(0)")
+            q = []
+    return lines
+
+
+# ---------------------------------------------------------------- building blocks
+def k_read(kbuf_imm, j, t):
+    kb, sx = j >> 1, j & 1
+    return ("LDS", f"ds_read_b128 {ar(KA(j) + 4 * t, 4)}, {v(KADDR[2 * sx + t])} offset:{kbuf_imm + kb * 4096}", ("k", j, t))
+
+
+def v_read(vbuf_imm, db, t):
+    return ("LDS", f"ds_read_b128 {vr(VF[db] + 4 * t, 4)}, {v(VADDR[t])} offset:{V_REGION + vbuf_imm + db * 2048}", ("v", db, t))
+
+
+MFMA = "v_mfma_scale_f32_32x32x64_f8f6f4"
+SCALES = f"{v(VSC)}, {v(VSC)} op_sel_hi:[0,0,0]"
+
+
+def mfma_qk(sset, kb, sx, qb):
+    d = S_(sset, qb, kb)
+    c = "0" if sx == 0 else vr(d, 16)
+    return f"    {MFMA} {vr(d, 16)}, {ar(KA(2 * kb + sx), 8)}, {ar(QA(qb, sx), 8)}, {c}, {SCALES}"
+
+
+def mfma_pv(sset, db, qb):
+    return f"    {MFMA} {ar(O_(qb, db), 16)}, {vr(VF[db], 8)}, {vr(S_(sset, qb, 0), 8)}, {ar(O_(qb, db), 16)}, {SCALES}"
+
+
+def softmax_parts(sset, p):
+    """Pair p (elements 2p, 2p+1 of the 32 per lane and q-block; key block kb = p >> 3) of BOTH q-blocks."""
+    F, E, A, C = [], [], [], []
+    for qb in (0, 1):
+        e0 = 2 * p
+        kb, r = e0 >> 4, e0 & 15
+        r0 = S_(sset, qb, kb) + r
+        r1 = r0 + 1
+        dst = S_(sset, qb, 0) + 4 * kb + (r >> 2)         # 32 e4m3 bytes of a q-block = its first 8 registers
+        hi = " op_sel:[0,0,1]" if (r >> 1) & 1 else ""
+        ta, tb = T[8 + 2 * qb], T[9 + 2 * qb]
+        F.append([f"    v_fma_f32 {v(ta)}, {v(r0)}, {s(S_C)}, {v(NMS[qb])}", f"    v_fma_f32 {v(tb)}, {v(r1)}, {s(S_C)}, {v(NMS[qb])}"])
+        E.append([f"    v_exp_f32 {v(r0)}, {v(ta)}", f"    v_exp_f32 {v(r1)}, {v(tb)}"])
+        A.append([f"    v_add_f32 {v(L0[qb])}, {v(L0[qb])}, {v(r0)}", f"    v_add_f32 {v(L1[qb])}, {v(L1[qb])}, {v(r1)}"])
+        C.append([f"    v_cvt_pk_fp8_f32 {v(dst)}, {v(r0)}, {v(r1)}{hi}"])
+    return F, E, A, C
+
+
+def softmax_stream(sset, groups):
+    """Software-pipelined: every v_exp of group g is followed by the fma of group g+1 (same temp, just consumed) and the add /
+    convert of group g-1; exps are never adjacent."""
+    if not groups:
+        return []
+    parts = [softmax_parts(sset, p) for p in groups]
+    o = parts[0][0][0] + parts[0][0][1]
+    n = len(parts)
+    for g in range(n):
+        Fn = parts[g + 1][0] if g + 1 < n else None
+        Ap, Cp = (parts[g - 1][2], parts[g - 1][3]) if g > 0 else (None, None)
+        E = parts[g][1]
+        for qb in (0, 1):
+            fill0 = ([Fn[qb][0]] if Fn else []) + (list(Ap[qb][:1]) if Ap else [])
+            fill1 = ([Fn[qb][1]] if Fn else []) + (list(Ap[qb][1:]) if Ap else []) + (list(Cp[qb]) if Cp else [])
+            o += [E[qb][0]] + fill0 + [E[qb][1]] + fill1
+    for qb in (0, 1):
+        o += parts[-1][2][qb]
+    for qb in (0, 1):
+        o += parts[-1][3][qb]
+    return o
+
+
+def row_max_ops(sset):
+    per = []
+    for qb in (0, 1):
+        regs = [S_(sset, qb, 0) + r for r in range(32)]
+        ops = [f"    v_max_f32 {v(MLOC[qb])}, {v(regs[0])}, {v(regs[1])}", f"    v_max_f32 {v(MLOC2[qb])}, {v(regs[2])}, {v(regs[3])}"]
+        rest = regs[4:]
+        chains = [MLOC[qb], MLOC2[qb]]
+        for n_, i in enumerate(range(0, len(rest), 2)):
+            ch = chains[n_ & 1]
+            ops.append(f"    v_max3_f32 {v(ch)}, {v(ch)}, {v(rest[i])}, {v(rest[i + 1])}")
+        ops.append(f"    v_max_f32 {v(MLOC[qb])}, {v(MLOC[qb])}, {v(MLOC2[qb])}")
+        per.append(ops)
+    return [x for pair in zip(*per) for x in pair]
+
+
+def stats_ops(pos_sgpr, valid_sgpr, rare_label, back_label, flush_label, flush_back, inval_label, inval_back):
+    o = []
+    a = o.append
+    a(f"    v_mov_b32 {v(T[0])}, {v(MLOC[0])}")
+    a(f"    v_mov_b32 {v(T[1])}, {v(MLOC[1])}")
+    a(f"    v_mov_b32 {v(T[2])}, {v(MTRUE[0])}")
+    a(f"    v_permlane32_swap_b32 {v(MLOC[0])}, {v(T[0])}")
+    a(f"    v_permlane32_swap_b32 {v(MLOC[1])}, {v(T[1])}")
+    a(f"    v_mov_b32 {v(T[3])}, {v(MTRUE[1])}")
+    a(f"    v_max_f32 {v(MLOC[0])}, {v(MLOC[0])}, {v(T[0])}")
+    a(f"    v_max_f32 {v(MLOC[1])}, {v(MLOC[1])}, {v(T[1])}")
+    a(f"    s_cmp_eq_u32 {s(valid_sgpr)}, 0")
+    a(f"    s_cbranch_scc1 {inval_label}")
+    o.append(inval_back + ":")
+    a(f"    v_max_f32 {v(MTRUE[0])}, {v(MTRUE[0])}, {v(MLOC[0])}")
+    a(f"    v_max_f32 {v(MTRUE[1])}, {v(MTRUE[1])}, {v(MLOC[1])}")
+    a(f"    v_sub_f32 {v(T[2])}, {v(MLOC[0])}, {v(T[2])}")                  # vote: (m_loc - m_prev) * c > thr (softmax.h:194)
+    a(f"    v_sub_f32 {v(T[3])}, {v(MLOC[1])}, {v(T[3])}")
+    a(f"    v_mul_f32 {v(T[2])}, {s(S_C)}, {v(T[2])}")
+    a(f"    v_mul_f32 {v(T[3])}, {s(S_C)}, {v(T[3])}")
+    a(f"    v_cmp_gt_f32 {sr(S_T64)}, {v(T[2])}, {s(S_THR)}")
+    a(f"    v_cmp_gt_f32 vcc, {v(T[3])}, {s(S_THR)}")
+    a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")
+    a("    s_cmp_lg_u64 vcc, 0")
+    a(f"    s_cselect_b32 {s(S_T0)}, 1, 0")
+    a(f"    s_and_b32 {s(S_T1)}, {s(pos_sgpr)}, 31")
+    a(f"    s_lshl_b32 {s(S_T0)}, {s(S_T0)}, {s(S_T1)}")
+    a(f"    s_or_b32 {s(S_DOMASK)}, {s(S_DOMASK)}, {s(S_T0)}")
+    a(f"    v_cmp_gt_f32 {sr(S_T64)}, {v(MTRUE[0])}, {v(MTHR[0])}")         # lazy rescale trigger
+    a(f"    v_cmp_gt_f32 vcc, {v(MTRUE[1])}, {v(MTHR[1])}")
+    a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")
+    a(f"    s_cbranch_vccnz {rare_label}")
+    o.append(back_label + ":")
+    a(f"    s_cmp_eq_u32 {s(S_T1)}, 31")
+    a(f"    s_cbranch_scc1 {flush_label}")
+    o.append(flush_back + ":")
+    return o
+
+
+def set_nms(qb):
+    """-m_ref*c + P_OFFSET (the literal needs the VOP2 encoding: gfx9 VOP3 takes no literals)."""
+    emit(f"v_mul_f32 {v(NMS[qb])}, {s(S_NEGC)}, {v(MREF[qb])}")
+    emit(f"v_add_f32 {v(NMS[qb])}, 0x{float_bits(P_OFFSET):08x}, {v(NMS[qb])}")
+
+
+def float_bits(x):
+    import struct
+    return struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+def rare_rescale_block(rare_label, back_label):
+    label(rare_label)
+    for qb in (0, 1):
+        emit(f"v_sub_f32 {v(T[2 + qb])}, {v(MREF[qb])}, {v(MTRUE[qb])}")
+    for qb in (0, 1):
+        emit(f"v_mul_f32 {v(T[2 + qb])}, {s(S_C)}, {v(T[2 + qb])}")
+    for qb in (0, 1):
+        emit(f"v_exp_f32 {v(ALPHA[qb])}, {v(T[2 + qb])}")
+    for qb in (0, 1):
+        emit(f"v_mov_b32 {v(MREF[qb])}, {v(MTRUE[qb])}")
+    for qb in (0, 1):
+        set_nms(qb)
+        emit(f"v_add_f32 {v(MTHR[qb])}, {s(S_TAU)}, {v(MREF[qb])}")
+    for qb in (0, 1):
+        emit(f"v_mul_f32 {v(L0[qb])}, {v(L0[qb])}, {v(ALPHA[qb])}")
+        emit(f"v_mul_f32 {v(L1[qb])}, {v(L1[qb])}, {v(ALPHA[qb])}")
+    emit(f"s_mov_b32 {s(S_RESC)}, 1")
+    emit(f"s_branch {back_label}")
+
+
+def inval_block(lbl, back):
+    label(lbl)
+    for qb in (0, 1):
+        emit(f"v_mov_b32 {v(MLOC[qb])}, {v(NEGINF)}")
+        emit(f"v_mov_b32 {v(NMS[qb])}, {v(NEGINF)}")
+    emit(f"s_branch {back}")
+
+
+def flush_block(flush_label, back_label, pos_sgpr):
+    label(flush_label)
+    flush_domask(pos_sgpr)
+    emit("s_waitcnt lgkmcnt(0)")
+    emit(f"s_branch {back_label}")
+
+
+def flush_domask(pos_sgpr):
+    emit(f"s_lshr_b32 {s(S_T0)}, {s(pos_sgpr)}, 5")
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_T0)}, 2")
+    emit(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_DOFLAGS)}")
+    emit(f"v_mov_b32 {v(T[4])}, {s(S_T0)}")
+    emit(f"v_mov_b32 {v(T[5])}, {s(S_DOMASK)}")
+    emit(f"s_mov_b64 {sr(S_EXEC)}, exec")
+    emit("s_mov_b64 exec, 1")
+    emit(f"ds_or_b32 {v(T[4])}, {v(T[5])}")
+    emit(f"s_mov_b64 exec, {sr(S_EXEC)}")
+    emit(f"s_mov_b32 {s(S_DOMASK)}, 0")
+
+
+def rescale_o_block(lbl, back):
+    label(lbl)
+    emit("s_nop 15")
+    emit("s_nop 15")
+    emit("s_nop 15")
+    emit("s_nop 15")
+    for qb in (0, 1):
+        for base in range(0, 64, 8):
+            for k in range(8):
+                emit(f"v_accvgpr_read_b32 {v(T[k])}, a{64 * qb + base + k}")
+            for k in range(8):
+                emit(f"v_mul_f32 {v(T[k])}, {v(T[k])}, {v(ALPHA[qb])}")
+            for k in range(8):
+                emit(f"v_accvgpr_write_b32 a{64 * qb + base + k}, {v(T[k])}")
+    emit(f"s_mov_b32 {s(S_RESC)}, 0")
+    emit("s_nop 7")
+    emit(f"s_branch {back}")
+
+
+def dma_bases(n_k, n_v, st=0):
+    """K: kbase + min(64 n, saferow) * k_rs (a ragged last tile is staged only by the shell, at position 0: valid lists hold
+    tile Kt-1 nowhere else; the clamp keeps every other case memory-safe). V^T: tile n of the pre-transposed workspace."""
+    return [f"    s_lshl_b32 {s(S_T0)}, {s(n_k)}, 6",
+            f"    s_min_u32 {s(S_T0)}, {s(S_T0)}, {s(S_SAFEROW)}",
+            f"    s_mul_hi_u32 {s(TBS[st] + 1)}, {s(S_T0)}, {s(S_KRS)}",
+            f"    s_mul_i32 {s(TBS[st])}, {s(S_T0)}, {s(S_KRS)}",
+            f"    s_add_u32 {s(TBS[st])}, {s(TBS[st])}, {s(S_KBASE)}",
+            f"    s_addc_u32 {s(TBS[st] + 1)}, {s(TBS[st] + 1)}, {s(S_KBASE + 1)}",
+            f"    s_lshl_b32 {s(S_T0)}, {s(n_v)}, 13",
+            f"    s_add_u32 {s(VBS[st])}, {s(S_VBASE)}, {s(S_T0)}",
+            f"    s_addc_u32 {s(VBS[st] + 1)}, {s(S_VBASE + 1)}, 0"]
+
+
+def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True, st=0):
+    """[m0K, K0, K1, m0V, V0, V1]: one M0 per tensor, the piece index rides on the instruction offset (applied to the global
+    and the LDS address alike; LK[j] is pre-compensated by -1024 j, LV is the same for both pieces)."""
+    o = []
+    if do_k:
+        o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {kbuf_imm}")
+        o += [f"    global_load_lds_dwordx4 {v(LK[j])}, {sr(TBS[st])} offset:{1024 * j}" for j in range(2)]
+    if do_v:
+        o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {V_REGION + vbuf_imm}")
+        o += [f"    global_load_lds_dwordx4 {v(LV)}, {sr(VBS[st])} offset:{1024 * j}" for j in range(2)]
+    return o
+
+
+def weight(it):
+    if isinstance(it, str):
+        if it.endswith(":"):
+            return 0
+        if "v_exp_f32" in it:
+            return 2
+    return 1
+
+
+def n_fill(items):
+    return sum(weight(it) for it in items)
+
+
+def distribute(queue, post, start, cap=0):
+    q = list(queue)
+    if cap <= 0:
+        total = sum(n_fill(post[t]) for t in range(start, NG)) + n_fill(q)
+        cap = -(-total // (NG - start))
+    for t in range(start, NG):
+        while q and n_fill(post[t]) < cap:
+            post[t].append(q.pop(0))
+            while q and isinstance(q[0], str) and q[0].endswith(":"):
+                post[t].append(q.pop(0))
+    post[NG - 1] += q
+
+
+deferred = []
+QK_ORDER = [(sx, kb, qb) for sx in (0, 1) for kb in (0, 1) for qb in (0, 1)]      # dependent pairs are 4 MFMAs apart
+PV_ORDER = [(db, qb) for db in range(4) for qb in (0, 1)]
+K_FRAGS = [(j, t) for j in (0, 2, 1, 3) for t in (0, 1)]                            # sx = 0 fragments first
+
+
+def step(variant):
+    cur, nxt = variant, variant ^ 1
+    kbuf_read = cur * KV_TILE                # K(i+2)
+    kbuf_stage = nxt * KV_TILE               # K(i+3) goes where K(i+1) was
+    vbuf_cur = cur * KV_TILE                 # V^T(i)
+    vbuf_stage = nxt * KV_TILE               # V^T(i+1)
+
+    # ---- phase 1
+    post = [[] for _ in range(NG)]
+    mf = [mfma_qk(nxt, kb, sx, qb) for (sx, kb, qb) in QK_ORDER]
+    for g, op in zip(DMA_GAPS, dma_ops(kbuf_stage, vbuf_stage, st=variant)):
+        post[g].append(op)
+    for f, (db, t) in enumerate([(db, t) for db in range(4) for t in (0, 1)]):
+        post[4 + f // 2].append(v_read(vbuf_cur, db, t))
+    distribute(softmax_stream(cur, list(range(XPAIRS, 16))), post, 0)
+    for t in range(NG):
+        out.append(mf[t])
+        out.extend(post[t])
+
+    # ---- phase 2
+    emit("s_nop 1")                          # the last e4m3 converts (VALU writes) -> first PV MFMA (reads them as B)
+    pre = [[] for _ in range(NG)]
+    post = [[] for _ in range(NG)]
+    mf = []
+    for t, (db, qb) in enumerate(PV_ORDER):
+        if qb == 0:
+            pre[t].append(("WAIT", ("v", db, 1)))
+        mf.append(mfma_pv(cur, db, qb))
+        post[t].append(k_read(kbuf_read, *K_FRAGS[t]))
+    rare, back = new_label("rare"), new_label("rare_back")
+    fl, flback = new_label("flush"), new_label("flush_back")
+    vq = [f"    s_add_u32 {s(S_T3)}, {s(S_I)}, 4",
+          f"    s_min_u32 {s(S_T3)}, {s(S_T3)}, {s(S_NM1)}",
+          f"    s_lshl_b32 {s(S_T3)}, {s(S_T3)}, 2",
+          f"    s_add_u32 {s(S_T3)}, {s(S_T3)}, {s(S_SEQ)}",
+          f"    v_mov_b32 {v(T[6])}, {s(S_T3)}",
+          ("LDS", f"ds_read_b32 {v(T[7])}, {v(T[6])}", "seq"),
+          f"    s_add_u32 {s(S_POS)}, {s(S_I)}, 1",
+          f"    s_cmp_lt_u32 {s(S_POS)}, {s(S_NTILES)}",
+          f"    s_cselect_b32 {s(S_HASNEXT)}, 1, 0"]
+    n_head = len(vq)
+    rm = row_max_ops(nxt)
+    vq += rm[:8]
+    rm = rm[8:]
+    vq += [("WAIT", "seq"), f"    v_readfirstlane_b32 {s(S_T3)}, {v(T[7])}"]
+    nb = dma_bases(S_T3, S_NB, st=variant ^ 1) + [f"    s_mov_b32 {s(S_NB)}, {s(S_NC)}", f"    s_mov_b32 {s(S_NC)}, {s(S_T3)}"]
+    mixed = []
+    while rm or nb:
+        if rm:
+            mixed += rm[:2]
+            rm = rm[2:]
+        if nb:
+            mixed.append(nb.pop(0))
+    vq += mixed
+    inv, invback = new_label("inval"), new_label("inval_back")
+    vq += stats_ops(S_POS, S_HASNEXT, rare, back, fl, flback, inv, invback)
+    deferred.append(lambda: inval_block(inv, invback))
+    deferred.append(lambda: rare_rescale_block(rare, back))
+    deferred.append(lambda: flush_block(fl, flback, S_POS))
+    vq += softmax_stream(nxt, list(range(XPAIRS)))
+    # gap 0 holds only ops that do not read S_nxt (its last MFMA was issued just before this phase)
+    post[0] += vq[:n_head]
+    distribute(vq[n_head:], post, 1)
+    for t in range(NG):
+        out.extend(pre[t])
+        out.append(mf[t])
+        out.extend(post[t])
+
+    # ---- tail: rare O rescale, drain, barrier
+    slow, slow_back = new_label("slow"), new_label("slow_back")
+    emit(f"s_cmp_lg_u32 {s(S_RESC)}, 0")
+    emit(f"s_cbranch_scc1 {slow}")
+    label(slow_back)
+    deferred.append(lambda: rescale_o_block(slow, slow_back))
+    emit(("DRAIN",))
+    emit("s_barrier")
+    emit(f"s_add_u32 {s(S_I)}, {s(S_I)}, 1")
+
+
+def prologue():
+    emit("; ---- lane id, parameter block -> SGPRs")
+    emit(f"v_mbcnt_lo_u32_b32 {v(LANE)}, -1, 0")
+    emit(f"v_mbcnt_hi_u32_b32 {v(LANE)}, -1, {v(LANE)}")
+    emit(f"s_mov_b32 {s(S_WAVE)}, %0")
+    emit(f"s_mov_b32 {s(S_PARAM)}, %1")
+    emit(f"v_mov_b32 {v(T[0])}, {s(S_PARAM)}")
+    for q in range(6):
+        emit(f"ds_read_b128 {vr(4 * q, 4)}, {v(T[0])} offset:{16 * q}")
+    emit("s_waitcnt lgkmcnt(0)")
+    plist = [S_KBASE, S_KBASE + 1, S_VBASE, S_VBASE + 1, S_KRS, S_VRS, S_LASTROW, S_NTILES, S_C, S_THR, S_TAILVALID,
+             S_KTM1, S_SEQ, S_DOFLAGS, S_QBASE, S_QBASE + 1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_LDS, S_NEGC, S_TAU]
+    for idx, sg in enumerate(plist):
+        emit(f"v_readfirstlane_b32 {s(sg)}, {v(idx)}")
+    emit("s_nop 4")
+    emit(f"s_sub_u32 {s(S_NM1)}, {s(S_NTILES)}, 1")
+    emit(f"s_sub_u32 {s(S_SAFEROW)}, {s(S_LASTROW)}, 63")
+    emit(f"s_max_i32 {s(S_SAFEROW)}, {s(S_SAFEROW)}, 0")
+    emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, 11")          # 2 KiB of every 8 KiB tile per wave
+    emit(f"s_add_u32 {s(S_DMAW)}, {s(S_DMAW)}, {s(S_LDS)}")
+    emit(f"s_mov_b32 {s(S_I)}, 0")
+    emit(f"s_mov_b32 {s(S_RESC)}, 0")
+    emit(f"v_mov_b32 {v(NEGINF)}, 0xff800000")
+    emit(f"v_mov_b32 {v(VSC)}, 0x7f7f7f7f")
+
+    emit("; ---- per-lane constants")
+    emit(f"v_lshrrev_b32 {v(T[0])}, 5, {v(LANE)}")            # hh
+    emit(f"v_lshlrev_b32 {v(HH4)}, 2, {v(T[0])}")
+    emit(f"v_and_b32 {v(T[1])}, 31, {v(LANE)}")               # l31
+    # K fragment addresses: lds + l31*128 + (((4 sx + 2 t + hh) ^ ((l31 >> 1) & 7)) << 4)
+    emit(f"v_lshrrev_b32 {v(T[2])}, 1, {v(T[1])}")
+    emit(f"v_and_b32 {v(T[2])}, 7, {v(T[2])}")                # k swizzle
+    emit(f"v_lshlrev_b32 {v(T[3])}, 7, {v(T[1])}")
+    emit(f"v_add_u32 {v(T[3])}, {s(S_LDS)}, {v(T[3])}")
+    for sx in (0, 1):
+        for t in (0, 1):
+            emit(f"v_add_u32 {v(T[4])}, {4 * sx + 2 * t}, {v(T[0])}")
+            emit(f"v_xor_b32 {v(T[4])}, {v(T[4])}, {v(T[2])}")
+            emit(f"v_lshl_add_u32 {v(KADDR[2 * sx + t])}, {v(T[4])}, 4, {v(T[3])}")
+    # V^T fragment addresses: lds + l31*64 + (((2 t + hh) ^ ((l31 >> 2) & 3)) << 4)   (V_REGION rides on the offsets)
+    emit(f"v_lshrrev_b32 {v(T[2])}, 2, {v(T[1])}")
+    emit(f"v_and_b32 {v(T[2])}, 3, {v(T[2])}")
+    emit(f"v_lshlrev_b32 {v(T[3])}, 6, {v(T[1])}")
+    emit(f"v_add_u32 {v(T[3])}, {s(S_LDS)}, {v(T[3])}")
+    for t in (0, 1):
+        emit(f"v_add_u32 {v(T[4])}, {2 * t}, {v(T[0])}")
+        emit(f"v_xor_b32 {v(T[4])}, {v(T[4])}, {v(T[2])}")
+        emit(f"v_lshl_add_u32 {v(VADDR[t])}, {v(T[4])}, 4, {v(T[3])}")
+    # DMA lane offsets. K piece j of this wave: rows 16 w + 8 j + rip (rip = lane >> 3), source chunk cpos ^ ((row >> 1) & 7)
+    emit(f"v_lshrrev_b32 {v(T[6])}, 3, {v(LANE)}")            # rip
+    emit(f"v_and_b32 {v(T[7])}, 7, {v(LANE)}")                # cpos
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 4")
+    for j in (0, 1):
+        emit(f"v_add_u32 {v(T[4])}, {s(S_T0)}, {v(T[6])}")
+        if j:
+            emit(f"v_add_u32 {v(T[4])}, 8, {v(T[4])}")
+        emit(f"v_lshrrev_b32 {v(T[5])}, 1, {v(T[4])}")
+        emit(f"v_and_b32 {v(T[5])}, 7, {v(T[5])}")
+        emit(f"v_xor_b32 {v(T[5])}, {v(T[5])}, {v(T[7])}")
+        emit(f"v_min_i32 {v(T[4])}, {v(T[4])}, {s(S_LASTROW)}")   # seqlen_k < 64: rows of the only tile stay inside K
+        emit(f"v_mul_lo_u32 {v(LK[j])}, {v(T[4])}, {s(S_KRS)}")
+        emit(f"v_lshl_add_u32 {v(LK[j])}, {v(T[5])}, 4, {v(LK[j])}")
+        if j:
+            emit(f"v_subrev_u32 {v(LK[j])}, {1024 * j}, {v(LK[j])}")
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 11")
+    emit(f"v_lshl_add_u32 {v(LV)}, {v(LANE)}, 4, {s(S_T0)}")  # 2048 w + 16 lane: linear copy of the prepared tile
+
+    emit("; ---- Q fragments -> AGPRs: row q_row0 + 64 w + 32 qb + l31, d = 64 sx + 32 t + 16 hh + [0,16); rows past seqlen_q are ZERO")
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 6")
+    emit(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_QROW0)}")
+    emit(f"s_sub_u32 {s(S_T1)}, {s(S_SEQLENQ)}, 1")
+    emit(f"v_lshlrev_b32 {v(T[6])}, 4, {v(T[0])}")            # hh * 16 bytes
+    for qb in (0, 1):
+        emit(f"v_add_u32 {v(QROW[qb])}, {s(S_T0)}, {v(T[1])}")
+        if qb:
+            emit(f"v_add_u32 {v(QROW[qb])}, 32, {v(QROW[qb])}")
+        emit(f"v_min_i32 {v(T[3])}, {v(QROW[qb])}, {s(S_T1)}")
+        emit(f"v_mad_u64_u32 {vr(T[4], 2)}, {sr(S_T64)}, {v(T[3])}, {s(S_QRS)}, 0")
+        emit(f"v_add_co_u32 {v(T[4])}, vcc, {v(T[4])}, {v(T[6])}")
+        emit(f"v_addc_co_u32 {v(T[5])}, vcc, 0, {v(T[5])}, vcc")
+        emit(f"v_add_co_u32 {v(T[4])}, vcc, {s(S_QBASE)}, {v(T[4])}")
+        emit(f"v_mov_b32 {v(T[7])}, {s(S_QBASE + 1)}")
+        emit(f"v_addc_co_u32 {v(T[5])}, vcc, {v(T[5])}, {v(T[7])}, vcc")
+        for sx in (0, 1):
+            for t in (0, 1):
+                emit(f"global_load_dwordx4 {vr(16 * qb + 8 * sx + 4 * t, 4)}, {vr(T[4], 2)}, off offset:{64 * sx + 32 * t}")
+    emit("s_waitcnt vmcnt(0)")
+    for qb in (0, 1):
+        emit(f"v_cmp_gt_i32 vcc, {s(S_SEQLENQ)}, {v(QROW[qb])}")
+        for r in range(16):
+            emit(f"v_cndmask_b32 {v(16 * qb + r)}, 0, {v(16 * qb + r)}, vcc")
+    for r in range(32):
+        emit(f"v_accvgpr_write_b32 a{128 + r}, {v(r)}")
+    emit("; ---- state")
+    for r in range(128):
+        emit(f"v_accvgpr_write_b32 a{r}, 0")
+    for qb in (0, 1):
+        emit(f"v_mov_b32 {v(MTRUE[qb])}, 0xff800000")
+        emit(f"v_mov_b32 {v(L0[qb])}, 0")
+        emit(f"v_mov_b32 {v(L1[qb])}, 0")
+        emit(f"v_mov_b32 {v(ALPHA[qb])}, 1.0")
+
+    emit("; ---- tiles of positions 0..3; K(0) fragments -> AGPRs, S(0) = K(0) Q^T, then K(1) fragments")
+    for p_, dst in ((0, S_NCUR), (1, S_NA), (2, S_NB), (3, S_NC)):
+        emit(f"s_min_u32 {s(S_T0)}, {p_}, {s(S_NM1)}")
+        emit(f"s_lshl_b32 {s(S_T0)}, {s(S_T0)}, 2")
+        emit(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_SEQ)}")
+        emit(f"v_mov_b32 {v(T[6])}, {s(S_T0)}")
+        emit(f"ds_read_b32 {v(T[8 + p_])}, {v(T[6])}")
+    for (j, t) in K_FRAGS:
+        emit(k_read(0, j, t))
+    emit(("DRAIN",))
+    for p_, dst in ((0, S_NCUR), (1, S_NA), (2, S_NB), (3, S_NC)):
+        emit(f"v_readfirstlane_b32 {s(dst)}, {v(T[8 + p_])}")
+    emit("s_nop 7")                                           # v_accvgpr_write (Q) / ds_read (K) -> MFMA operand reads
+    for (sx, kb, qb) in QK_ORDER:
+        out.append(mfma_qk(0, kb, sx, qb))
+    for (j, t) in K_FRAGS:
+        emit(k_read(KV_TILE, j, t))
+    emit(("DRAIN",))
+    emit("s_barrier")                                          # every wave has read K(0) and K(1): both K buffers are free
+    for it in dma_bases(S_NB, S_NB):                           # K(2) -> K buffer 0. V^T(1) / K(3) are staged by step 0.
+        out.append(it)
+    for it in dma_ops(0, 0, do_k=True, do_v=False):
+        out.append(it)
+        if "m0" in it:
+            emit("s_nop 0")
+    emit("s_nop 15")                                           # S(0): the last MFMA's results before the VALU reads them
+    emit("s_nop 15")
+    nomask = new_label("nomask")
+    emit(f"s_cmp_eq_u32 {s(S_NCUR)}, {s(S_KTM1)}")             # seqlen-k mask: first walked tile only (mask.h:44-78)
+    emit(f"s_cbranch_scc0 {nomask}")
+    emit(f"s_cmp_lt_i32 {s(S_TAILVALID)}, 64")
+    emit(f"s_cbranch_scc0 {nomask}")
+    for kb in range(2):
+        for r in range(16):
+            key = 32 * kb + (r & 3) + 8 * (r >> 2)
+            emit(f"v_add_u32 {v(T[0])}, {key}, {v(HH4)}")
+            emit(f"v_cmp_gt_i32 vcc, {s(S_TAILVALID)}, {v(T[0])}")
+            for qb in (0, 1):
+                emit(f"v_cndmask_b32 {v(S_(0, qb, kb) + r)}, {v(NEGINF)}, {v(S_(0, qb, kb) + r)}, vcc")
+    label(nomask)
+    for op in row_max_ops(0):
+        out.append(op)
+    emit(f"v_mov_b32 {v(T[0])}, {v(MLOC[0])}")
+    emit(f"v_mov_b32 {v(T[1])}, {v(MLOC[1])}")
+    emit("s_nop 1")
+    emit(f"v_permlane32_swap_b32 {v(MLOC[0])}, {v(T[0])}")
+    emit(f"v_permlane32_swap_b32 {v(MLOC[1])}, {v(T[1])}")
+    emit("s_nop 1")
+    for qb in (0, 1):
+        emit(f"v_max_f32 {v(MTRUE[qb])}, {v(MLOC[qb])}, {v(T[qb])}")
+    for qb in (0, 1):
+        emit(f"v_mov_b32 {v(MREF[qb])}, {v(MTRUE[qb])}")
+        set_nms(qb)
+        emit(f"v_add_f32 {v(MTHR[qb])}, {s(S_TAU)}, {v(MTRUE[qb])}")
+    emit(f"s_mov_b32 {s(S_DOMASK)}, 1")
+    for op in softmax_stream(0, list(range(XPAIRS))):
+        out.append(op)
+    for it in dma_bases(S_NC, S_NA, st=0):
+        out.append(it)
+    emit(("DRAIN",))
+    emit("s_barrier")
+
+
+def epilogue():
+    emit("; ---- flush the last vote word, export O^T / m_ref / l through LDS")
+    nofl = new_label("nolastflush")
+    emit(f"s_and_b32 {s(S_T0)}, {s(S_NTILES)}, 31")
+    emit(f"s_cmp_eq_u32 {s(S_T0)}, 0")
+    emit(f"s_cbranch_scc1 {nofl}")
+    emit(f"s_sub_u32 {s(S_T2)}, {s(S_NTILES)}, 1")
+    flush_domask(S_T2)
+    label(nofl)
+    emit("s_nop 15")
+    emit("s_nop 15")
+    emit("s_nop 15")
+    emit("s_nop 15")
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 10")
+    emit(f"v_lshl_add_u32 {v(T[0])}, {v(LANE)}, 4, {s(S_T0)}")
+    emit(f"v_add_u32 {v(T[0])}, {s(S_LDS)}, {v(T[0])}")
+    emit(f"v_add_u32 {v(T[1])}, 0x10000, {v(T[0])}")
+    for qb in (0, 1):
+        for db in range(4):
+            for q4 in range(4):
+                off = ((qb * 4 + db) * 4 + q4) * 4096
+                base, o2 = (T[0], off) if off < 65536 else (T[1], off - 65536)
+                emit(f"ds_write_b128 {v(base)}, {ar(O_(qb, db) + 4 * q4, 4)} offset:{o2}")
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 9")
+    emit(f"v_lshl_add_u32 {v(T[2])}, {v(LANE)}, 3, {s(S_T0)}")
+    emit(f"v_add_u32 {v(T[2])}, {s(S_EXPORT)}, {v(T[2])}")
+    for qb in (0, 1):
+        emit(f"v_mov_b32 {v(T[4])}, {v(MREF[qb])}")
+        emit(f"v_add_f32 {v(T[5])}, {v(L0[qb])}, {v(L1[qb])}")
+        emit(f"ds_write_b64 {v(T[2])}, {vr(T[4], 2)} offset:{2048 * qb}")
+    emit("s_waitcnt lgkmcnt(0)")
+
+
+def main():
+    prologue()
+    loop, done = new_label("loop"), new_label("done")
+    label(loop)
+    emit(f"s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}")
+    emit(f"s_cbranch_scc0 {done}")
+    step(0)
+    emit(f"s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}")
+    emit(f"s_cbranch_scc0 {done}")
+    step(1)
+    emit(f"s_branch {loop}")
+    for blk in deferred:
+        blk()
+    label(done)
+    epilogue()
+    lines = finalize(out)
+    text = "\n".join(lines)
+    path = sys.argv[1] if len(sys.argv) > 1 else "la_fwd_x64_fp8_body.inc"
+    with open(path, "w") as f:
+        f.write("// GENERATED by gen_fwd_x64_fp8.py — do not edit. Inline-asm body of la_fwd_fp8_d128_x64_kernel.\n")
+        f.write('R"ASM(\n' + text + '\n)ASM"\n')
+    print(f"wrote {path}: {len(lines)} lines, {text.count('v_mfma')} MFMAs")
+
+
+if __name__ == "__main__":
+    main()

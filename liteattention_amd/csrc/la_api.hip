@@ -38,6 +38,11 @@ bool dynamic_sched_enabled() {
     return on;
 }
 constexpr uint64_t kSchedWorkspaceBytes = 1024;   // 8 ticket counters of 64 bytes (+ slack)
+// fp8 kernel variant (env LA_FP8_KERNEL): x64 (default; q-tile 256, hand-scheduled) or v1 (128-row, hipcc-scheduled; A/B).
+bool fp8_x64_kernel() {
+    static const bool on = [] { const char* e = getenv("LA_FP8_KERNEL"); return !(e && e[0] == 'v'); }();
+    return on;
+}
 float rescale_tau() {
     static const float t = [] { const char* e = getenv("LA_RESCALE_TAU"); return e ? static_cast<float>(atof(e)) : 8.0f; }();
     return t;
@@ -74,6 +79,7 @@ int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n
     la::TileShape t = la::tile_shape(head_dim, element_size);
     if (t.block_m == 0) return (element_size == 2 || element_size == 1) ? LA_ERR_HEAD_DIM : LA_ERR_DTYPE;
     if (element_size == 2 && head_dim == 128 && bf16_d128_kernel() != Bf16Kernel::x64) t.block_m = 128;   // A/B kernels: 32 rows per wave
+    if (element_size == 1 && !fp8_x64_kernel()) t.block_m = 128;
     if (block_m) *block_m = t.block_m;
     if (block_n) *block_n = t.block_n;
     return LA_OK;
@@ -176,7 +182,8 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     if (static_cast<int64_t>(p.batch) * p.num_heads * p.q_tiles > 0x7fffffffLL) return LA_ERR_SHAPE;
 
     if (fp8) {
-        if (la::fwd_lds_bytes_fp8(p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
+        if ((fp8_x64_kernel() ? la::fwd_lds_bytes_x64_fp8(p.k_tiles, nullptr) : la::fwd_lds_bytes_fp8(p.k_tiles, nullptr)) > 160 * 1024)
+            return LA_ERR_SEQLEN;
         // 1) V -> pre-transposed, pre-swizzled V^T tiles in the caller's workspace; 2) forward on (Q, K, V^T)
         hipError_t e8 = hipSuccess;
         if (!(a->flags & LA_FLAG_V_PREPARED))
@@ -184,7 +191,8 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
                                        a->batch, a->seqlen_k, a->num_heads_k, p.k_tiles, stream);
         if (e8 == hipSuccess) {
             p.v = static_cast<const uint16_t*>(a->workspace);
-            e8 = la::launch_fwd_fp8_d128(p, a->read_list != nullptr, stream);
+            e8 = fp8_x64_kernel() ? la::launch_fwd_fp8_d128_x64(p, a->read_list != nullptr, stream)
+                                  : la::launch_fwd_fp8_d128(p, a->read_list != nullptr, stream);
         }
         if (e8 != hipSuccess) { g_last_hip_error = static_cast<int>(e8); return LA_ERR_LAUNCH; }
         return LA_OK;

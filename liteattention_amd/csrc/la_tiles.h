@@ -27,7 +27,7 @@ constexpr TileShape tile_shape(int head_dim, int element_size) {
         if (head_dim == 64) return {128, 64};   // K/V tile 8 KiB each: same key granularity, half the LDS
     }
     if (element_size == 1) {
-        if (head_dim == 128) return {128, 64};  // fp8 e4m3: K 8 KiB + V^T 8 KiB per stage
+        if (head_dim == 128) return {256, 64};  // fp8 e4m3: x64 structure on the block-scaled MFMA; K 8 KiB + V^T 8 KiB per stage
     }
     return {0, 0};
 }

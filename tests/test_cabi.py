@@ -52,7 +52,7 @@ def test_struct_layout_matches_header(tmp_path):
 
 def test_tile_sizes_and_status_strings():
     assert _cabi.get_tile_sizes(128, 2) == (256, 64) and _cabi.get_tile_sizes(64, 2) == (128, 64)
-    assert _cabi.get_tile_sizes(128, 1) == (128, 64)
+    assert _cabi.get_tile_sizes(128, 1) == (256, 64)
     lib = _cabi.load()
     m, n = ctypes.c_int(), ctypes.c_int()
     assert lib.la_get_tile_sizes(48, 2, ctypes.byref(m), ctypes.byref(n)) == _cabi.LA_ERR_HEAD_DIM
@@ -109,7 +109,6 @@ def test_argument_validation_returns_codes_without_launching():
     # fp8: workspace contract
     a.q_row_stride = 4 * 128
     a.dtype = _cabi.LA_DTYPE_FP8_E4M3
-    a.block_m = 128                                                            # the fp8 kernel's tile
     a.read_list = a.write_list = None
     assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 1 * 2 * 4 * 8192 + 1024  # B * Hk * Kt * 8 KiB + ticket counter
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_WORKSPACE

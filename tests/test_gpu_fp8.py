@@ -14,8 +14,15 @@ import torch
 from helpers import FP8_CASES, load_dense_case, ref_tolerance, structured_qkv
 
 pytestmark = pytest.mark.gpu
-BM, BN = 128, 64
 F8 = torch.float8_e4m3fn
+
+
+def _tiles():
+    import liteattention_amd as L
+    return L.get_tile_sizes(128, 1)           # (256, 64) x64 kernel; (128, 64) with LA_FP8_KERNEL=v1
+
+
+BM, BN = _tiles()
 
 
 def _tol(o):
@@ -26,7 +33,6 @@ def _tol(o):
 def test_fp8_dense_matches_reference_outputs(name):
     import liteattention_amd as L
     from oracle import oracle as orc
-    assert L.get_tile_sizes(128, 1) == (BM, BN)
     c = load_dense_case(name)
     q, k, v = [x.to(F8).cuda() for x in (c["q"], c["k"], c["v"])]
     qd, kd, vd = [c[n].cuda() for n in ("q_descale", "k_descale", "v_descale")]
