@@ -429,7 +429,10 @@ def step(variant):
         if qb == 0:
             pre[t].append(("WAIT", ("v", db, 1)))
         mf.append(mfma_pv(cur, db, qb))
-        post[t].append(k_read(kbuf_read, *K_FRAGS[t]))
+        if "klate" in OPT:
+            post[t].append(k_read(kbuf_read, *K_FRAGS[t]))
+        elif t < 4:                              # K(i+2) fragments in the first half: nothing young is left for the drain
+            post[t] += [k_read(kbuf_read, *K_FRAGS[2 * t]), k_read(kbuf_read, *K_FRAGS[2 * t + 1])]
     rare, back = new_label("rare"), new_label("rare_back")
     fl, flback = new_label("flush"), new_label("flush_back")
     vq = [f"    s_add_u32 {s(S_T3)}, {s(S_I)}, 4",

@@ -16,11 +16,13 @@ sys.path.insert(0, ROOT)
 
 def build_one(spec):
     name, _, opt = spec.partition("=")
-    x64 = opt.startswith("x64:")
-    if x64:
-        opt = opt[4:]
     inc = os.path.join(OUT, f"{name}.inc")
-    gen, env_key, macro = ("gen_fwd_x64.py", "LA_X64_OPT", "LA_X64_BODY_INC") if x64 else ("gen_fwd_asm.py", "LA_ASM_OPT", "LA_ASM_BODY_INC")
+    if opt.startswith("x64f8:"):          # name=x64f8:<opts> -> gen_fwd_x64_fp8.py with LA_X64F8_OPT (bench with --dtype fp8)
+        opt, gen, env_key, macro = opt[6:], "gen_fwd_x64_fp8.py", "LA_X64F8_OPT", "LA_X64F8_BODY_INC"
+    elif opt.startswith("x64:"):
+        opt, gen, env_key, macro = opt[4:], "gen_fwd_x64.py", "LA_X64_OPT", "LA_X64_BODY_INC"
+    else:
+        gen, env_key, macro = "gen_fwd_asm.py", "LA_ASM_OPT", "LA_ASM_BODY_INC"
     subprocess.run([sys.executable, os.path.join(CSRC, gen), inc], check=True, env=dict(os.environ, **{env_key: opt}),
                    stdout=subprocess.DEVNULL)
     # the other generated include must exist too (default options)
