@@ -277,7 +277,7 @@ def main():
                      "peak": MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(flops_rank / kern_s / 1e12 / (MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS), 4),
                      "traffic": None,
-                     "kernel": "la_prep_v_fp8_kernel + la_fwd_fp8_d128_kernel<true>" if fp8 else "la_fwd_bf16_d128_x64_kernel<true>",
+                     "kernel": "la_prep_v_fp8_kernel + la_fwd_fp8_d128_x64_kernel<true>" if fp8 else "la_fwd_bf16_d128_x64_kernel<true>",
                      "kernel_ms": round(kern_s * 1e3, 3),
                      "algorithmic_tflop_per_launch": round(flops_rank / 1e12, 3)},
     }
