@@ -372,16 +372,21 @@ def rescale_o_block(lbl, back):
 
 
 def dma_bases(n_k, n_v, st=0):
-    """Tile bases into register set `st` (clamped so a ragged tile never reads past the tensor; such a tile is re-staged by
-    dma_fixup): K -> TBS[st], V -> VBS[st], ragged flags -> RAGS[st]."""
+    """Tile bases into register set `st`: K -> TBS[st], V -> VBS[st], first row clamped to seqlen_k - 64. A ragged last tile
+    (k_tiles - 1, the only one that can be) is staged exactly - per-lane clamped rows - by the C++ shell, at position 0: a
+    valid list is strictly descending and holds it nowhere else. Wherever else it turns up (clamped duplicates past the end
+    of a short walk, malformed lists) the clamp keeps the reads inside the tensor; with LA_X64_OPT=ragfix the first version's
+    in-loop re-staging of such a tile is generated as well (19 instead of 12 SALU per step)."""
     S_RAG = RAGS[st]
-    o = [f"    s_mov_b32 {s(S_RAG)}, 0"]
+    ragfix = "ragfix" in OPT
+    o = [f"    s_mov_b32 {s(S_RAG)}, 0"] if ragfix else []
     for (n_sgpr, rs, base, dst, bit) in ((n_k, S_KRS, S_KBASE, TBS[st], 1), (n_v, S_VRS, S_VBASE, VBS[st], 2)):
-        o += [f"    s_lshl_b32 {s(S_T0)}, {s(n_sgpr)}, 6",
-              f"    s_cmp_gt_u32 {s(S_T0)}, {s(S_SAFEROW)}",
-              f"    s_cselect_b32 {s(S_T1)}, {bit}, 0",
-              f"    s_or_b32 {s(S_RAG)}, {s(S_RAG)}, {s(S_T1)}",
-              f"    s_min_u32 {s(S_T0)}, {s(S_T0)}, {s(S_SAFEROW)}",
+        o += [f"    s_lshl_b32 {s(S_T0)}, {s(n_sgpr)}, 6"]
+        if ragfix:
+            o += [f"    s_cmp_gt_u32 {s(S_T0)}, {s(S_SAFEROW)}",
+                  f"    s_cselect_b32 {s(S_T1)}, {bit}, 0",
+                  f"    s_or_b32 {s(S_RAG)}, {s(S_RAG)}, {s(S_T1)}"]
+        o += [f"    s_min_u32 {s(S_T0)}, {s(S_T0)}, {s(S_SAFEROW)}",
               f"    s_mul_hi_u32 {s(dst + 1)}, {s(S_T0)}, {s(rs)}",
               f"    s_mul_i32 {s(dst)}, {s(S_T0)}, {s(rs)}",
               f"    s_add_u32 {s(dst)}, {s(dst)}, {s(base)}",
@@ -584,8 +589,11 @@ def step(variant):
 
     # ---- tail: rare paths (O rescale, ragged re-stage), drain, barrier
     slow, slow_back = new_label("slow"), new_label("slow_back")
-    emit(f"s_or_b32 {s(S_T0)}, {s(S_RESC)}, {s(RAGS[variant])}")
-    emit(f"s_cmp_lg_u32 {s(S_T0)}, 0")
+    if "ragfix" in OPT:
+        emit(f"s_or_b32 {s(S_T0)}, {s(S_RESC)}, {s(RAGS[variant])}")
+        emit(f"s_cmp_lg_u32 {s(S_T0)}, 0")
+    else:
+        emit(f"s_cmp_lg_u32 {s(S_RESC)}, 0")
     emit(f"s_cbranch_scc1 {slow}")
     label(slow_back)
 
@@ -595,12 +603,14 @@ def step(variant):
         emit(f"s_cmp_lg_u32 {s(S_RESC)}, 0")
         emit(f"s_cbranch_scc1 {resc}")
         label(resc_back)
-        fix = new_label("fix")
-        emit(f"s_cmp_lg_u32 {s(RAGS[variant])}, 0")
-        emit(f"s_cbranch_scc1 {fix}")
+        if "ragfix" in OPT:
+            fix = new_label("fix")
+            emit(f"s_cmp_lg_u32 {s(RAGS[variant])}, 0")
+            emit(f"s_cbranch_scc1 {fix}")
         emit(f"s_branch {slow_back}")
         rescale_o_block(resc, resc_back)
-        dma_fixup_block(fix, slow_back, ("pos", 3), kbuf_stage, ("pos", 1), vbuf_stage, st=variant)
+        if "ragfix" in OPT:
+            dma_fixup_block(fix, slow_back, ("pos", 3), kbuf_stage, ("pos", 1), vbuf_stage, st=variant)
     deferred.append(slow_block)
     emit(("DRAIN",))
     if "nobarrier" not in OPT:
@@ -667,7 +677,7 @@ def prologue():
     emit(f"v_lshlrev_b32 {v(RAGV)}, 2, {v(T[6])}")
     emit(f"v_xor_b32 {v(RAGV)}, {v(T[2])}, {v(RAGV)}")
     emit(f"v_lshlrev_b32 {v(RAGV)}, 4, {v(RAGV)}")            # (cpos ^ (rip<<2)) << 4
-    emit(f"s_max_i32 {s(S_T1)}, {s(S_LASTROW)}, 63")          # seqlen_k < 64: the only tile is ragged, clamp its rows here
+    emit(f"s_mov_b32 {s(S_T1)}, {s(S_LASTROW)}")              # seqlen_k < 64: rows of the only tile stay inside the tensor
     for j in range(4):
         # LK[j] = (16w + 4j + rip)*k_rs + (RAGK ^ (j<<6)) - 1024j ; LV[j] = (16w + 4j + rip)*v_rs + RAGV - 1024j
         emit(f"v_add_u32 {v(T[4])}, {4 * j}, {v(RIPROW)}")
@@ -741,12 +751,13 @@ def prologue():
         out.append(it)
         if "m0" in it:
             emit("s_nop 0")
-    emit(f"s_and_b32 {s(S_RAG)}, {s(S_RAG)}, 1")
-    fix, fix_back = new_label("pfix"), new_label("pfix_back")
-    emit(f"s_cmp_lg_u32 {s(S_RAG)}, 0")
-    emit(f"s_cbranch_scc1 {fix}")
-    label(fix_back)
-    deferred.append(lambda: dma_fixup_block(fix, fix_back, S_NB, 0, S_NB, 0))
+    if "ragfix" in OPT:
+        emit(f"s_and_b32 {s(S_RAG)}, {s(S_RAG)}, 1")
+        fix, fix_back = new_label("pfix"), new_label("pfix_back")
+        emit(f"s_cmp_lg_u32 {s(S_RAG)}, 0")
+        emit(f"s_cbranch_scc1 {fix}")
+        label(fix_back)
+        deferred.append(lambda: dma_fixup_block(fix, fix_back, S_NB, 0, S_NB, 0))
     emit("s_nop 7")
     # seqlen-k mask: only if n0 == k_tiles-1 and tail_valid < 64  (mask.h:44-78; first walked tile only, mainloop...:1626)
     nomask = new_label("nomask")
