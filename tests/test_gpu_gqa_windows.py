@@ -214,3 +214,35 @@ def test_malformed_read_lists_are_memory_safe(dtype, D):
     assert n_tiles == B * H * Qt
     tol = (0.05 * o_ref.abs().max().item() + 2e-2) if dtype == "fp8" else _oracle_tol(o_ref)
     assert (out.float().cpu() - o_ref).abs().max().item() <= tol
+
+
+# ------------------------------------------------------------------------------------------ maximum key length
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+def test_longest_supported_key_sequence_and_the_typed_error_beyond_it(dtype):
+    """The expanded read list of a workgroup lives in LDS beside the K/V rings: ~6 700 key tiles (Sk ~ 429 000) fit. A walk of
+    6 000 tiles must match a torch fp32 reference; one tile count past the limit must raise the typed error, not launch."""
+    L = _L()
+    D, H, Sq = 128, 1, 300
+    Sk = 6000 * 64 - 17                                   # ragged last tile
+    g = torch.Generator().manual_seed(42)
+    q = torch.randn(1, Sq, H, D, generator=g)
+    k = torch.randn(1, Sk, H, D, generator=g)
+    v = torch.randn(1, Sk, H, D, generator=g)
+    if dtype == "fp8":
+        q, k, v = [x.to(F8) for x in (q, k, v)]
+    else:
+        q, k, v = [x.bfloat16() for x in (q, k, v)]
+    att = L.LiteAttention(threshold=-40.0, max_batch_size=1)           # lists walked, nothing dropped
+    out, lse = att(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
+    dense, lse_d = L.flash_attn_func(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
+    assert torch.equal(out, dense) and torch.equal(lse, lse_d)
+    qf, kf, vf = [x.float().cuda()[0, :, 0] for x in (q, k, v)]
+    sc = qf @ kf.T / D ** 0.5
+    ref = torch.softmax(sc, -1) @ vf
+    tol = 0.05 * ref.abs().max().item() + 2e-2 if dtype == "fp8" else 2.0 ** -7 * ref.abs().max().item() + 1e-3
+    assert (out.float()[0, :, 0] - ref).abs().max().item() <= tol
+    assert (lse[0, 0] - torch.logsumexp(sc, -1)).abs().max().item() <= 1e-3
+    assert att.get_skip_fraction() == 0.0
+    too_long = torch.zeros(1, 7000 * 64, H, D, dtype=q.dtype, device="cuda")
+    with pytest.raises(RuntimeError, match="too long"):
+        L.flash_attn_func(q.cuda(), too_long, too_long)
