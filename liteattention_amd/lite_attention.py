@@ -120,21 +120,27 @@ class LiteAttention:
 
     # ---- the attention call -------------------------------------------------------------------
     def __call__(self, query: Tensor, key: Tensor, value: Tensor, scale: Optional[float] = None,
-                 return_softmax_lse: bool = False, must_do_list: list = None, must_skip_list: list = None
-                 ) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+                 return_softmax_lse: bool = False, must_do_list: list = None, must_skip_list: list = None, *,
+                 q_descale: Optional[Tensor] = None, k_descale: Optional[Tensor] = None,
+                 v_descale: Optional[Tensor] = None) -> Union[Tensor, Tuple[Tensor, Tensor]]:
         """One attention call of a denoising step (:244-291).
 
         query (B, S, H, D) bf16; key/value (B, Sk, H, D). Returns out (B, S, H, D) — the reference
         docstring's (B, S, H*D) is wrong (Appendix B-5) — or ``(out, lse)`` with lse (B, H, S) fp32.
         ``must_do_list``: token ranges ``[start0, end0, ...]`` (descending) never dropped;
-        ``must_skip_list``: token ranges dropped from the start, applied when the lists are (re)built."""
+        ``must_skip_list``: token ranges dropped from the start, applied when the lists are (re)built.
+        ``q/k/v_descale`` (keyword-only extension; the reference class cannot pass them): fp32
+        ``(batch, nheads_k)`` dequantisation scales for e4m3 inputs, as ``flash_attn_func`` takes them."""
         read_list, write_list = self._get_read_write_lists(query, key, must_skip_list)
         must_do = None
         if read_list is not None:
             must_do = self._must_do_device_row(must_do_list, query, read_list.shape[3])
+        descales = {}
+        if q_descale is not None or k_descale is not None or v_descale is not None:      # only when given: the host-logic
+            descales = dict(q_descale=q_descale, k_descale=k_descale, v_descale=v_descale)   # tests record the exact call
         output = flash_attn_func(q=query, k=key, v=value, softmax_scale=scale, attn_read_list=read_list,
                                  attn_must_do_list=must_do, attn_write_list=write_list, thr=self.threshold,
-                                 return_softmax_lse=return_softmax_lse)
+                                 return_softmax_lse=return_softmax_lse, **descales)
         if read_list is not None and _verbose():
             self._last_percentage = self.calc_percentage(read_list[: query.shape[0]])
             print(f"[Info]: Percentage of tiles skipped: {1.0 - self._last_percentage:.2%}")

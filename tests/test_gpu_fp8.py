@@ -72,14 +72,18 @@ def test_fp8_skip_lists_match_oracle_over_steps():
     md_row = orc.expand_must_do_ref([0, 0], BN, Kt + 1)
     margins = torch.empty(B, H, Qt, Kt)
     listed = []
+    # descales through LiteAttention.__call__ (keyword-only extension): per (batch, K/V head)
+    qd, kd, vd = torch.tensor([[0.7, 1.3]]), torch.tensor([[1.1, 0.9]]), torch.tensor([[0.5, 1.7]])
     for step in range(4):
         q, k, v = [x.to(F8) for x in structured_qkv(B, S, H, 128, seed=300, alpha=9.0, dtype=torch.float32)]
         rd_idx = att._phase if att._skip_list is not None else 0
-        out, lse = att(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
+        out, lse = att(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True, q_descale=qd.cuda(), k_descale=kd.cuda(),
+                       v_descale=vd.cuda())
         rd, wr = att._skip_list[rd_idx].cpu(), att._skip_list[1 - rd_idx].cpu()
         wr_orc = torch.zeros_like(wr)
         o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN, read_list=rd, write_list=wr_orc,
-                                           must_do_list=md_row, thr=thr, margins=margins, p_round="fp8")
+                                           must_do_list=md_row, thr=thr, margins=margins, p_round="fp8",
+                                           q_descale=qd, k_descale=kd, v_descale=vd)
         assert (out.float().cpu() - o_ref).abs().max().item() <= _tol(o_ref)
         assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
         bad, _ = _compare_lists(orc, rd, wr, wr_orc, margins, thr, B)
