@@ -270,7 +270,18 @@ __device__ __forceinline__ int expand_read_list(const int* __restrict__ row, int
         const int first = pos + incl - cnt;
         const int room = max(k_tiles - first, 0);
         cnt = min(cnt, room);
-        for (int j = 0; j < cnt; ++j) seq[first + j] = start - j;
+        // short ranges (the common case of real lists: hundreds of ranges of a few tiles): the lane writes its own tiles;
+        // the rest of a LONG range (imposed bands, early denoising steps: 1-2 ranges of hundreds of tiles, which one lane
+        // would write one LDS store at a time: 16 k cycles per item, tools/phase_profile.py) is filled by the whole wave
+        constexpr int kOwn = 4;
+        for (int j = 0; j < min(cnt, kOwn); ++j) seq[first + j] = start - j;
+        unsigned long long longs = __ballot(cnt > kOwn);
+        while (longs) {
+            const int src = __builtin_ctzll(longs);
+            longs &= longs - 1;
+            const int f = __shfl(first, src), s0 = __shfl(start, src), c = __shfl(cnt, src);
+            for (int j = kOwn + lane; j < c; j += 64) seq[f + j] = s0 - j;
+        }
         if (cnt > 0) atomicOr(&endflags[(first + cnt - 1) >> 5], 1u << ((first + cnt - 1) & 31));
         pos = min(pos + __shfl(incl, 63), k_tiles);
     }
