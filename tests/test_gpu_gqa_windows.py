@@ -246,3 +246,31 @@ def test_longest_supported_key_sequence_and_the_typed_error_beyond_it(dtype):
     too_long = torch.zeros(1, 7000 * 64, H, D, dtype=q.dtype, device="cuda")
     with pytest.raises(RuntimeError, match="too long"):
         L.flash_attn_func(q.cuda(), too_long, too_long)
+
+
+# ------------------------------------------------------------------------------------------ ticket queues cover every item
+@pytest.mark.parametrize("dtype,D", [("bf16", 128), ("bf16", 64), ("fp8", 128)])
+@pytest.mark.parametrize("B,H,S", [(1, 5, 2400), (3, 3, 700), (1, 1, 9000), (2, 7, 260)])
+def test_dynamic_work_distribution_computes_every_item_exactly(dtype, D, B, H, S):
+    """Per-XCD ticket queues + stealing must hand out every (batch, head, q-tile) once: head groups of 4 with a short last
+    group (B*H = 5, 9, 1, 14), chunks with a short last chunk, fewer items than workgroups. `out` is pre-filled with NaN
+    (a fresh allocation could still hold an earlier, identical result), and the result must equal the static map's bit for bit."""
+    L = _L()
+    from liteattention_amd.flash_attn_interface import mha_fwd
+    es = 1 if dtype == "fp8" else 2
+    bm, bn = L.get_tile_sizes(D, es)
+    Qt, Kt = math.ceil(S / bm), math.ceil(S / bn)
+    g = torch.Generator().manual_seed(B * 100 + H)
+    q, k, v = [torch.randn(B, S, H, D, generator=g) for _ in range(3)]
+    q, k, v = [(x.to(F8) if dtype == "fp8" else x.bfloat16()).cuda() for x in (q, k, v)]
+    lists = L.LiteAttention.init_skip_list(B, S, H, D, False, q.dtype, "cuda")
+    res = []
+    for static in (False, True):
+        out = torch.full((B, S, H, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+        lists[1].zero_()
+        mha_fwd(q, k, v, out=out, attn_read_list=lists[0], attn_write_list=lists[1], thr=-30.0, _static_sched=static)
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(out.float()).any()), "an item was never computed"
+        assert bool((lists[1][..., 0] == 2).all()) and bool((lists[1][..., 1] == Kt - 1).all())      # every row was written
+        res.append(out)
+    assert torch.equal(res[0], res[1])
