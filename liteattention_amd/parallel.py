@@ -65,7 +65,7 @@ class HeadShardedLiteAttention:
                  max_batch_size: int = 4, process_group=None,
                  attention_fn: Optional[Callable[..., torch.Tensor]] = None, overlap_windows: int = 1,
                  windowed_attention_fn: Optional[Callable[..., torch.Tensor]] = None,
-                 q_tile_rows: Optional[int] = None):
+                 q_tile_rows: Optional[int] = None, _collective_at_world_1: bool = False):
         self.group = process_group
         if process_group is not None:
             import torch.distributed as dist
@@ -88,6 +88,9 @@ class HeadShardedLiteAttention:
                                                                                  static_sched="after_first", **kw)))
         self.overlap_windows = int(overlap_windows)
         self._q_tile_rows = q_tile_rows                # test seam (CPU stand-ins have no kernel tile); None = ask the library
+        # test seam: run the collective path on a 1-rank group too (an RCCL all-gather of one rank is a copy on RCCL's
+        # stream), so a 1-GPU box exercises the real async-collective / stream-ordering code with the real kernels
+        self._gather_min_world = 1 if _collective_at_world_1 else 2
 
     def shard(self, x: torch.Tensor) -> torch.Tensor:
         """(B, S, H, D) -> this rank's heads (a view)."""
@@ -137,14 +140,15 @@ class HeadShardedLiteAttention:
     def __call__(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None,
                  gather: bool = True, _kernel_events=None, **kw) -> Union[torch.Tensor, List[torch.Tensor]]:
         assert q.shape[2] == self.h1 - self.h0, "pass the local head shard (see shard())"
-        if self.world > 1 and gather and self.overlap_windows > 1 and self._windowed is not None:
+        if self.world >= self._gather_min_world and self.group is not None and gather and self.overlap_windows > 1 \
+                and self._windowed is not None:
             return self._call_overlapped(q, k, v, scale, _kernel_events, **kw)
         if _kernel_events is not None:
             _kernel_events[0].record()
         out = self._attention(q, k, v, scale, **kw)
         if _kernel_events is not None:
             _kernel_events[1].record()
-        if self.world == 1 or not gather:
+        if self.world < self._gather_min_world or self.group is None or not gather:
             return out
         import torch.distributed as dist
         out = out.contiguous()
