@@ -179,7 +179,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # LA_BENCH_FORCE_DIST=1: run the N > 1 code path (process group, trial step, overlapped all-gather, agreement
+    # all-reduce) on ONE rank too — a 1-rank RCCL all-gather is a copy on RCCL's stream. For exercising this file on a 1-GPU box.
+    force_dist = os.environ.get("LA_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -201,8 +204,9 @@ def main():
                for _ in range(3)]
 
     att = HeadShardedLiteAttention(num_heads=H, threshold=-10.0, max_batch_size=B,
-                                   process_group=None if world == 1 else dist.group.WORLD,
-                                   overlap_windows=args.overlap_windows if world > 1 else 1)
+                                   process_group=None if dist is None else dist.group.WORLD,
+                                   overlap_windows=args.overlap_windows if dist is not None else 1,
+                                   _collective_at_world_1=force_dist)
     att.local.threshold = float("-inf")     # imposed lists are a fixed point: identical work every step
 
     def set_sparsity(s):
@@ -238,7 +242,7 @@ def main():
     # ---- headline: 42 % imposed sparsity
     rows = set_sparsity(HEADLINE_SPARSITY)
     overlap_note = None
-    if world > 1 and att.overlap_windows > 1:
+    if dist is not None and att.overlap_windows > 1:
         # one trial step of the overlapped form; every rank must agree to keep it (a rank-local failure would
         # otherwise leave the others inside a collective), else all fall back to kernel-then-gather
         ok = 1
@@ -269,7 +273,7 @@ def main():
                                f"{HEADLINE_SPARSITY:.0%} sparsity (banded lists, thr=-inf), tiles {bm}x{bn}",
                    "sparsity": round(1 - listed_frac, 4),
                    "parallelism": f"heads sharded {world}x{Hl}" + (
-                       "" if world == 1 else
+                       "" if dist is None else
                        (f" + RCCL all-gather of O in {len(att.q_windows(q))} q-tile windows overlapped with compute"
                         if att.overlap_windows > 1 else " + 1 RCCL all-gather of O per step")),
                    "dense_equiv_tflops": round(4.0 * B * H * S * S * D / step_s / 1e12, 2)},
