@@ -106,3 +106,38 @@ def test_fp8_errors():
     q72 = torch.randn(1, 256, 2, 72, device="cuda").bfloat16().view(torch.int16)[..., :72].view(torch.bfloat16)
     with pytest.raises(RuntimeError, match="multiple of 16"):
         L.flash_attn_func(q72.to(F8), q72.to(F8), q72.to(F8))                               # fp8: head_size % 16 (:854-856)
+
+
+@pytest.mark.parametrize("gain", [3.0, 8.0])
+def test_fp8_running_max_that_grows_late_in_the_walk(gain):
+    """The fp8 x64 kernel keeps O and l relative to a reference max that follows the true running max only when it has
+    grown by more than tau = 2 (log2 units), with P offset 2^(8 - tau): keys walked LAST score far higher here, so every row's
+    max keeps growing through the walk — the O^T rescale round trip fires repeatedly and P sits at the top of its e4m3 range.
+    Lists must match the oracle (votes use the true running max), outputs stay inside the fp8 tolerance, nothing saturates."""
+    import liteattention_amd as L
+    from oracle import oracle as orc
+    from test_gpu_parity import _compare_lists
+    B, S, H = 1, 1536, 2
+    g = torch.Generator().manual_seed(91)
+    q, k, v = [torch.randn(B, S, H, 128, generator=g) for _ in range(3)]
+    k = k * torch.linspace(gain, 1.0, S).view(1, S, 1, 1)                  # early keys (walked last) up to `gain` x larger
+    q, k, v = [x.to(F8) for x in (q, k, v)]
+    o8, lse8, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN, p_round="fp8")
+    out, lse = L.flash_attn_func(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
+    assert bool(torch.isfinite(out.float()).all())
+    assert (out.float().cpu() - o8).abs().max().item() <= _tol(o8)
+    assert (lse.cpu() - lse8).abs().max().item() <= 1e-3
+    Qt, Kt = -(-S // BM), -(-S // BN)
+    att = L.LiteAttention(threshold=-1.0, max_batch_size=B)
+    margins = torch.empty(B, H, Qt, Kt)
+    for _ in range(2):
+        rd_idx = att._phase if att._skip_list is not None else 0
+        out, lse = att(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
+        rd, wr = att._skip_list[rd_idx].cpu(), att._skip_list[1 - rd_idx].cpu()
+        wr_orc = torch.zeros_like(wr)
+        o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN, read_list=rd, write_list=wr_orc, thr=-1.0,
+                                           margins=margins, p_round="fp8")
+        assert (out.float().cpu() - o_ref).abs().max().item() <= _tol(o_ref)
+        assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
+        bad, _ = _compare_lists(orc, rd, wr, wr_orc, margins, -1.0, B)
+        assert bad == 0
