@@ -31,7 +31,9 @@ def test_overlapped_and_plain_all_gather_on_a_one_rank_rccl_group():
                                            overlap_windows=1, _collective_at_world_1=True)
         over = L.HeadShardedLiteAttention(num_heads=H, threshold=-3.0, max_batch_size=B, process_group=dist.group.WORLD,
                                           overlap_windows=3, _collective_at_world_1=True)
-        over.q_windows = lambda q_: [(0, 4), (4, 4), (8, 3)]                 # 11 q-tiles of 256 rows in three windows
+        bm = L.get_tile_sizes(D, 2)[0]
+        Qt, per = -(-S // bm), 1024 // bm
+        over.q_windows = lambda q_: [(0, per), (per, per), (2 * per, Qt - 2 * per)]     # 1024 + 1024 + 552 rows
         for step in range(3):
             ref = local(q, k, v)
             g1 = plain(q, k, v)
