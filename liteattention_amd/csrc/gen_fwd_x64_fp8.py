@@ -140,7 +140,7 @@ def finalize(items):
                 lines.append(f"    s_waitcnt lgkmcnt({min(len(q) - 1 - idx, 15)})")
                 q = q[idx + 1:]
         elif it[0] == "DRAIN":
-            lines.append("    s_waitcnt vmcnt(0) lgkmcnt(0)")
+            lines.append("    s_waitcnt lgkmcnt(0)" if "nowaitvm" in OPT else "    s_waitcnt vmcnt(0) lgkmcnt(0)")   # nowaitvm: pricing only
             q = []
     return lines
 
@@ -479,7 +479,8 @@ def step(variant):
     label(slow_back)
     deferred.append(lambda: rescale_o_block(slow, slow_back))
     emit(("DRAIN",))
-    emit("s_barrier")
+    if "nobarrier" not in OPT:                 # pricing only
+        emit("s_barrier")
     emit(f"s_add_u32 {s(S_I)}, {s(S_I)}, 1")
 
 
