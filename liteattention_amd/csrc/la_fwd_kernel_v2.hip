@@ -56,8 +56,9 @@ constexpr int BN = 64;                           // keys per tile
 //                                                                         two rows per 256-byte bank row)
 //   V, read with ds_read_b64_tr_b16 by 32-lane groups covering 4 keys x 64 bytes: the 64-byte segment index is
 //      XOR-ed with  D=128: key & 3  (4 segments/row),  D=64: (key>>1) & 1  (2 segments/row).
-template <int D> __device__ __forceinline__ constexpr int k_swz(int row) { return D == 128 ? (row & 15) : ((row >> 1) & 7); }
-template <int D> __device__ __forceinline__ constexpr int v_swz(int row) { return D == 128 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2); }
+//   head_dim 256 (512-byte rows = two bank rows each): the same XORs as D = 128 on the low bits of the chunk / segment index.
+template <int D> __device__ __forceinline__ constexpr int k_swz(int row) { return D >= 128 ? (row & 15) : ((row >> 1) & 7); }
+template <int D> __device__ __forceinline__ constexpr int v_swz(int row) { return D >= 128 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2); }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -71,7 +72,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
 }  // namespace
 
 template <int D, bool SKIPABLE>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, D > 128 ? 1 : 2)      // head_dim 256: O 128 + Q 64 + S 64 registers -> one wave per SIMD
 la_fwd_bf16_v2_kernel(const FwdParams p) {
     constexpr int BM = 128;
     constexpr int ROW_BYTES = D * 2;                 // 256 / 128
@@ -103,7 +104,7 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
   for (;;) {
     int vid;
     if (dynamic) {
-        if (tid == 0) meta[1] = next_work_item(p, 64, &meta[2]);     // 64 = workgroups co-resident on an XCD
+        if (tid == 0) meta[1] = next_work_item(p, D > 128 ? 32 : 64, &meta[2]);     // = workgroups co-resident on an XCD
         __syncthreads();
         vid = meta[1];
         if (static_cast<unsigned>(vid) >= static_cast<unsigned>(total_work)) return;     // -1: no work left
@@ -168,8 +169,13 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
             const unsigned char* vb_ = vg + static_cast<int64_t>(row_w) * v_rs;
 #pragma unroll
             for (int j = 0; j < PPW; ++j) {
-                if (do_k) dma16(kb_ + j * RPP * k_rs + (k_lane ^ (j << 6)), k_lds + kbuf * TILE_BYTES + (PPW * wave + j) * 1024);
-                if (do_v) dma16(vb_ + j * RPP * v_rs + v_lane, v_lds + vbuf * TILE_BYTES + (PPW * wave + j) * 1024);
+                // swizzle of row RPP*j + rip from the lane's swz(rip): K: ^ (RPP*j mapped through k_swz) = 4j (D = 128: rows
+                // 4j+rip; D = 64: rows 8j+rip, >>1) or 2j (D = 256: rows 2j+rip); V: unchanged, except D = 256 where rows
+                // 2j+rip flip bit 1 of (row & 3) on odd j
+                constexpr int KX = D > 128 ? 2 : 4;
+                const int vx = D > 128 ? ((j & 1) << 7) : 0;
+                if (do_k) dma16(kb_ + j * RPP * k_rs + (k_lane ^ ((KX * j) << 4)), k_lds + kbuf * TILE_BYTES + (PPW * wave + j) * 1024);
+                if (do_v) dma16(vb_ + j * RPP * v_rs + (v_lane ^ vx), v_lds + vbuf * TILE_BYTES + (PPW * wave + j) * 1024);
             }
         } else {
             asm volatile("; ragged K/V tail" ::: "memory");                  // keep this a real (rare) branch
@@ -418,7 +424,7 @@ static hipError_t launch_v2(const FwdParams& p, hipStream_t stream) {
                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (err != hipSuccess) return err;
     int grid = total;
-    const hipError_t qerr = prepare_work_queue(pp, SKIPABLE, total, 2, stream, &grid);     // two workgroups per CU
+    const hipError_t qerr = prepare_work_queue(pp, SKIPABLE, total, D > 128 ? 1 : 2, stream, &grid);     // workgroups per CU
     if (qerr != hipSuccess) return qerr;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, pp);
     return hipGetLastError();
@@ -427,6 +433,7 @@ static hipError_t launch_v2(const FwdParams& p, hipStream_t stream) {
 hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, hipStream_t stream) {
     if (head_dim == 128) return skipable ? launch_v2<128, true>(p, stream) : launch_v2<128, false>(p, stream);
     if (head_dim == 64) return skipable ? launch_v2<64, true>(p, stream) : launch_v2<64, false>(p, stream);
+    if (head_dim == 256) return skipable ? launch_v2<256, true>(p, stream) : launch_v2<256, false>(p, stream);
     return hipErrorInvalidValue;
 }
 

@@ -25,6 +25,8 @@ constexpr TileShape tile_shape(int head_dim, int element_size) {
     if (element_size == 2) {
         if (head_dim == 128) return {256, 64};
         if (head_dim == 64) return {128, 64};   // K/V tile 8 KiB each: same key granularity, half the LDS
+        if (head_dim == 256) return {128, 64};  // K/V tile 32 KiB each, one workgroup per CU, one wave per SIMD (functional
+                                                // coverage of the reference's 192/256 instantiations; 192 runs here zero-padded)
     }
     if (element_size == 1) {
         if (head_dim == 128) return {256, 64};  // fp8 e4m3: x64 structure on the block-scaled MFMA; K 8 KiB + V^T 8 KiB per stage

@@ -145,7 +145,7 @@ def test_q_tile_window_leaves_other_rows_untouched_and_rejects_bad_windows():
 
 
 # ------------------------------------------------------------------------------------------ head dims between instantiations
-@pytest.mark.parametrize("D,dtype", [(96, "bf16"), (40, "bf16"), (72, "bf16"), (96, "fp8")])
+@pytest.mark.parametrize("D,dtype", [(96, "bf16"), (40, "bf16"), (72, "bf16"), (96, "fp8"), (256, "bf16"), (192, "bf16"), (160, "bf16")])
 def test_other_head_dims_run_on_the_next_instantiated_kernel(D, dtype):
     """head_dim 96 (instantiated by the reference, hopper/setup.py:58) and other multiples of 8 below 128 run the next
     kernel up on zero-padded operands; results must match the oracle at the ORIGINAL head_dim (scale D^-0.5) and the lists
@@ -275,3 +275,26 @@ def test_dynamic_work_distribution_computes_every_item_exactly(dtype, D, B, H, S
         assert bool((lists[1][..., 0] == 2).all()) and bool((lists[1][..., 1] == Kt - 1).all())      # every row was written
         res.append(out)
     assert torch.equal(res[0], res[1])
+
+
+def test_reference_profile_script_head_dims():
+    """/root/reference/profile_lite_attention.py: LiteAttention on (1, 10000, 4, d) bf16 for d in 32, 64, 96, 128, 192, 256 with
+    threshold +2 (a tile survives only if it raises some row's running max by more than 2^2), two calls each, then prints
+    `_skip_list.shape`. Every head_dim must run; after the calls almost everything is skipped, and every row still starts
+    with the tile that can never be dropped."""
+    L = _L()
+    torch.manual_seed(0)
+    for head_dim in [32, 64, 96, 128, 192, 256]:
+        attn = L.LiteAttention()
+        attn.threshold = float(2)
+        for i in range(2):
+            q, k, v = [torch.randn(1, 2 * 5000, 4, head_dim, device="cuda", dtype=torch.bfloat16) for _ in range(3)]
+            output = attn(q, k, v)
+        torch.cuda.synchronize()
+        bm, bn = L.get_tile_sizes(head_dim, 2)
+        Qt, Kt = math.ceil(10000 / bm), math.ceil(10000 / bn)
+        assert tuple(attn._skip_list.shape) == (2, 4, 4, Qt, Kt + 1) and output.shape == q.shape
+        cur = attn.current_read_list()[:1]
+        assert bool((cur[..., 0] >= 2).all()) and bool((cur[..., 1] == Kt - 1).all())
+        assert attn.get_skip_fraction(batch=1) > 0.9
+        assert bool(torch.isfinite(output.float()).all())

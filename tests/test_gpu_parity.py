@@ -353,9 +353,9 @@ def test_error_behaviour():
         L.flash_attn_func(q3, q3[:, :, :2], q3[:, :, :2])                      # nheads_k must divide nheads (:777)
     with pytest.raises(NotImplementedError):
         L.flash_attn_func(q, q, q[..., :64])                                   # head_dim_v != head_dim
-    q192 = torch.randn(1, 256, 2, 192, device="cuda").bfloat16()
+    q320 = torch.randn(1, 256, 2, 320, device="cuda").bfloat16()
     with pytest.raises(RuntimeError, match="head_size"):
-        L.flash_attn_func(q192, q192, q192)                                    # head_dim > 128 not instantiated
+        L.flash_attn_func(q320, q320, q320)                                    # head_dim > 256 not instantiated
     lists = torch.zeros(1, 2, 256 // BM, 5, dtype=torch.int32, device="cuda")
     with pytest.raises(RuntimeError, match="attn_read_list"):
         L.flash_attn_func(q, q, q, attn_read_list=lists.long(), attn_write_list=lists)

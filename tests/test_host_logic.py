@@ -41,8 +41,11 @@ def test_g1_reference_tile_table_is_recorded_and_build_table_comes_from_library(
     # gets the tiles of the next one up — the kernel that serves it on zero-padded operands
     assert L.get_tile_sizes(40, 2) == L.get_tile_sizes(64, 2) and L.get_tile_sizes(96, 2) == L.get_tile_sizes(128, 2)
     assert L.get_tile_sizes(96, 1) == L.get_tile_sizes(128, 1)
+    assert L.get_tile_sizes(192, 2) == L.get_tile_sizes(256, 2) == (128, 64)     # the reference's 192 / 256 instantiations
     with pytest.raises(RuntimeError):
-        L.get_tile_sizes(192, 2)                           # above 128: nothing instantiated
+        L.get_tile_sizes(320, 2)                           # above 256: nothing instantiated
+    with pytest.raises(RuntimeError):
+        L.get_tile_sizes(192, 1)                           # fp8: head_dim 128 only
     with pytest.raises(RuntimeError):
         L.get_tile_sizes(100, 2)                           # not a multiple of 8 (flash_api.cpp:854)
 
