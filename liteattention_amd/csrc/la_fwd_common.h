@@ -203,7 +203,7 @@ struct SchedGeom {
 
 // Returns the next item for this workgroup (bh * cnt + q-tile offset) or -1 when all queues are empty.
 // *own_empty (workgroup state, kept in LDS by the caller) remembers that the XCD's own queue has run dry.
-__device__ __noinline__ int next_work_item(const FwdParams& p, int chunk, int* own_empty) {
+__device__ __forceinline__ int next_work_item(const FwdParams& p, int chunk, int* own_empty) {
     const SchedGeom geo(p, chunk);
     unsigned* const ctr = p.work_counter;
     const int xcd = static_cast<int>(__builtin_amdgcn_s_getreg((3 << 11) | 20)) & (kSchedQueues - 1);   // HW_REG_XCC_ID[3:0]
