@@ -42,58 +42,21 @@ SPARSITIES = (0.0, 0.21, 0.42, 0.57, 0.77)
 HEADLINE_SPARSITY = 0.42
 
 
-def banded_rows(q_tiles: int, k_tiles: int, block_m: int, block_n: int, sparsity: float) -> torch.Tensor:
-    """[q_tiles, 5] int32 list-row heads for the imposed-sparsity pattern (<= 2 ranges)."""
-    keep = max(1, round((1.0 - sparsity) * k_tiles))
-    rows = torch.zeros(q_tiles, 5, dtype=torch.int32)
-    for m in range(q_tiles):
-        if keep >= k_tiles:
-            rows[m, :3] = torch.tensor([2, k_tiles - 1, 0])
-            continue
-        centre = min(k_tiles - 1, (m * block_m + block_m // 2) // block_n)
-        band = keep - 1                                   # + the always-walked first tile k_tiles-1
-        lo = max(0, min(centre - band // 2, k_tiles - 1 - band))
-        hi = lo + band - 1
-        if band <= 0:
-            rows[m, :3] = torch.tensor([2, k_tiles - 1, k_tiles - 1])
-        elif hi >= k_tiles - 2:                           # band touches the first tile: one range
-            rows[m, :3] = torch.tensor([2, k_tiles - 1, lo])
-        else:
-            rows[m] = torch.tensor([4, k_tiles - 1, k_tiles - 1, hi, lo])
-    return rows
+from liteattention_amd.selfcheck import (banded_rows, executed_flops, impose_lists,  # noqa: E402,F401  (re-exported:
+                                         listed_tiles_of_rows, sampled_row_check)          # tools/ and tests import them from here)
 
 
-def listed_tiles_of_rows(rows: torch.Tensor) -> int:
-    n = 0
-    for r in rows.tolist():
-        n += r[1] - r[2] + 1
-        if r[0] == 4:
-            n += r[3] - r[4] + 1
-    return n
-
-
-def impose_lists(att, rows: torch.Tensor):
-    """Overwrite BOTH ping-pong buffers of `att` with the same rows (fixed point under thr=-inf)."""
-    sl = att._skip_list
-    sl.zero_()
-    sl[..., :5] = rows.to(sl.device)[None, None, None]
-
-
-def executed_flops(rows: torch.Tensor, heads: int, batch: int, S: int, Sk: int, bm: int, bn: int, D: int) -> float:
-    """sum over listed tiles of 4*rows*cols*D with ragged edge tiles counted at their real size."""
-    q_tiles, k_tiles = rows.shape[0], -(-Sk // bn)
-    total = 0.0
-    last_cols = Sk - (k_tiles - 1) * bn
-    for m, r in enumerate(rows.tolist()):
-        nrows = min(bm, S - m * bm)
-        ranges = [(r[1], r[2])] + ([(r[3], r[4])] if r[0] == 4 else [])
-        cols = 0
-        for s, e in ranges:
-            cols += (s - e + 1) * bn
-            if s == k_tiles - 1:
-                cols -= bn - last_cols
-        total += 4.0 * nrows * cols * D
-    return total * heads * batch
+def kernel_source_hash() -> str:
+    """sha256[:16] over the kernel sources: `roofline.traffic` is taken from a committed PMC summary only when that
+    summary was measured on exactly these sources (a stale byte count is worse than null)."""
+    import hashlib
+    csrc = os.path.join(ROOT, "liteattention_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".py")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(S, D, bm, bn, rows, target_seconds=15.0):
@@ -162,6 +125,8 @@ def main():
     ap.add_argument("--heads", type=int, default=40)
     ap.add_argument("--no-sweep", action="store_true", help="skip the 1-GPU sparsity sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the fp8 (configs[4]) sub-record of the 1-GPU bf16 line")
+    ap.add_argument("--no-verify", action="store_true", help="skip the sampled-row check after the timed loop")
     ap.add_argument("--overlap-windows", type=int, default=3,
                     help="N > 1: q-tile windows per step whose all-gathers overlap the next window's compute (1 = off)")
     ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
@@ -194,128 +159,203 @@ def main():
     B, S, H, D = 1, args.seqlen, args.heads, 128
     assert H % world == 0, "heads must divide over ranks"
     Hl = H // world
-    fp8 = args.dtype == "fp8"
-    in_dtype = torch.float8_e4m3fn if fp8 else torch.bfloat16
-    bm, bn = L.get_tile_sizes(D, 1 if fp8 else 2)
-    q_tiles, k_tiles = -(-S // bm), -(-S // bn)
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    q, k, v = [torch.randn(B, S, Hl, D, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16).to(in_dtype)
-               for _ in range(3)]
-
-    att = HeadShardedLiteAttention(num_heads=H, threshold=-10.0, max_batch_size=B,
-                                   process_group=None if dist is None else dist.group.WORLD,
-                                   overlap_windows=args.overlap_windows if dist is not None else 1,
-                                   _collective_at_world_1=force_dist)
-    att.local.threshold = float("-inf")     # imposed lists are a fixed point: identical work every step
-
-    def set_sparsity(s):
-        rows = banded_rows(q_tiles, k_tiles, bm, bn, s)
-        if att.local._skip_list is None:
-            att.local._get_read_write_lists(q, k)          # allocate for this shape
-            att.local._phase = 0
-        impose_lists(att.local, rows)
-        return rows
+    qkv_bf16 = [torch.randn(B, S, Hl, D, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16) for _ in range(3)]
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(steps, warmup):
-        for _ in range(warmup):
-            att(q, k, v)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            att(q, k, v, _kernel_events=ev[i])
-        barrier()
-        dt = time.perf_counter() - t0
-        kern_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
-        if dist is not None:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = t.item()
-        return dt / steps, kern_ms / 1e3
+    def run_dtype(dtype_name, steps, warmup, sweep, distributed):
+        """Headline measurement (+ optional sparsity sweep, + verification) for one input dtype on this rank's heads."""
+        fp8 = dtype_name == "fp8"
+        peak = MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS
+        q, k, v = [x.to(torch.float8_e4m3fn) for x in qkv_bf16] if fp8 else qkv_bf16
+        bm, bn = L.get_tile_sizes(D, 1 if fp8 else 2)
+        q_tiles, k_tiles = -(-S // bm), -(-S // bn)
+        use_dist = dist if distributed else None
+        att = HeadShardedLiteAttention(num_heads=H, threshold=-10.0, max_batch_size=B,
+                                       process_group=None if use_dist is None else dist.group.WORLD,
+                                       overlap_windows=args.overlap_windows if use_dist is not None else 1,
+                                       _collective_at_world_1=force_dist)
+        att.local.threshold = float("-inf")     # imposed lists are a fixed point: identical work every step
 
-    # ---- headline: 42 % imposed sparsity
-    rows = set_sparsity(HEADLINE_SPARSITY)
-    overlap_note = None
-    if dist is not None and att.overlap_windows > 1:
-        # one trial step of the overlapped form; every rank must agree to keep it (a rank-local failure would
-        # otherwise leave the others inside a collective), else all fall back to kernel-then-gather
-        ok = 1
-        try:
-            att(q, k, v)
-            torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001
-            ok, overlap_note = 0, f"overlapped all-gather failed ({e!r}); fell back to one all-gather after the kernel"
-        flag = torch.tensor([ok], device=dev, dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if flag.item() == 0:
-            att.overlap_windows = 1
-            overlap_note = overlap_note or "another rank failed the overlapped all-gather; fell back"
-    flops_rank = executed_flops(rows, Hl, B, S, S, bm, bn, D)
-    step_s, kern_s = timed(args.steps, args.warmup)
-    flops_job = flops_rank * world
-    listed_frac = listed_tiles_of_rows(rows) / (q_tiles * k_tiles)
+        def set_sparsity(s):
+            rows = banded_rows(q_tiles, k_tiles, bm, bn, s)
+            if att.local._skip_list is None:
+                att.local._get_read_write_lists(q, k)          # allocate for this shape
+                att.local._phase = 0
+            impose_lists(att.local, rows)
+            return rows
+
+        def timed(n_steps, n_warmup):
+            for _ in range(n_warmup):
+                att(q, k, v)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)]
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(n_steps):
+                att(q, k, v, _kernel_events=ev[i])
+            barrier()
+            dt = time.perf_counter() - t0
+            kern_ms = sum(a.elapsed_time(b) for a, b in ev) / n_steps
+            if use_dist is not None:
+                t = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = t.item()
+            return dt / n_steps, kern_ms / 1e3
+
+        # ---- headline: 42 % imposed sparsity
+        rows = set_sparsity(HEADLINE_SPARSITY)
+        overlap_note = None
+        if use_dist is not None and att.overlap_windows > 1:
+            # one trial step of the overlapped form; every rank must agree to keep it (a rank-local failure would
+            # otherwise leave the others inside a collective), else all fall back to kernel-then-gather
+            ok = 1
+            try:
+                att(q, k, v)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                ok, overlap_note = 0, f"overlapped all-gather failed ({e!r}); fell back to one all-gather after the kernel"
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if flag.item() == 0:
+                att.overlap_windows = 1
+                overlap_note = overlap_note or "another rank failed the overlapped all-gather; fell back"
+        flops_rank = executed_flops(rows, Hl, B, S, S, bm, bn, D)
+        step_s, kern_s = timed(steps, warmup)
+        flops_job = flops_rank * world
+        listed_frac = listed_tiles_of_rows(rows) / (q_tiles * k_tiles)
+        kernel_name = ("la_prep_v_fp8_kernel + la_fwd_fp8_d128_x64_kernel<true>" if fp8 else "la_fwd_bf16_d128_x64_kernel<true>")
+        # algorithmic minimum HBM bytes of one launch: Q + K + V once at the input width, O once in bf16 (lists and LSE are <2 %)
+        esz = 1 if fp8 else 2
+        alg_bytes = B * S * Hl * D * (3 * esz + 2)
+        res = {
+            "value": round(flops_job / step_s / 1e12, 2),
+            "ms_per_step": round(step_s * 1e3, 3),
+            "tiles": [bm, bn], "sparsity": round(1 - listed_frac, 4),
+            "dense_equiv_tflops": round(4.0 * B * H * S * S * D / step_s / 1e12, 2),
+            "roofline": {"bound": "mfma", "achieved": round(flops_rank / kern_s / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(flops_rank / kern_s / 1e12 / peak, 4), "traffic": None, "kernel": kernel_name,
+                         "kernel_ms": round(kern_s * 1e3, 3),
+                         "algorithmic_tflop_per_launch": round(flops_rank / 1e12, 3),
+                         "algorithmic_hbm_bytes_per_launch": alg_bytes},
+            "overlap_note": overlap_note,
+            "parallelism": f"heads sharded {world}x{Hl}" + (
+                "" if use_dist is None else
+                (f" + RCCL all-gather of O in {len(att.q_windows(q))} q-tile windows overlapped with compute"
+                 if att.overlap_windows > 1 else " + 1 RCCL all-gather of O per step")),
+        }
+        # traffic: only from a PMC summary measured on exactly these kernel sources
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary_fp8.json" if fp8 else "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as f:
+                    p = json.load(f)
+                if p.get("kernel_source_sha16") == kernel_source_hash() and p.get("n_gpus", 1) == world:
+                    res["roofline"]["traffic"] = p.get("hbm_bytes_per_launch")
+                    res["roofline"]["traffic_source"] = p.get("source")
+                else:
+                    res["roofline"]["traffic_source"] = "none: profiles/" + os.path.basename(pmc) + " was measured on other kernel sources"
+            except Exception:
+                pass
+
+        if use_dist is not None:
+            # per-rank kernel time (heads differ in sparsity on real lists; on the imposed lists this shows RCCL interference),
+            # the world RCCL actually sees, bytes gathered per step
+            t = torch.tensor([kern_s * 1e3], device=dev, dtype=torch.float64)
+            all_t = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+            dist.all_gather(all_t, t)
+            ks = [x.item() for x in all_t]
+            res["multi_gpu"] = {"rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                                "kernel_ms_per_rank": [round(x, 3) for x in ks],
+                                "kernel_ms_min": round(min(ks), 3), "kernel_ms_max": round(max(ks), 3),
+                                "bytes_gathered_per_rank_per_step": (dist.get_world_size() - 1) * B * S * Hl * D * 2,
+                                "overlapped_form_kept": bool(att.overlap_windows > 1),
+                                "overlap_windows": len(att.q_windows(q)) if att.overlap_windows > 1 else 1}
+
+        # ---- correctness gate on the timed configuration: sampled rows vs an fp32 torch reference with the same block mask
+        if not args.no_verify:
+            try:
+                rows42 = set_sparsity(HEADLINE_SPARSITY)
+                read_list = att.local._skip_list[att.local._phase].clone()
+                out, lse = att.local(q, k, v, return_softmax_lse=True)
+                heads = sorted({0, Hl // 2, Hl - 1})
+                tol = dict(o_rtol=0.05, o_atol=1e-3) if fp8 else dict(o_rtol=2.0 ** -8, o_atol=1e-4)
+                ver = sampled_row_check(q, k, v, out, lse, read_list, bm, bn, heads, n_rows=256, **tol)
+                ver["finite"] = bool(torch.isfinite(out.float()).all().item())
+                ver["lists_fixed_point"] = bool(torch.equal(att.local._skip_list[0], att.local._skip_list[1]))
+                ver["ok"] = bool(ver["ok"] and ver["finite"] and ver["lists_fixed_point"])
+                ver["what"] = (f"{ver['rows']} query rows ({len(heads)} heads x 256) of the timed {HEADLINE_SPARSITY:.0%} configuration vs fp32 "
+                               "torch attention over the listed keys; whole output finite; write list == read list at thr=-inf")
+                del out, lse
+            except Exception as e:  # noqa: BLE001
+                ver = {"ok": False, "error": repr(e)}
+            if use_dist is not None:
+                flag = torch.tensor([1 if ver.get("ok") else 0], device=dev, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ver["ok_all_ranks"] = bool(flag.item())
+                ver["ok"] = bool(ver.get("ok") and ver["ok_all_ranks"])
+            res["verified"] = ver
+
+        # ---- 1-GPU sparsity sweep (the reference's sparsity-vs-runtime curve, README.md:81-87)
+        if sweep:
+            sw = []
+            for s_ in SPARSITIES:
+                r = set_sparsity(s_)
+                fl = executed_flops(r, Hl, B, S, S, bm, bn, D)
+                st, ks_ = timed(max(5, steps // 2), 2)
+                sw.append({"sparsity": round(1 - listed_tiles_of_rows(r) / (q_tiles * k_tiles), 4),
+                           "ms": round(st * 1e3, 3), "kernel_ms": round(ks_ * 1e3, 3),
+                           "executed_tflops": round(fl / st / 1e12, 1),
+                           "dense_equiv_tflops": round(4.0 * B * H * S * S * D / st / 1e12, 1)})
+            t0 = sw[0]["ms"]
+            ref_curve = {0.0: 1.0, 0.21: 0.824, 0.42: 0.601, 0.57: 0.443, 0.77: 0.235}
+            for e, s_ in zip(sw, SPARSITIES):
+                e["t_over_t0"] = round(e["ms"] / t0, 3)
+                e["reference_t_over_t0"] = ref_curve[s_]
+            res["sweep"] = sw
+        res["_bm_bn_tiles"] = (bm, bn, q_tiles, k_tiles)
+        return res
+
+    main_res = run_dtype(args.dtype, args.steps, args.warmup, sweep=(world == 1 and not args.no_sweep), distributed=True)
+    bm, bn, q_tiles, k_tiles = main_res.pop("_bm_bn_tiles")
 
     result = {
         "metric": "self-attn TFLOPS + ms/step @ seq=75k d=128 bf16, sparsity 0->77%; 1/2/4/8 GPU",
-        "value": round(flops_job / step_s / 1e12, 2),
+        "value": main_res["value"],
         "unit": "TFLOP/s (executed: FLOPs of listed tiles only)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(step_s * 1e3, 3),
+        "ms_per_step": main_res["ms_per_step"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"QK-Skip self-attention fwd, B={B} S={S} H={H} D={D} {args.dtype}, imposed "
                                f"{HEADLINE_SPARSITY:.0%} sparsity (banded lists, thr=-inf), tiles {bm}x{bn}",
-                   "sparsity": round(1 - listed_frac, 4),
-                   "parallelism": f"heads sharded {world}x{Hl}" + (
-                       "" if dist is None else
-                       (f" + RCCL all-gather of O in {len(att.q_windows(q))} q-tile windows overlapped with compute"
-                        if att.overlap_windows > 1 else " + 1 RCCL all-gather of O per step")),
-                   "dense_equiv_tflops": round(4.0 * B * H * S * S * D / step_s / 1e12, 2)},
-        "roofline": {"bound": "mfma", "achieved": round(flops_rank / kern_s / 1e12, 2),
-                     "peak": MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(flops_rank / kern_s / 1e12 / (MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS), 4),
-                     "traffic": None,
-                     "kernel": "la_prep_v_fp8_kernel + la_fwd_fp8_d128_x64_kernel<true>" if fp8 else "la_fwd_bf16_d128_x64_kernel<true>",
-                     "kernel_ms": round(kern_s * 1e3, 3),
-                     "algorithmic_tflop_per_launch": round(flops_rank / 1e12, 3)},
+                   "sparsity": main_res["sparsity"],
+                   "parallelism": main_res["parallelism"],
+                   "dense_equiv_tflops": main_res["dense_equiv_tflops"]},
+        "roofline": main_res["roofline"],
     }
-    if overlap_note:
-        result["config"]["overlap_note"] = overlap_note
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary_fp8.json" if fp8 else "r01_pmc_summary.json")
-    if os.path.exists(pmc):
+    if main_res.get("overlap_note"):
+        result["config"]["overlap_note"] = main_res["overlap_note"]
+    for key in ("verified", "multi_gpu", "sweep"):
+        if key in main_res:
+            result[key] = main_res[key]
+
+    # ---- BASELINE.json configs[4] beside the headline: the same workload with e4m3 Q/K/V (bf16 out), a few extra seconds
+    if world == 1 and args.dtype == "bf16" and not args.no_fp8:
         try:
-            with open(pmc) as f:
-                p = json.load(f)
-            result["roofline"]["traffic"] = p.get("hbm_bytes_per_launch")
-            result["roofline"]["traffic_source"] = p.get("source")
-        except Exception:
-            pass
+            f8 = run_dtype("fp8", max(5, args.steps // 2), 2, sweep=False, distributed=False)
+            f8.pop("_bm_bn_tiles")
+            result["fp8"] = {"value": f8["value"], "unit": result["unit"], "ms_per_step": f8["ms_per_step"], "dtype": "fp8 (e4m3 in, fp32 accumulate, bf16 out)",
+                             "steps": max(5, args.steps // 2), "sparsity": f8["sparsity"], "tiles": f8["tiles"],
+                             "roofline": f8["roofline"], "verified": f8.get("verified")}
+        except Exception as e:  # noqa: BLE001
+            result["fp8"] = {"value": None, "error": repr(e)}
 
-    # ---- 1-GPU sparsity sweep (the reference's sparsity-vs-runtime curve, README.md:81-87)
-    if world == 1 and not args.no_sweep:
-        sweep = []
-        for s in SPARSITIES:
-            r = set_sparsity(s)
-            fl = executed_flops(r, Hl, B, S, S, bm, bn, D)
-            st, ks = timed(max(5, args.steps // 2), 2)
-            sweep.append({"sparsity": round(1 - listed_tiles_of_rows(r) / (q_tiles * k_tiles), 4),
-                          "ms": round(st * 1e3, 3), "kernel_ms": round(ks * 1e3, 3),
-                          "executed_tflops": round(fl / st / 1e12, 1),
-                          "dense_equiv_tflops": round(4.0 * B * H * S * S * D / st / 1e12, 1)})
-        t0 = sweep[0]["ms"]
-        ref_curve = {0.0: 1.0, 0.21: 0.824, 0.42: 0.601, 0.57: 0.443, 0.77: 0.235}
-        for e, s in zip(sweep, SPARSITIES):
-            e["t_over_t0"] = round(e["ms"] / t0, 3)
-            e["reference_t_over_t0"] = ref_curve[s]
-        result["sweep"] = sweep
-
-    if world == 1 and rank == 0 and not args.no_cpu_baseline and not fp8:
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.dtype == "bf16":
         try:
             result["cpu_baseline"] = cpu_baseline(S, D, bm, bn, banded_rows(q_tiles, k_tiles, bm, bn, HEADLINE_SPARSITY))
         except Exception as e:  # the baseline is a reported number, never the measured path

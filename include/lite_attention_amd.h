@@ -22,7 +22,8 @@
  *   - plain C: pointers, sizes, scalars. No torch types, no C++ types, no exceptions.
  *   - every pointer is a DEVICE pointer unless the name says `host`.
  *   - the library owns nothing, allocates nothing on the device and keeps no global mutable
- *     state; outputs and skip lists are caller-owned. `write_list` is mutated in place.
+ *     state (no environment variables are read either: every choice is an argument or a flag);
+ *     outputs and skip lists are caller-owned. `write_list` is mutated in place.
  *   - launches are asynchronous on the given hipStream_t (passed as void*); no host sync.
  *   - return value: LA_OK (0) or a negative la_status; on error nothing has been launched.
  */
@@ -35,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LA_ABI_VERSION 3
+#define LA_ABI_VERSION 4
 
 typedef enum la_status {
     LA_OK = 0,
@@ -43,7 +44,8 @@ typedef enum la_status {
     LA_ERR_STRUCT_SIZE = -2,     /* args->struct_size != sizeof(la_fwd_args): ABI mismatch        */
     LA_ERR_DTYPE = -3,           /* dtype not built (flash_api.cpp:715 "only supports fp16, bf16, fp8") */
     LA_ERR_HEAD_DIM = -4,        /* head_dim not instantiated / not a multiple of 8 (flash_api.cpp:854) */
-    LA_ERR_SHAPE = -5,           /* non-positive sizes, num_heads % num_heads_k != 0 (flash_api.cpp:777) */
+    LA_ERR_SHAPE = -5,           /* non-positive sizes, num_heads % num_heads_k != 0 (flash_api.cpp:777). seqlen_k == 0 is NOT
+                                  * an error: la_fwd stores o = 0, lse = +inf like the reference (flash_api.cpp:1241-1245) */
     LA_ERR_STRIDE = -6,          /* last dim must be contiguous (flash_api.cpp:726-728) / 16-byte rows  */
     LA_ERR_TILE_MISMATCH = -7,   /* block_m/block_n echo != la_get_tile_sizes (list indexing would be wrong) */
     LA_ERR_LISTS = -8,           /* read list without write list, or vice versa                   */
@@ -55,6 +57,11 @@ typedef enum la_status {
 } la_status;
 
 /* la_fwd_args.flags */
+#define LA_FLAG_KERNEL_128ROW 4u /* A/B: run the 128-row (32 rows per wave, hipcc-scheduled) kernel where the default is the 256-row
+                                  * hand-scheduled one (bf16 head_dim 128). The skip lists then use 128-row q-tiles: take the tile
+                                  * sizes from la_get_tile_sizes_ex() with the same flags. fp8: needs a -DLA_WITH_AB_KERNELS build. */
+#define LA_FLAG_EXACT_RESCALE 8u /* A/B: the 256-row kernels rescale O on EVERY growth of a row maximum (tau = 0) instead of lazily
+                                  * (bf16: only after it grew by more than 2^8; results agree to rounding, lists are identical) */
 #define LA_FLAG_STATIC_SCHED 2u  /* keep one workgroup per item (static XCD map) even when a workspace is given. For
                                   * launches that must share the GPU with another kernel while they run — e.g. an RCCL
                                   * collective on another stream: persistent workgroups would hold every CU until the
@@ -139,11 +146,24 @@ typedef struct la_fwd_args {
     int32_t  q_tile_begin, q_tile_count;
     uint32_t flags;              /* LA_FLAG_* */
     uint32_t reserved0;          /* must be 0 */
+
+    /* Variable-length (packed) batches (ABI 4) — the reference's cu_seqlens_q / cu_seqlens_k of mha_fwd
+     * (flash_api.cpp:672-674, 736-760; Python: hopper/_internal/flash_attn_interface.py:638-682). Both NULL = fixed length.
+     * Both given: q is (total_q, H, D), k/v (total_k, Hk, D), o (total_q, H, D) — the *_batch_stride fields are ignored —
+     * cu_seqlens_* are DEVICE int32[batch + 1] prefix sums (sequence b = rows [cu[b], cu[b+1])), seqlen_q / seqlen_k are the
+     * MAXIMUM sequence lengths (they size the grid; longer sequences are truncated to them), and lse is (H, total_q):
+     * lse[h * total_q + row]. Sequences with no keys get o = 0, lse = +inf. Dense only: read_list must be NULL (the
+     * reference's varlen entry point has no skip lists either); bf16 only. One launch for the whole batch, no host sync. */
+    const int32_t* cu_seqlens_q;
+    const int32_t* cu_seqlens_k;
+    int64_t        total_q;      /* rows of q / o (= cu_seqlens_q[batch]); the head stride of lse */
 } la_fwd_args;
 
 /* Tile sizes (kBlockM, kBlockN) of the kernel that la_fwd will run for (head_dim, element size).
  * Skip-list geometry depends on them, so host code must take them from here. */
 int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n);
+/* The same for a launch that sets `flags` (only LA_FLAG_KERNEL_128ROW changes the answer). */
+int la_get_tile_sizes_ex(int head_dim, int element_size, uint32_t flags, int* block_m, int* block_n);
 
 /* Bytes of `workspace` la_fwd wants for these arguments (fp8: required; bf16 with lists: optional, see la_fwd_args;
  * 0 otherwise). Negative la_status on bad arguments. */

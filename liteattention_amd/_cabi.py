@@ -13,7 +13,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # LITEATTENTION_AMD_LIB overrides the in-tree location (deployment / tests of the failure path)
 LIB_PATH = os.environ.get("LITEATTENTION_AMD_LIB") or os.path.join(_PKG_DIR, "libliteattention_amd.so")
 
-LA_ABI_VERSION = 3
+LA_ABI_VERSION = 4
 LA_DTYPE_BF16, LA_DTYPE_FP16, LA_DTYPE_FP8_E4M3 = 0, 1, 2
 
 LA_OK = 0
@@ -24,7 +24,7 @@ LA_ERR_WORKSPACE = -12
 LA_ERR_Q_WINDOW = -13
 
 EXPORTED_SYMBOLS = (
-    "la_abi_version", "la_get_tile_sizes", "la_fwd", "la_fwd_workspace_bytes", "la_skip_list_stats", "la_combine",
+    "la_abi_version", "la_get_tile_sizes", "la_get_tile_sizes_ex", "la_fwd", "la_fwd_workspace_bytes", "la_skip_list_stats", "la_combine",
     "la_status_string", "la_last_hip_error",
 )
 
@@ -53,11 +53,30 @@ class LaFwdArgs(ctypes.Structure):
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64),
         ("q_tile_begin", ctypes.c_int32), ("q_tile_count", ctypes.c_int32),
         ("flags", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
+        ("cu_seqlens_q", ctypes.c_void_p), ("cu_seqlens_k", ctypes.c_void_p), ("total_q", ctypes.c_int64),
     ]
 
 
 LA_FLAG_V_PREPARED = 1
 LA_FLAG_STATIC_SCHED = 2
+LA_FLAG_KERNEL_128ROW = 4
+LA_FLAG_EXACT_RESCALE = 8
+
+
+def default_flags() -> int:
+    """A/B switches of the HOST layer (the C library reads no environment): they only choose the default ``la_fwd_args.flags``.
+    LA_FWD_KERNEL=v2 -> the 128-row bf16 head_dim-128 kernel (lists then use 128-row q-tiles); LA_SCHED=static -> one
+    workgroup per item instead of the ticket queues; LA_RESCALE_TAU=0 -> O rescaled on every growth of a row maximum."""
+    f = 0
+    if os.environ.get("LA_FWD_KERNEL", "").startswith("v2"):
+        f |= LA_FLAG_KERNEL_128ROW
+    if os.environ.get("LA_SCHED", "").startswith("s"):
+        f |= LA_FLAG_STATIC_SCHED
+    if os.environ.get("LA_RESCALE_TAU", "") not in ("", "8", "8.0"):
+        if float(os.environ["LA_RESCALE_TAU"]) != 0.0:
+            raise ValueError("LA_RESCALE_TAU: only 0 (exact rescale, LA_FLAG_EXACT_RESCALE) or the default 8 are available")
+        f |= LA_FLAG_EXACT_RESCALE
+    return f
 
 
 class NativeLibraryError(RuntimeError):
@@ -90,6 +109,9 @@ def load() -> ctypes.CDLL:
     lib.la_abi_version.restype = ctypes.c_int
     lib.la_get_tile_sizes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     lib.la_get_tile_sizes.restype = ctypes.c_int
+    lib.la_get_tile_sizes_ex.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int),
+                                         ctypes.POINTER(ctypes.c_int)]
+    lib.la_get_tile_sizes_ex.restype = ctypes.c_int
     lib.la_fwd.argtypes = [ctypes.POINTER(LaFwdArgs), ctypes.c_void_p]
     lib.la_fwd.restype = ctypes.c_int
     lib.la_fwd_workspace_bytes.argtypes = [ctypes.POINTER(LaFwdArgs)]
@@ -114,10 +136,14 @@ def status_string(code: int) -> str:
     return load().la_status_string(code).decode()
 
 
-def get_tile_sizes(head_dim: int, element_size: int) -> Tuple[int, int]:
-    """(kBlockM, kBlockN) of the kernel la_fwd runs for this head_dim / element size."""
+def get_tile_sizes(head_dim: int, element_size: int, flags: int = None) -> Tuple[int, int]:
+    """(kBlockM, kBlockN) of the kernel la_fwd runs for this head_dim / element size (and kernel-selection flags; default:
+    ``default_flags()``, what ``mha_fwd`` passes). fp8 has no 128-row kernel: the flag is dropped for 1-byte elements."""
     m, n = ctypes.c_int(0), ctypes.c_int(0)
-    rc = load().la_get_tile_sizes(int(head_dim), int(element_size), ctypes.byref(m), ctypes.byref(n))
+    f = (default_flags() if flags is None else flags) & LA_FLAG_KERNEL_128ROW
+    if element_size == 1:
+        f = 0
+    rc = load().la_get_tile_sizes_ex(int(head_dim), int(element_size), f, ctypes.byref(m), ctypes.byref(n))
     if rc != LA_OK:
         raise RuntimeError(f"la_get_tile_sizes(head_dim={head_dim}, element_size={element_size}): {status_string(rc)}")
     return m.value, n.value

@@ -1,7 +1,7 @@
 """In-tree build of the HIP extension: ``hipcc --offload-arch=gfx950 -shared`` -> libliteattention_amd.so.
 
 Replaces the reference's nvcc/CUTLASS build (/root/reference/hopper/setup.py:381-674): no network, no
-downloaded toolchain, no feature-flag matrix — the build is {bf16} x {head_dim 128} for gfx950 only.
+downloaded toolchain, no feature-flag matrix — the build is {bf16: head_dim 64/128/256, fp8 e4m3: head_dim 128} for gfx950 only.
 The .so is written next to this file so that it travels with the source tree.
 """
 from __future__ import annotations
@@ -16,12 +16,10 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_NAME = "libliteattention_amd.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
-SOURCES = ["la_fwd_kernel_v2.hip", "la_fwd_kernel_asm.hip", "la_fwd_kernel_x64.hip", "la_fwd_kernel_fp8.hip",
-           "la_fwd_kernel_x64_fp8.hip", "la_aux_kernels.hip", "la_api.hip"]
-HEADERS = ["la_kernel_params.h", "la_tiles.h", "la_fwd_common.h", "gen_fwd_asm.py", "gen_fwd_x64.py", "gen_fwd_x64_fp8.py"]
-ASM_GEN = "gen_fwd_asm.py"      # writes la_fwd_asm_body.inc (the hand-scheduled main loop), included by la_fwd_kernel_asm.hip
-ASM_INC = "la_fwd_asm_body.inc"
-X64_GEN, X64_INC = "gen_fwd_x64.py", "la_fwd_x64_body.inc"
+SOURCES = ["la_fwd_kernel_v2.hip", "la_fwd_kernel_x64.hip", "la_prep_fp8.hip", "la_fwd_kernel_x64_fp8.hip", "la_aux_kernels.hip",
+           "la_api.hip"]
+HEADERS = ["la_kernel_params.h", "la_tiles.h", "la_fwd_common.h", "gen_fwd_x64.py", "gen_fwd_x64_fp8.py"]
+X64_GEN, X64_INC = "gen_fwd_x64.py", "la_fwd_x64_body.inc"      # the hand-scheduled main loop, included by la_fwd_kernel_x64.hip
 X64F8_GEN, X64F8_INC = "gen_fwd_x64_fp8.py", "la_fwd_x64_fp8_body.inc"     # fp8: the same structure on the block-scaled MFMA
 
 
@@ -52,8 +50,6 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str = Non
 
 
 def _compile(lib_path: str, defines, verbose: bool) -> str:
-    subprocess.run([sys.executable, os.path.join(CSRC, ASM_GEN), os.path.join(CSRC, ASM_INC)], check=True,
-                   stdout=None if verbose else subprocess.DEVNULL)
     subprocess.run([sys.executable, os.path.join(CSRC, X64_GEN), os.path.join(CSRC, X64_INC)], check=True,
                    stdout=None if verbose else subprocess.DEVNULL)
     subprocess.run([sys.executable, os.path.join(CSRC, X64F8_GEN), os.path.join(CSRC, X64F8_INC)], check=True,

@@ -1,10 +1,12 @@
 """Adapters that put the other operator surfaces named in BASELINE.json's north_star on the ONE gfx950 kernel
 (SURVEY.md §8 f2/f3). They add no new device code: every call ends in ``flash_attn_func`` above the C-ABI.
 
-* ``fa2_flash_attn_func`` / ``flash_attn_varlen_func`` — the dense FlashAttention surfaces Wan2.x's stock
-  ``flash_attention()`` wrapper calls for cross-attention (/root/reference/flash_attn/flash_attn_interface.py:1135,
-  1370; /root/reference/hopper/_internal/flash_attn_interface.py:638). Non-causal, no dropout / window / softcap /
-  alibi: anything else raises NotImplementedError (outside the hot path).
+* ``fa2_*`` / ``fa3_*`` / ``flash_attn_varlen_func`` — the dense FlashAttention surfaces Wan2.x's stock
+  ``flash_attention()`` wrapper calls for cross-attention (/root/reference/flash_attn/flash_attn_interface.py:998-1462;
+  /root/reference/hopper/_internal/flash_attn_interface.py:487-682), with the reference's signatures and return
+  conventions. Variable-length batches are ONE launch over the packed tensors (C-ABI ``cu_seqlens_q/k``), no host sync.
+  Non-causal, no dropout / window / softcap / alibi: anything else raises NotImplementedError (outside the hot path).
+  ``compat_shims/`` (opt-in, on PYTHONPATH) exposes them under the import names ``flash_attn`` / ``flash_attn_interface``.
 * ``blockmask_to_skip_lists`` / ``flash_blocksparse_attn_func`` — a STATIC 0/1 block mask expressed as skip lists
   and run with thr=-inf (nothing new is dropped). Counterpart of the reference's FA1-era block-sparse API
   (/root/reference/flash_attn/flash_blocksparse_attn_interface.py:7-39,185-200), which is dead code there (its
@@ -20,55 +22,157 @@ import torch
 from .flash_attn_interface import flash_attn_func, get_tile_sizes
 
 
+def _to_list(x) -> List[int]:
+    return x.tolist() if isinstance(x, torch.Tensor) else list(x)
+
+
 def _reject(**opts):
     for name, (val, default) in opts.items():
+        if isinstance(val, torch.Tensor):
+            raise NotImplementedError(f"{name} (tensor argument) is outside the QK-Skip hot path of this build")
         if val != default and val is not None:
             raise NotImplementedError(f"{name}={val!r} is outside the QK-Skip hot path of this build")
 
 
+def _reject_fa2(dropout_p, causal, window_size, softcap, alibi_slopes, block_table=None):
+    _reject(dropout_p=(dropout_p, 0.0), causal=(causal, False), window_size=(tuple(window_size), (-1, -1)),
+            softcap=(softcap, 0.0), alibi_slopes=(alibi_slopes, None), block_table=(block_table, None))
+
+
 def fa2_flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
                         alibi_slopes=None, deterministic=False, return_attn_probs=False):
-    """FlashAttention-2 signature (flash_attn/flash_attn_interface.py:1135-1211), dense forward on the gfx950 kernel."""
-    _reject(dropout_p=(dropout_p, 0.0), causal=(causal, False), window_size=(tuple(window_size), (-1, -1)),
-            softcap=(softcap, 0.0), alibi_slopes=(alibi_slopes, None))
+    """FlashAttention-2 signature (flash_attn/flash_attn_interface.py:1135-1211), dense forward on the gfx950 kernel.
+    Returns ``out`` or ``(out, softmax_lse, None)``."""
+    _reject_fa2(dropout_p, causal, window_size, softcap, alibi_slopes)
     if return_attn_probs:
         out, lse = flash_attn_func(q, k, v, softmax_scale=softmax_scale, return_softmax_lse=True)
         return out, lse, None
     return flash_attn_func(q, k, v, softmax_scale=softmax_scale)
 
 
-def _to_list(x) -> List[int]:
-    return x.tolist() if isinstance(x, torch.Tensor) else list(x)
+def fa2_flash_attn_kvpacked_func(q, kv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
+                                 alibi_slopes=None, deterministic=False, return_attn_probs=False):
+    """kv: (batch, seqlen_k, 2, nheads_k, headdim) (flash_attn_interface.py:1057-1133); views, no copies."""
+    return fa2_flash_attn_func(q, kv[:, :, 0], kv[:, :, 1], dropout_p, softmax_scale, causal, window_size, softcap,
+                               alibi_slopes, deterministic, return_attn_probs)
+
+
+def fa2_flash_attn_qkvpacked_func(qkv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
+                                  alibi_slopes=None, deterministic=False, return_attn_probs=False):
+    """qkv: (batch, seqlen, 3, nheads, headdim) (flash_attn_interface.py:998-1055); views, no copies."""
+    return fa2_flash_attn_func(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dropout_p, softmax_scale, causal, window_size,
+                               softcap, alibi_slopes, deterministic, return_attn_probs)
+
+
+def _cu_tensor(cu, device) -> torch.Tensor:
+    if isinstance(cu, torch.Tensor):
+        if cu.dtype != torch.int32:
+            raise RuntimeError("cu_seqlens must have dtype int32")                         # flash_api.cpp cu_seqlens checks
+        return cu.to(device).contiguous()
+    return torch.tensor(list(cu), dtype=torch.int32, device=device)
+
+
+def _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale, want_lse,
+                    q_descale=None, k_descale=None, v_descale=None):
+    """Packed variable-length dense attention in ONE launch: q (total_q, H, D), k/v (total_k, Hk, D), cu_seqlens_* int32
+    [B+1] (device tensors are used as they are: no host sync; ``max_seqlen_*`` size the grid, as in the reference,
+    hopper/_internal/flash_attn_interface.py:638-682). Returns (out bf16 (total_q, H, D), lse fp32 (H, total_q) or None)."""
+    if q.dim() != 3 or k.dim() != 3 or v.dim() != 3:
+        raise RuntimeError("varlen: q, k, v must be (total_tokens, nheads, headdim)")
+    n_q = cu_seqlens_q.numel() if isinstance(cu_seqlens_q, torch.Tensor) else len(cu_seqlens_q)
+    n_k = cu_seqlens_k.numel() if isinstance(cu_seqlens_k, torch.Tensor) else len(cu_seqlens_k)
+    if n_q != n_k or n_q < 2:
+        raise RuntimeError("cu_seqlens_q and cu_seqlens_k must both be [0, ..., total] with batch+1 entries")
+    for cu in (cu_seqlens_q, cu_seqlens_k):
+        if not isinstance(cu, torch.Tensor) and (cu[0] != 0 or any(b < a for a, b in zip(cu, cu[1:]))):
+            raise RuntimeError("cu_seqlens_q and cu_seqlens_k must both be [0, ..., total] with batch+1 entries")
+    if max_seqlen_q is None or max_seqlen_k is None:
+        if isinstance(cu_seqlens_q, torch.Tensor) or isinstance(cu_seqlens_k, torch.Tensor):
+            raise RuntimeError("max_seqlen_q / max_seqlen_k are required with device cu_seqlens (they size the launch)")
+        max_seqlen_q = max(b - a for a, b in zip(cu_seqlens_q, cu_seqlens_q[1:]))
+        max_seqlen_k = max(b - a for a, b in zip(cu_seqlens_k, cu_seqlens_k[1:]))
+    from .flash_attn_interface import mha_fwd
+    cq, ck = _cu_tensor(cu_seqlens_q, q.device), _cu_tensor(cu_seqlens_k, q.device)
+    out, lse, *_ = mha_fwd(q, k, v, cu_seqlens_q=cq, cu_seqlens_k=ck, max_seqlen_q=int(max_seqlen_q),
+                           max_seqlen_k=int(max_seqlen_k), softmax_scale=softmax_scale, q_descale=q_descale,
+                           k_descale=k_descale, v_descale=v_descale)
+    return out, (lse if want_lse else None)
+
+
+def fa2_flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q=None, max_seqlen_k=None,
+                               dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
+                               alibi_slopes=None, deterministic=False, return_attn_probs=False, block_table=None):
+    """FlashAttention-2 varlen signature (flash_attn/flash_attn_interface.py:1370-1462): returns ``out`` (total_q, H, D) bf16 or
+    ``(out, softmax_lse (H, total_q), None)``."""
+    _reject_fa2(dropout_p, causal, window_size, softcap, alibi_slopes, block_table)
+    out, lse = _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale,
+                               return_attn_probs)
+    return (out, lse, None) if return_attn_probs else out
+
+
+def fa2_flash_attn_varlen_kvpacked_func(q, kv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p=0.0,
+                                        softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
+                                        alibi_slopes=None, deterministic=False, return_attn_probs=False):
+    """kv: (total_k, 2, nheads_k, headdim) (flash_attn_interface.py:1278-1368)."""
+    return fa2_flash_attn_varlen_func(q, kv[:, 0], kv[:, 1], cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                                      dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic,
+                                      return_attn_probs)
+
+
+def fa2_flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
+                                         window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False,
+                                         return_attn_probs=False):
+    """qkv: (total, 3, nheads, headdim) (flash_attn_interface.py:1212-1276)."""
+    return fa2_flash_attn_varlen_func(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens, cu_seqlens, max_seqlen, max_seqlen,
+                                      dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic,
+                                      return_attn_probs)
+
+
+def fa3_flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, seqused_q=None,
+                               seqused_k=None, softmax_scale=None, causal=False, qv=None, q_descale=None, k_descale=None,
+                               v_descale=None, window_size=(-1, -1), attention_chunk=0, softcap=0.0, num_splits=1,
+                               pack_gqa=None, deterministic=False, sm_margin=0):
+    """FlashAttention-3 varlen signature (hopper/_internal/flash_attn_interface.py:638-682); returns ``out`` like the reference
+    (FlashAttnVarlenFunc.forward returns ``out`` only, :451)."""
+    _reject(seqused_q=(seqused_q, None), seqused_k=(seqused_k, None), causal=(causal, False), qv=(qv, None),
+            window_size=(tuple(window_size), (-1, -1)), attention_chunk=(attention_chunk, 0), softcap=(softcap, 0.0),
+            pack_gqa=(pack_gqa, None))
+    if num_splits not in (0, 1):
+        raise NotImplementedError("split-KV is compiled out (hopper/setup.py:48)")
+    out, _ = _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale, False,
+                             q_descale, k_descale, v_descale)
+    return out
+
+
+def fa3_flash_attn_qkvpacked_func(qkv, softmax_scale=None, causal=False, q_descale=None, k_descale=None, v_descale=None,
+                                  window_size=(-1, -1), attention_chunk=0, softcap=0.0, deterministic=False, num_heads_q=None,
+                                  sm_margin=0):
+    """FA3 packed signature (hopper/_internal/flash_attn_interface.py:487-545): qkv (batch, seqlen, 3, nheads, headdim), or
+    (batch, seqlen, nheads_q + 2*nheads_k, headdim) with ``num_heads_q``."""
+    if qkv.dim() == 5:
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    else:
+        if num_heads_q is None:
+            raise RuntimeError("num_heads_q is required for (batch, seqlen, nheads_q + 2*nheads_k, headdim) input")
+        hk = (qkv.shape[2] - num_heads_q) // 2
+        q, k, v = qkv[:, :, :num_heads_q], qkv[:, :, num_heads_q:num_heads_q + hk], qkv[:, :, num_heads_q + hk:]
+    return flash_attn_func(q, k, v, softmax_scale=softmax_scale, causal=causal, q_descale=q_descale, k_descale=k_descale,
+                           v_descale=v_descale, window_size=window_size, attention_chunk=attention_chunk, softcap=softcap,
+                           deterministic=deterministic, sm_margin=sm_margin)
 
 
 def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q=None, max_seqlen_k=None,
                            dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
                            alibi_slopes=None, deterministic=False, return_attn_probs=False, **fa3_kwargs):
-    """Packed variable-length attention: q (total_q, H, D), k/v (total_k, H, D), cu_seqlens_* int32 [B+1].
-
-    Each sequence is one dense launch on a view of the packed tensors (no copies). ``cu_seqlens`` given as
-    device tensors are read back once (one host sync per call) — pass Python lists to avoid it."""
-    _reject(dropout_p=(dropout_p, 0.0), causal=(causal, False), window_size=(tuple(window_size), (-1, -1)),
-            softcap=(softcap, 0.0), alibi_slopes=(alibi_slopes, None))
+    """Both varlen dialects in one entry point (kept for round-1 callers): FA2 keywords, FA3 keywords via ``**fa3_kwargs``
+    (tensor-valued or non-default ones are rejected explicitly)."""
+    descales = {n: fa3_kwargs.pop(n, None) for n in ("q_descale", "k_descale", "v_descale")}
     for name, val in fa3_kwargs.items():
-        if val not in (None, False, 0, 0.0, 1, (-1, -1)):
+        if isinstance(val, torch.Tensor) or val not in (None, False, 0, 0.0, 1, (-1, -1)):
             raise NotImplementedError(f"{name}={val!r} is outside the QK-Skip hot path of this build")
-    cq, ck = _to_list(cu_seqlens_q), _to_list(cu_seqlens_k)
-    if len(cq) != len(ck) or cq[0] != 0 or ck[0] != 0:
-        raise RuntimeError("cu_seqlens_q and cu_seqlens_k must both be [0, ..., total] with batch+1 entries")
-    out = torch.empty_like(q)
-    lse = torch.full((q.shape[1], q.shape[0]), float("inf"), dtype=torch.float32, device=q.device) if return_attn_probs else None
-    for b in range(len(cq) - 1):
-        q0, q1, k0, k1 = cq[b], cq[b + 1], ck[b], ck[b + 1]
-        if q1 == q0:
-            continue
-        res = flash_attn_func(q[q0:q1].unsqueeze(0), k[k0:k1].unsqueeze(0), v[k0:k1].unsqueeze(0),
-                              softmax_scale=softmax_scale, return_softmax_lse=return_attn_probs)
-        if return_attn_probs:
-            out[q0:q1] = res[0][0]
-            lse[:, q0:q1] = res[1][0]
-        else:
-            out[q0:q1] = res[0]
+    _reject_fa2(dropout_p, causal, window_size, softcap, alibi_slopes)
+    out, lse = _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale,
+                               return_attn_probs, **descales)
     return (out, lse, None) if return_attn_probs else out
 
 
@@ -135,3 +239,46 @@ def flash_blocksparse_attn_func(q, k, v, blockmask: torch.Tensor, softmax_scale=
     return flash_attn_func(q, k, v, softmax_scale=softmax_scale, attn_read_list=skip_lists[0],
                            attn_must_do_list=must_do, attn_write_list=skip_lists[1], thr=float("-inf"),
                            return_softmax_lse=return_softmax_lse)
+
+
+def convert_blockmask(blockmask: torch.Tensor, causal: bool = False) -> torch.Tensor:
+    """Name kept from the reference (flash_blocksparse_attn_interface.py:7-39), whose converted format feeds a CUDA entry point
+    that exists nowhere in its csrc; here the 0/1 mask is already the kernel-facing form (it becomes skip lists)."""
+    if causal:
+        raise NotImplementedError("causal block-sparse attention is outside the QK-Skip hot path of this build")
+    return blockmask.to(torch.bool)
+
+
+def flash_blocksparse_attn_qkvpacked_func(qkv, cu_seqlens, blockmask, dropout_p, max_s, softmax_scale=None, causal=False,
+                                          return_attn_probs=False, convert_mask=True):
+    """The reference's signature (flash_blocksparse_attn_interface.py:185-200): qkv (total, 3, nheads, headdim) packed
+    sequences, cu_seqlens [B+1], blockmask [ceil(max_s/kBlockM), ceil(max_s/kBlockN)] over THIS kernel's tiles, shared by
+    every sequence and head (sequence b uses its top-left ceil(len_b/kBlockM) x ceil(len_b/kBlockN) corner). Returns
+    ``context`` (total, nheads, headdim) or ``(context, softmax_lse (nheads, total), None)``. One launch per sequence:
+    skip lists are per fixed-length problem (mainloop_fwd_sm90_tma_gmma_ws.hpp:63-69)."""
+    _reject(dropout_p=(dropout_p, 0.0), causal=(causal, False))
+    if qkv.dim() != 4 or qkv.shape[1] != 3:
+        raise RuntimeError("qkv must be (total_tokens, 3, nheads, headdim)")
+    cu = _to_list(cu_seqlens)
+    H, D = qkv.shape[2], qkv.shape[3]
+    bm, bn = get_tile_sizes(D, qkv.element_size())
+    if tuple(blockmask.shape) != (-(-max_s // bm), -(-max_s // bn)):
+        raise ValueError(f"blockmask must be [{-(-max_s // bm)}, {-(-max_s // bn)}] for max_s={max_s} and tiles ({bm}, {bn})")
+    mask = convert_blockmask(blockmask, causal) if convert_mask else blockmask.to(torch.bool)
+    out = torch.empty((qkv.shape[0], H, D), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((H, qkv.shape[0]), dtype=torch.float32, device=qkv.device) if return_attn_probs else None
+    for b in range(len(cu) - 1):
+        t0, t1 = cu[b], cu[b + 1]
+        if t1 == t0:
+            continue
+        if t1 - t0 > max_s:
+            raise RuntimeError("a sequence is longer than max_s")
+        sub = mask[: -(-(t1 - t0) // bm), : -(-(t1 - t0) // bn)]
+        res = flash_blocksparse_attn_func(qkv[t0:t1, 0][None], qkv[t0:t1, 1][None], qkv[t0:t1, 2][None], sub,
+                                          softmax_scale=softmax_scale, return_softmax_lse=return_attn_probs)
+        if return_attn_probs:
+            out[t0:t1] = res[0][0]
+            lse[:, t0:t1] = res[1][0]
+        else:
+            out[t0:t1] = res[0]
+    return (out, lse, None) if return_attn_probs else out

@@ -6,47 +6,26 @@
 // layer turns codes into the reference's exception types.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "../../include/lite_attention_amd.h"
 #include "la_kernel_params.h"
 #include "la_tiles.h"
 
 namespace {
-thread_local int g_last_hip_error = 0;
+thread_local int g_last_hip_error = 0;     // per-thread error detail of the last failed launch; the only state in the library
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// bf16 / head_dim-128 kernel variant, fixed for the life of the process (env LA_FWD_KERNEL): the skip lists are
-// indexed by the selected kernel's tile, so la_get_tile_sizes and la_fwd must agree on it.
-// Default: x64 (one wave per SIMD, 64 rows per wave, q-tile 256). The 128-row kernels stay selectable for A/B runs:
-// v2 (hipcc-scheduled, also the head_dim-64 kernel) and asm (v2 with a hand-scheduled loop).
-enum class Bf16Kernel { v2, hand, x64 };
-Bf16Kernel bf16_d128_kernel() {
-    static const Bf16Kernel k = [] {
-        const char* e = getenv("LA_FWD_KERNEL");
-        if (e == nullptr || e[0] == 0) return Bf16Kernel::x64;
-        if (e[0] == 'v' && e[1] == '2') return Bf16Kernel::v2;
-        if (e[0] == 'a' && e[1] == 's') return Bf16Kernel::hand;
-        return Bf16Kernel::x64;
-    }();
-    return k;
-}
-// LA_SCHED=static disables the dynamic (ticket) work distribution of the x64 kernel for A/B runs.
-bool dynamic_sched_enabled() {
-    static const bool on = [] { const char* e = getenv("LA_SCHED"); return !(e && e[0] == 's'); }();
-    return on;
+// Kernel selection is a pure function of the arguments (no environment variables, no process-wide statics):
+//   bf16 head_dim 128: the 256-row hand-scheduled kernel (x64) unless LA_FLAG_KERNEL_128ROW asks for the 128-row one (v2);
+//   bf16 head_dim 64 / 256: v2; fp8 head_dim 128: x64-fp8. The skip lists are indexed by the selected kernel's tile, so
+//   la_get_tile_sizes_ex and la_fwd must agree on it: both call uses_128row().
+constexpr uint32_t kKnownFlags = LA_FLAG_V_PREPARED | LA_FLAG_STATIC_SCHED | LA_FLAG_KERNEL_128ROW | LA_FLAG_EXACT_RESCALE;
+bool uses_128row(int head_dim, int element_size, uint32_t flags) {
+    return element_size == 2 && head_dim == 128 && (flags & LA_FLAG_KERNEL_128ROW) != 0;
 }
 constexpr uint64_t kSchedWorkspaceBytes = 1024;   // 8 ticket counters of 64 bytes (+ slack)
-// fp8 kernel variant (env LA_FP8_KERNEL): x64 (default; q-tile 256, hand-scheduled) or v1 (128-row, hipcc-scheduled; A/B).
-bool fp8_x64_kernel() {
-    static const bool on = [] { const char* e = getenv("LA_FP8_KERNEL"); return !(e && e[0] == 'v'); }();
-    return on;
-}
-float rescale_tau() {
-    static const float t = [] { const char* e = getenv("LA_RESCALE_TAU"); return e ? static_cast<float>(atof(e)) : 8.0f; }();
-    return t;
-}
+constexpr float kRescaleTauBf16 = 8.0f;           // lazy-rescale slack of the x64 kernel, log2 units
 }  // namespace
 
 extern "C" {
@@ -62,11 +41,11 @@ const char* la_status_string(int status) {
         case LA_ERR_STRUCT_SIZE: return "la_fwd_args.struct_size mismatch (ABI version skew)";
         case LA_ERR_DTYPE: return "FlashAttention only supports fp16, bf16, and fp8_e4m3 type; this build instantiates bf16";
         case LA_ERR_HEAD_DIM: return "head_size not instantiated in this build (bf16: 64, 128, 256; fp8: 128)";
-        case LA_ERR_SHAPE: return "invalid shape (sizes must be positive; number of heads in key/value must divide number of heads in query)";
+        case LA_ERR_SHAPE: return "invalid shape (batch, seqlen_q, heads and head_dim must be positive; number of heads in key/value must divide number of heads in query)";
         case LA_ERR_STRIDE: return "Input tensor must have contiguous last dimension and 16-byte aligned rows";
         case LA_ERR_TILE_MISMATCH: return "block_m/block_n do not match la_get_tile_sizes(): skip lists would be mis-indexed";
         case LA_ERR_LISTS: return "attn_read_list and attn_write_list must be given together";
-        case LA_ERR_UNSUPPORTED: return "feature outside the QK-Skip hot path (head_dim_v != head_dim)";
+        case LA_ERR_UNSUPPORTED: return "feature outside the QK-Skip hot path (head_dim_v != head_dim, unknown flags, skip lists or fp8 with cu_seqlens)";
         case LA_ERR_LAUNCH: return "HIP kernel launch failed (see la_last_hip_error)";
         case LA_ERR_SEQLEN: return "seqlen_k too long: expanded skip list does not fit in LDS";
         case LA_ERR_WORKSPACE: return "fp8 needs a 16-byte aligned workspace of la_fwd_workspace_bytes() bytes";
@@ -75,25 +54,29 @@ const char* la_status_string(int status) {
     }
 }
 
-int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n) {
+int la_get_tile_sizes_ex(int head_dim, int element_size, uint32_t flags, int* block_m, int* block_n) {
     la::TileShape t = la::tile_shape(head_dim, element_size);
     if (t.block_m == 0) return (element_size == 2 || element_size == 1) ? LA_ERR_HEAD_DIM : LA_ERR_DTYPE;
-    if (element_size == 2 && head_dim == 128 && bf16_d128_kernel() != Bf16Kernel::x64) t.block_m = 128;   // A/B kernels: 32 rows per wave
-    if (element_size == 1 && !fp8_x64_kernel()) t.block_m = 128;
+    if ((flags & ~kKnownFlags) != 0) return LA_ERR_UNSUPPORTED;
+    if ((flags & LA_FLAG_KERNEL_128ROW) && element_size == 1) return LA_ERR_UNSUPPORTED;   // the 128-row fp8 kernel is not in this build
+    if (uses_128row(head_dim, element_size, flags)) t.block_m = 128;                       // A/B kernel: 32 rows per wave
     if (block_m) *block_m = t.block_m;
     if (block_n) *block_n = t.block_n;
     return LA_OK;
 }
 
+int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n) {
+    return la_get_tile_sizes_ex(head_dim, element_size, 0u, block_m, block_n);
+}
+
 int64_t la_fwd_workspace_bytes(const la_fwd_args* a) {
     if (a == nullptr) return LA_ERR_NULL_ARG;
     if (a->struct_size != sizeof(la_fwd_args)) return LA_ERR_STRUCT_SIZE;
-    if (a->dtype == LA_DTYPE_BF16)      // ticket counter of the dynamic work distribution (launches with lists)
-        return (a->read_list != nullptr && bf16_d128_kernel() != Bf16Kernel::hand && dynamic_sched_enabled())
-                   ? static_cast<int64_t>(kSchedWorkspaceBytes) : 0;
+    if (a->dtype == LA_DTYPE_BF16)      // ticket counters of the dynamic work distribution (launches with lists)
+        return (a->read_list != nullptr && !(a->flags & LA_FLAG_STATIC_SCHED)) ? static_cast<int64_t>(kSchedWorkspaceBytes) : 0;
     if (a->dtype != LA_DTYPE_FP8_E4M3) return LA_ERR_DTYPE;
     int bm = 0, bn = 0;
-    const int trc = la_get_tile_sizes(a->head_dim, 1, &bm, &bn);
+    const int trc = la_get_tile_sizes_ex(a->head_dim, 1, a->flags, &bm, &bn);
     if (trc != LA_OK) return trc;
     if (a->batch <= 0 || a->num_heads <= 0 || a->num_heads_k <= 0 || a->seqlen_k < 0) return LA_ERR_SHAPE;
     // V^T tiles, then the ticket counter of the dynamic work distribution
@@ -114,9 +97,9 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     if (a->num_heads % a->num_heads_k != 0) return LA_ERR_SHAPE;                          // flash_api.cpp:777
     if (a->head_dim % (fp8 ? 16 : 8) != 0) return LA_ERR_HEAD_DIM;                         // flash_api.cpp:854-856
     if (a->head_dim_v != a->head_dim) return LA_ERR_UNSUPPORTED;
-    if (a->reserved0 != 0 || (a->flags & ~(LA_FLAG_V_PREPARED | LA_FLAG_STATIC_SCHED)) != 0) return LA_ERR_UNSUPPORTED;
+    if (a->reserved0 != 0 || (a->flags & ~kKnownFlags) != 0) return LA_ERR_UNSUPPORTED;
     int bm = 0, bn = 0;
-    const int trc = la_get_tile_sizes(a->head_dim, esize, &bm, &bn);
+    const int trc = la_get_tile_sizes_ex(a->head_dim, esize, a->flags, &bm, &bn);
     if (trc != LA_OK) return trc;
     if (a->block_m != bm || a->block_n != bn) return LA_ERR_TILE_MISMATCH;
     if ((a->read_list == nullptr) != (a->write_list == nullptr)) return LA_ERR_LISTS;
@@ -132,10 +115,25 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     if (a->k_row_stride > 0x3fffffff || a->v_row_stride > 0x3fffffff) return LA_ERR_STRIDE;   // byte strides kept in int32
     if (!aligned16(a->q) || !aligned16(a->k) || !aligned16(a->v) || !aligned16(a->o)) return LA_ERR_STRIDE;
 
+    const bool varlen = a->cu_seqlens_q != nullptr || a->cu_seqlens_k != nullptr;
+    if (varlen) {                                                                        // flash_api.cpp:736-760
+        if (a->cu_seqlens_q == nullptr || a->cu_seqlens_k == nullptr) return LA_ERR_NULL_ARG;
+        if (a->read_list != nullptr || fp8) return LA_ERR_UNSUPPORTED;                    // dense bf16 only
+        if (a->total_q < 0 || a->q_tile_count != 0) return LA_ERR_SHAPE;
+    }
     if (a->seqlen_k == 0) {
-        // flash_api.cpp:1241-1245: empty K -> out = 0, lse = +inf. Done with memset-class kernels by the
-        // caller-visible contract; the Python layer handles it (no kernel here).
-        return LA_ERR_SHAPE;
+        // flash_api.cpp:1241-1245: no keys -> out = 0, lse = +inf (the write list, if any, is left as it is: nothing was
+        // walked). Varlen reaches here only when EVERY sequence is empty (seqlen_k is the maximum); rows then are total_q.
+        const hipError_t e0 = varlen
+            ? la::launch_empty_k_fill(static_cast<uint16_t*>(a->o), nullptr, 0, a->o_row_stride, a->o_head_stride, 1,
+                                      static_cast<int>(a->total_q), a->num_heads, a->head_dim_v, stream)
+            : la::launch_empty_k_fill(static_cast<uint16_t*>(a->o), a->lse, a->o_batch_stride, a->o_row_stride, a->o_head_stride,
+                                      a->batch, a->seqlen_q, a->num_heads, a->head_dim_v, stream);
+        hipError_t e1 = hipSuccess;
+        if (e0 == hipSuccess && varlen && a->lse != nullptr && a->total_q > 0)            // +inf = 0x7f800000 is not a memset byte pattern
+            e1 = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a->lse), 0x7f800000, static_cast<size_t>(a->total_q) * a->num_heads, stream);
+        if (e0 != hipSuccess || e1 != hipSuccess) { g_last_hip_error = static_cast<int>(e0 != hipSuccess ? e0 : e1); return LA_ERR_LAUNCH; }
+        return LA_OK;
     }
 
     la::FwdParams p{};
@@ -143,7 +141,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         const size_t tiles = la::fp8_workspace_bytes(a->batch, a->num_heads_k, (a->seqlen_k + bn - 1) / bn);
         if (a->workspace == nullptr || a->workspace_bytes < tiles + kSchedWorkspaceBytes || !aligned16(a->workspace))
             return LA_ERR_WORKSPACE;
-        if (a->read_list != nullptr && dynamic_sched_enabled() && !(a->flags & LA_FLAG_STATIC_SCHED))
+        if (a->read_list != nullptr && !(a->flags & LA_FLAG_STATIC_SCHED))
             p.work_counter = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(a->workspace) + tiles);
     }
     p.q = static_cast<const uint16_t*>(a->q);
@@ -168,7 +166,8 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     }
     p.scale_log2 = static_cast<float>(static_cast<double>(a->softmax_scale) * 1.4426950408889634);  // flash_api.cpp:125-126
     p.thr = a->thr;                                                                      // flash_api.cpp:930
-    p.rescale_tau = rescale_tau();
+    p.rescale_tau = (a->flags & LA_FLAG_EXACT_RESCALE) ? 0.0f : kRescaleTauBf16;
+    p.cu_seqlens_q = a->cu_seqlens_q; p.cu_seqlens_k = a->cu_seqlens_k; p.total_q = a->total_q;
     p.read_list = a->read_list;
     p.write_list = a->write_list;
     p.must_do_list = a->must_do_list;
@@ -178,12 +177,11 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     p.k_descale_batch_stride = a->k_descale_batch_stride; p.k_descale_head_stride = a->k_descale_head_stride;
     p.v_descale_batch_stride = a->v_descale_batch_stride; p.v_descale_head_stride = a->v_descale_head_stride;
 
-    if (la::fwd_lds_bytes_v2(a->head_dim, p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
+    if (!fp8 && la::fwd_lds_bytes_v2(a->head_dim, p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
     if (static_cast<int64_t>(p.batch) * p.num_heads * p.q_tiles > 0x7fffffffLL) return LA_ERR_SHAPE;
 
     if (fp8) {
-        if ((fp8_x64_kernel() ? la::fwd_lds_bytes_x64_fp8(p.k_tiles, nullptr) : la::fwd_lds_bytes_fp8(p.k_tiles, nullptr)) > 160 * 1024)
-            return LA_ERR_SEQLEN;
+        if (la::fwd_lds_bytes_x64_fp8(p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
         // 1) V -> pre-transposed, pre-swizzled V^T tiles in the caller's workspace; 2) forward on (Q, K, V^T)
         hipError_t e8 = hipSuccess;
         if (!(a->flags & LA_FLAG_V_PREPARED))
@@ -191,26 +189,23 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
                                        a->batch, a->seqlen_k, a->num_heads_k, p.k_tiles, stream);
         if (e8 == hipSuccess) {
             p.v = static_cast<const uint16_t*>(a->workspace);
-            e8 = fp8_x64_kernel() ? la::launch_fwd_fp8_d128_x64(p, a->read_list != nullptr, stream)
-                                  : la::launch_fwd_fp8_d128(p, a->read_list != nullptr, stream);
+            e8 = la::launch_fwd_fp8_d128_x64(p, a->read_list != nullptr, stream);
         }
         if (e8 != hipSuccess) { g_last_hip_error = static_cast<int>(e8); return LA_ERR_LAUNCH; }
         return LA_OK;
     }
-    // head_dim 128: x64 unless LA_FWD_KERNEL names an A/B variant (v2, asm); head_dim 64: v2.
+    // head_dim 128: the 256-row x64 kernel unless LA_FLAG_KERNEL_128ROW; head_dim 64 / 256: the 128-row v2 template.
     const bool skipable = a->read_list != nullptr;                                      // is_skipable, flash_api.cpp:931
-    const Bf16Kernel kern = a->head_dim == 128 ? bf16_d128_kernel() : Bf16Kernel::v2;
+    const bool x64 = a->head_dim == 128 && !uses_128row(a->head_dim, 2, a->flags);
     hipError_t err;
-    // optional workspace (la_fwd_workspace_bytes): with it, launches that walk lists use persistent workgroups and a
-    // ticket counter; without it, the static one-workgroup-per-item map (same results either way)
-    if (skipable && kern != Bf16Kernel::hand && a->workspace != nullptr && a->workspace_bytes >= kSchedWorkspaceBytes &&
-        aligned16(a->workspace) && dynamic_sched_enabled() && !(a->flags & LA_FLAG_STATIC_SCHED))
+    // optional workspace (la_fwd_workspace_bytes): with it, launches that walk lists use persistent workgroups and the
+    // ticket queues; without it, the static one-workgroup-per-item map (same results either way)
+    if (skipable && a->workspace != nullptr && a->workspace_bytes >= kSchedWorkspaceBytes && aligned16(a->workspace) &&
+        !(a->flags & LA_FLAG_STATIC_SCHED))
         p.work_counter = static_cast<unsigned*>(a->workspace);
-    if (kern == Bf16Kernel::x64) {
+    if (x64) {
         if (la::fwd_lds_bytes_x64(p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
         err = la::launch_fwd_bf16_d128_x64(p, skipable, stream);
-    } else if (kern == Bf16Kernel::hand) {
-        err = la::launch_fwd_bf16_d128_asm(p, skipable, stream);
     } else {
         err = la::launch_fwd_bf16_v2(p, a->head_dim, skipable, stream);
     }

@@ -3,6 +3,7 @@
 //  * skip_list_stats: number of listed tiles of a skip list, computed on the device. Replaces
 //    LiteAttention.calc_percentage (/root/reference/hopper/lite_attention.py:61-85), whose
 //    arithmetic is wrong; same input, corrected statistic.
+//  * empty_k_fill: o = 0, lse = +inf for a call with seqlen_k == 0 (flash_api.cpp:1241-1245), on strided o.
 //  * combine: LSE-weighted merge of partial outputs of K/V splits — the device counterpart of
 //    attention_combine_ref (/root/reference/hopper/tests/test_flash_attn.py:1178-1187) and of the
 //    reference's (compiled-out) FlashAttnFwdCombine kernel
@@ -45,6 +46,39 @@ hipError_t launch_skip_list_stats(const int32_t* list, int rows, int k_tiles, in
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(skip_list_stats_kernel, dim3(blocks), dim3(256), 0, stream, list, rows, k_tiles,
                        reinterpret_cast<unsigned long long*>(out));
+    return hipGetLastError();
+}
+
+// seqlen_k == 0: every output row is the empty sum. One thread = 8 consecutive d of one (b, s, h) row of the strided o.
+__global__ void __launch_bounds__(256) empty_k_fill_kernel(uint16_t* __restrict__ o, float* __restrict__ lse,
+                                                            int64_t o_batch_stride, int64_t o_row_stride, int64_t o_head_stride,
+                                                            int batch, int seqlen_q, int num_heads, int dv) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int chunks = dv / 8;
+    const int64_t total = static_cast<int64_t>(batch) * seqlen_q * num_heads * chunks;
+    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+         idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int ch = static_cast<int>(idx % chunks);
+        const int64_t row = idx / chunks;   // (b*S + s)*H + h
+        const int h = static_cast<int>(row % num_heads);
+        const int64_t bs = row / num_heads;
+        const int s_ = static_cast<int>(bs % seqlen_q);
+        const int b = static_cast<int>(bs / seqlen_q);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(o + b * o_batch_stride + s_ * o_row_stride + h * o_head_stride + ch * 8) = z;
+        if (lse != nullptr && ch == 0) lse[(static_cast<int64_t>(b) * num_heads + h) * seqlen_q + s_] = INFINITY;
+    }
+}
+
+hipError_t launch_empty_k_fill(uint16_t* o, float* lse, int64_t o_batch_stride, int64_t o_row_stride, int64_t o_head_stride,
+                               int batch, int seqlen_q, int num_heads, int head_dim_v, hipStream_t stream) {
+    const int64_t total = static_cast<int64_t>(batch) * seqlen_q * num_heads * (head_dim_v / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(empty_k_fill_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, o, lse, o_batch_stride,
+                       o_row_stride, o_head_stride, batch, seqlen_q, num_heads, head_dim_v);
     return hipGetLastError();
 }
 

@@ -40,7 +40,13 @@ struct ListReader {
     __device__ void init(const int* r) {
         row = r; len = r[0]; idx = 1; start = r[1]; end = r[2];
     }
-    __device__ void load() { start = row[idx]; end = row[idx + 1]; }
+    // the row is width + 1 ints; a pair past its end reads as (0, 0) = "matches nothing", which is what the zero padding of a
+    // shorter list gives (the reference reads past the row there, mainloop...:156-159 with len >= k_tiles - 1)
+    __device__ void load(int width) {
+        const bool in_row = idx + 1 <= width;
+        start = in_row ? row[idx] : 0;
+        end = in_row ? row[idx + 1] : 0;
+    }
     __device__ void advance() { idx += 2; }
     __device__ bool has_more() const { return idx <= len; }
 };
@@ -63,7 +69,7 @@ __device__ __noinline__ void write_skip_list(const int* seq, const unsigned* end
         const bool raw_skip = pos != 0 && !((doflags[pos >> 5] >> (pos & 31)) & 1u);
         bool skip = raw_skip;
         if (has_md && skip) {                                            // record_transition :154-162
-            if (md.end > n && md.has_more()) { md.advance(); md.load(); }
+            if (md.end > n && md.has_more()) { md.advance(); md.load(k_tiles); }
             const bool must_do = n <= md.start && n > md.end;
             skip = skip && !must_do;
         }
@@ -133,6 +139,20 @@ __device__ __forceinline__ void write_skip_list_wave(const int* seq, const unsig
         carry_skip = __shfl(after, 63);
     }
     if (lane == 0) write_row[0] = min(w - 1, k_tiles);
+}
+
+// o = 0, lse = +inf for `nrows` query rows of one (sequence, head) that has no keys (flash_api.cpp:1241-1245), by the whole
+// workgroup. Varlen launches only: a fixed-length call with seqlen_k == 0 never reaches a forward kernel (la_api.hip).
+__device__ __forceinline__ void store_empty_rows(const FwdParams& p, const SeqView& sv, int h, int row0, int nrows, int head_dim,
+                                                 int tid, int nthreads) {
+    const int chunks = head_dim / 8;
+    const int rows = min(nrows, sv.seqlen_q - row0);
+    for (int i = tid; i < rows * chunks; i += nthreads) {
+        const int r = row0 + i / chunks, ch = i % chunks;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(p.o + sv.o_off + static_cast<int64_t>(r) * p.o_row_stride + h * p.o_head_stride + ch * 8) = z;
+        if (p.lse != nullptr && ch == 0) sv.lse_row0[r] = INFINITY;
+    }
 }
 
 // XCD-aware (bijective) block -> virtual work id. Blocks b%8 share an XCD/L2 (observed dispatch rule; used for

@@ -38,7 +38,35 @@ struct FwdParams {
     int64_t q_descale_batch_stride, q_descale_head_stride;
     int64_t k_descale_batch_stride, k_descale_head_stride;
     int64_t v_descale_batch_stride, v_descale_head_stride;
+    // variable-length batches (dense only): device prefix sums int32[batch + 1]; seqlen_q / seqlen_k / q_tiles / k_tiles above are
+    // then the MAXIMA over the batch, lse is (H, total_q). nullptr = fixed length.
+    const int* cu_seqlens_q;
+    const int* cu_seqlens_k;
+    int64_t total_q;
 };
+
+// Per-item view of the problem: fixed length = the launch-wide sizes; varlen = sequence b's own rows (la_fwd_args.cu_seqlens_*).
+struct SeqView {
+    int seqlen_q, seqlen_k, k_tiles;
+    int64_t q_off, k_off, v_off, o_off;   // element offsets of the sequence's first row in q / k / v / o
+    float* lse_row0;                      // &lse[row 0 of this (batch, head)] (may be derived from nullptr: check p.lse)
+};
+__device__ __forceinline__ SeqView seq_view(const FwdParams& p, int b, int h, int block_n) {
+    SeqView s;
+    if (p.cu_seqlens_q == nullptr) {
+        s.seqlen_q = p.seqlen_q; s.seqlen_k = p.seqlen_k; s.k_tiles = p.k_tiles;
+        s.q_off = b * p.q_batch_stride; s.k_off = b * p.k_batch_stride; s.v_off = b * p.v_batch_stride; s.o_off = b * p.o_batch_stride;
+        s.lse_row0 = p.lse + (static_cast<int64_t>(b) * p.num_heads + h) * p.seqlen_q;
+    } else {
+        const int q0 = p.cu_seqlens_q[b], k0 = p.cu_seqlens_k[b];
+        s.seqlen_q = min(max(p.cu_seqlens_q[b + 1] - q0, 0), p.seqlen_q);
+        s.seqlen_k = min(max(p.cu_seqlens_k[b + 1] - k0, 0), p.seqlen_k);
+        s.k_tiles = (s.seqlen_k + block_n - 1) / block_n;
+        s.q_off = q0 * p.q_row_stride; s.k_off = k0 * p.k_row_stride; s.v_off = k0 * p.v_row_stride; s.o_off = q0 * p.o_row_stride;
+        s.lse_row0 = p.lse + static_cast<int64_t>(h) * p.total_q + q0;
+    }
+    return s;
+}
 
 // Dynamic work distribution: zero the ticket counter on `stream` and return the persistent grid (workgroups per CU x CUs,
 // capped by the number of items). work_counter == nullptr -> static: one workgroup per item.
@@ -55,18 +83,16 @@ inline hipError_t prepare_work_queue(FwdParams& p, bool skipable, int total, int
 }
 
 size_t fwd_lds_bytes_v2(int head_dim, int k_tiles, int* seq_cap_out);
-hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, hipStream_t stream);   // v2: LDS-DMA, pipelined; head_dim 128 / 64
-size_t fwd_lds_bytes_asm(int k_tiles, int* seq_cap_out);
-hipError_t launch_fwd_bf16_d128_asm(const FwdParams& p, bool skipable, hipStream_t stream);  // v2 with a hand-scheduled main loop
+hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, hipStream_t stream);   // 128-row template: head_dim 64 / 256, and 128 as the A/B kernel
 size_t fwd_lds_bytes_x64(int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_d128_x64(const FwdParams& p, bool skipable, hipStream_t stream);  // 1 wave/SIMD, 64 rows/wave, q-tile 256
-size_t fwd_lds_bytes_fp8(int k_tiles, int* seq_cap_out);
 size_t fwd_lds_bytes_x64_fp8(int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_fp8_d128_x64(const FwdParams& p, bool skipable, hipStream_t stream);   // 1 wave/SIMD, 64 rows/wave; p.v = V^T workspace
 size_t fp8_workspace_bytes(int batch, int num_heads_k, int k_tiles);
 hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_row_stride, int64_t v_head_stride,
                              void* vt, int batch, int seqlen_k, int num_heads_k, int k_tiles, hipStream_t stream);
-hipError_t launch_fwd_fp8_d128(const FwdParams& p, bool skipable, hipStream_t stream);   // p.v = V^T workspace
+hipError_t launch_empty_k_fill(uint16_t* o, float* lse, int64_t o_batch_stride, int64_t o_row_stride, int64_t o_head_stride,
+                               int batch, int seqlen_q, int num_heads, int head_dim_v, hipStream_t stream);
 hipError_t launch_skip_list_stats(const int32_t* list, int rows, int k_tiles, int64_t* out, hipStream_t stream);
 hipError_t launch_combine(const void* o_partial, bool partial_is_bf16, const float* lse_partial, uint16_t* o,
                           float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v,

@@ -131,8 +131,7 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     is_fp8 = q.dtype == torch.float8_e4m3fn
     if k.dtype != q.dtype or v.dtype != q.dtype:
         raise RuntimeError("query and key must have the same dtype")                              # :718-719
-    for name, val in (("k_new", k_new), ("v_new", v_new), ("q_v", q_v), ("cu_seqlens_q", cu_seqlens_q),
-                      ("cu_seqlens_k", cu_seqlens_k), ("cu_seqlens_k_new", cu_seqlens_k_new),
+    for name, val in (("k_new", k_new), ("v_new", v_new), ("q_v", q_v), ("cu_seqlens_k_new", cu_seqlens_k_new),
                       ("seqused_q", seqused_q), ("seqused_k", seqused_k), ("page_table", page_table),
                       ("kv_batch_idx", kv_batch_idx), ("leftpad_k", leftpad_k), ("rotary_cos", rotary_cos),
                       ("rotary_sin", rotary_sin), ("seqlens_rotary", seqlens_rotary),
@@ -149,6 +148,9 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
         raise NotImplementedError("split-KV is compiled out (hopper/setup.py:48)")
     if pack_gqa:
         raise NotImplementedError("pack_gqa is compiled out (hopper/setup.py:53)")
+    if cu_seqlens_q is not None or cu_seqlens_k is not None:
+        return _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, q_descale, k_descale,
+                               v_descale, softmax_scale, attn_read_list, attn_write_list)
     if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
         raise RuntimeError("q, k, v must be 4D tensors (batch, seqlen, nheads, headdim)")
     if q.stride(-1) != 1 or k.stride(-1) != 1 or v.stride(-1) != 1:
@@ -206,11 +208,6 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     softmax_lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)                  # :887-892
     empty = torch.empty(0, dtype=torch.float32, device=q.device)
 
-    if Sk == 0:                                                                                   # :1241-1245
-        out.zero_()
-        softmax_lse.fill_(float("inf"))
-        return out, softmax_lse, empty, empty
-
     read_ptr = _check_list(attn_read_list, "attn_read_list", q)
     write_ptr = _check_list(attn_write_list, "attn_write_list", q)
     if _must_do_is_1d and attn_must_do_list is not None:
@@ -254,12 +251,15 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     # caller-owned scratch (the C side allocates nothing): fp8 = the pre-transposed V tiles; bf16 with lists = the ticket
     # counter of the dynamic work distribution. Freed after the launch by the caching allocator's stream-ordered reuse.
     workspace = None
+    a.flags = (_cabi.default_flags() & ~(_cabi.LA_FLAG_KERNEL_128ROW if is_fp8 else 0)) | \
+              (_cabi.LA_FLAG_STATIC_SCHED if _static_sched is True else 0)
     need = _cabi.load().la_fwd_workspace_bytes(ctypes.byref(a))
     if need < 0:
         raise RuntimeError(f"lite_attention::fwd: {_cabi.status_string(int(need))}")
     if need > 0:
         workspace = torch.empty(int(need), dtype=torch.uint8, device=q.device)
         a.workspace, a.workspace_bytes = workspace.data_ptr(), int(need)
+    base_flags = _cabi.default_flags() & ~(_cabi.LA_FLAG_KERNEL_128ROW if is_fp8 else 0)
     windows = [(0, 0)] if _q_windows is None else [(int(b0), int(c0)) for b0, c0 in _q_windows]
     if _q_windows is not None and any(c0 <= 0 or b0 < 0 or b0 + c0 > q_tiles for b0, c0 in windows):
         raise RuntimeError(f"q-tile windows must lie inside [0, {q_tiles}) with positive counts; got {windows}")
@@ -267,7 +267,7 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     with torch.cuda.device(q.device):                                                             # CUDAGuard :885
         for i, (w_begin, w_count) in enumerate(windows):
             a.q_tile_begin, a.q_tile_count = w_begin, w_count
-            a.flags = (_cabi.LA_FLAG_V_PREPARED if (is_fp8 and i > 0) else 0) | \
+            a.flags = base_flags | (_cabi.LA_FLAG_V_PREPARED if (is_fp8 and i > 0) else 0) | \
                       (_cabi.LA_FLAG_STATIC_SCHED if (_static_sched is True or (_static_sched == "after_first" and i > 0))
                        else 0)                                                   # V^T tiles prepared by window 0
             stream = torch.cuda.current_stream(q.device).cuda_stream                              # :1219
@@ -281,6 +281,83 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
                 raise RuntimeError(f"lite_attention::fwd: {msg}")
             if _window_hook is not None:
                 _window_hook(i, out, w_begin * block_m, min(Sq, (w_begin + w_count) * block_m) if w_count else Sq)
+    return out, softmax_lse, empty, empty
+
+
+def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, q_descale, k_descale, v_descale,
+                    softmax_scale, attn_read_list, attn_write_list):
+    """Packed variable-length batches (flash_api.cpp:672-674, 736-760): q (total_q, H, D), k/v (total_k, Hk, D), cu_seqlens_*
+    int32 [B+1] on the device, max_seqlen_* size the grid. ONE launch, no host sync. Dense bf16 only. lse is (H, total_q)."""
+    if cu_seqlens_q is None or cu_seqlens_k is None:
+        raise RuntimeError("cu_seqlens_q and cu_seqlens_k must be given together")
+    if attn_read_list is not None or attn_write_list is not None:
+        raise NotImplementedError("skip lists with cu_seqlens: the reference's varlen entry point has none either "
+                                  "(hopper/_internal/flash_attn_interface.py:638-682)")
+    if q.dtype != torch.bfloat16 or q_descale is not None or k_descale is not None or v_descale is not None:
+        raise NotImplementedError("varlen is built for bf16 (fp8 needs a per-sequence V^T prepare pass)")
+    if q.dim() != 3 or k.dim() != 3 or v.dim() != 3:
+        raise RuntimeError("varlen: q, k, v must be 3D tensors (total_tokens, nheads, headdim)")
+    for name, cu in (("cu_seqlens_q", cu_seqlens_q), ("cu_seqlens_k", cu_seqlens_k)):
+        if cu.dtype != torch.int32 or cu.dim() != 1 or not cu.is_contiguous() or cu.device != q.device:
+            raise RuntimeError(f"{name} must be a contiguous int32 vector on the input device")              # :739-741
+    if cu_seqlens_q.numel() != cu_seqlens_k.numel() or cu_seqlens_q.numel() < 2:
+        raise RuntimeError("cu_seqlens_q and cu_seqlens_k must both have batch + 1 entries")
+    if max_seqlen_q is None or max_seqlen_k is None:
+        raise RuntimeError("max_seqlen_q and max_seqlen_k must be provided if cu_seqlens are provided")           # :744-746
+    if q.stride(-1) != 1 or k.stride(-1) != 1 or v.stride(-1) != 1:
+        raise RuntimeError("Input tensor must have contiguous last dimension")
+    Tq, H, D = q.shape
+    Tk, Hk, Dk = k.shape
+    if Dk != D or tuple(v.shape) != (Tk, Hk, D):
+        raise RuntimeError("k/v shape mismatch: expected k, v (total_k, nheads_k, headdim)")
+    if H % Hk != 0:
+        raise RuntimeError("Number of heads in key/value must divide number of heads in query")
+    if D % 8 != 0:
+        raise RuntimeError("head_size should be a multiple of 8")
+    if softmax_scale is None:
+        softmax_scale = D ** -0.5
+    B = cu_seqlens_q.numel() - 1
+    D_kernel = kernel_head_dim(D, 2)
+    if D_kernel != D:
+        pad = lambda t: torch.nn.functional.pad(t, (0, D_kernel - D))                                          # noqa: E731
+        res = _mha_fwd_varlen(pad(q), pad(k), pad(v), None, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, None,
+                              None, None, softmax_scale, None, None)
+        o = res[0][..., :D]
+        if out is not None:
+            out.copy_(o)
+            o = out
+        return (o, *res[1:])
+    if out is None:
+        out = torch.empty((Tq, H, D), dtype=torch.bfloat16, device=q.device)
+    elif out.dtype != torch.bfloat16 or tuple(out.shape) != (Tq, H, D) or out.stride(-1) != 1:
+        raise RuntimeError("out must be bf16 of shape (total_q, nheads, headdim) with contiguous last dimension")
+    softmax_lse = torch.empty((H, Tq), dtype=torch.float32, device=q.device)
+    empty = torch.empty(0, dtype=torch.float32, device=q.device)
+    if Tq == 0 or max_seqlen_q <= 0:
+        return out, softmax_lse, empty, empty
+    flags = _cabi.default_flags()
+    block_m, block_n = _cabi.get_tile_sizes(D, 2, flags)
+    a = _cabi.LaFwdArgs()
+    a.struct_size = ctypes.sizeof(_cabi.LaFwdArgs)
+    a.dtype = _cabi.LA_DTYPE_BF16
+    a.q, a.k, a.v, a.o, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), softmax_lse.data_ptr()
+    a.q_row_stride, a.q_head_stride = q.stride(0), q.stride(1)
+    a.k_row_stride, a.k_head_stride = k.stride(0), k.stride(1)
+    a.v_row_stride, a.v_head_stride = v.stride(0), v.stride(1)
+    a.o_row_stride, a.o_head_stride = out.stride(0), out.stride(1)
+    a.batch, a.seqlen_q, a.seqlen_k = B, int(max_seqlen_q), max(int(max_seqlen_k), 0)
+    a.num_heads, a.num_heads_k, a.head_dim, a.head_dim_v = H, Hk, D, D
+    a.softmax_scale = float(softmax_scale)
+    a.block_m, a.block_n = block_m, block_n
+    a.flags = flags & (_cabi.LA_FLAG_KERNEL_128ROW | _cabi.LA_FLAG_EXACT_RESCALE)
+    a.cu_seqlens_q, a.cu_seqlens_k, a.total_q = cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), Tq
+    with torch.cuda.device(q.device):
+        rc = _cabi.load().la_fwd(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
+    if rc != _cabi.LA_OK:
+        msg = _cabi.status_string(rc)
+        if rc == _cabi.LA_ERR_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        raise RuntimeError(f"lite_attention::fwd (varlen): {msg}")
     return out, softmax_lse, empty, empty
 
 

@@ -198,22 +198,34 @@ class LiteAttention:
         return 1.0 - self.calc_percentage(rl[: (rl.shape[0] if batch is None else batch)])
 
     def state_dict(self) -> dict:
+        """Everything a run needs to continue bit-identically: both ping-pong lists, the phase, the threshold and what the
+        lists were built for (shape key incl. the DEVICE they live on). Tensors are returned on the CPU."""
         key = self._shape_key
         return {
             "skip_list": None if self._skip_list is None else self._skip_list.detach().cpu().clone(),
             "phase": self._phase, "threshold": self.threshold, "enable_skipping": self.enable_skipping,
             "max_batch_size": self.max_batch_size,
             "shape_key": None if key is None else (*key[:4], str(key[4]).replace("torch.", "")),
+            "device": None if key is None else str(key[5]),
         }
 
     def load_state_dict(self, state: dict, device=None):
+        """Restore ``state_dict()``. The lists go back to the device they were saved from (``state["device"]``) unless
+        ``device`` names another one; a state that records no device (round-1 checkpoints) needs ``device=``. The next call
+        must present the same shapes / dtype / device, otherwise the lists are rebuilt as on any shape change (:179-200)."""
         self.threshold = state["threshold"]
         self.enable_skipping = state["enable_skipping"]
         self.max_batch_size = state["max_batch_size"]
         self.reset_skip_state()
         if state["skip_list"] is None:
             return
-        dev = torch.device(device) if device is not None else state["skip_list"].device
+        if device is None:
+            device = state.get("device")
+            if device is None:
+                raise ValueError("this state_dict records no device: pass load_state_dict(state, device=...)")
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())      # query.device always carries an index
         self._skip_list = state["skip_list"].to(dev).contiguous()
         self._phase = state["phase"]
         sq, sk, h, d, dt = state["shape_key"]

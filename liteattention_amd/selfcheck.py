@@ -1,0 +1,140 @@
+"""Workload construction and result verification shared by ``bench.py`` and the headline-shape GPU tests.
+
+Pure torch on the device that holds the tensors (no oracle, no CPU fallback): the imposed-sparsity read lists of
+SURVEY.md §8(d) and a sampled-row check of an attention result against a plain fp32 torch reference that applies the
+same block mask. The check is the gate on shapes the CPU oracle cannot finish (S = 75 600, H = 40): it looks at whole
+query rows, so a tile that was skipped, walked twice or masked wrongly shows up in the LSE (one 64-key tile of a
+43 k-key row moves it by 1.5e-3; the bound is 2e-4) and in O.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import torch
+
+
+# ----------------------------------------------------------------------------------------- imposed lists
+def banded_rows(q_tiles: int, k_tiles: int, block_m: int, block_n: int, sparsity: float) -> torch.Tensor:
+    """[q_tiles, 5] int32 list-row heads for the imposed-sparsity pattern (<= 2 ranges): every q-tile keeps the first
+    walked tile (k_tiles - 1) plus a contiguous band of round((1 - s) * k_tiles) - 1 key tiles centred on its diagonal."""
+    keep = max(1, round((1.0 - sparsity) * k_tiles))
+    rows = torch.zeros(q_tiles, 5, dtype=torch.int32)
+    for m in range(q_tiles):
+        if keep >= k_tiles:
+            rows[m, :3] = torch.tensor([2, k_tiles - 1, 0])
+            continue
+        centre = min(k_tiles - 1, (m * block_m + block_m // 2) // block_n)
+        band = keep - 1                                   # + the always-walked first tile k_tiles-1
+        lo = max(0, min(centre - band // 2, k_tiles - 1 - band))
+        hi = lo + band - 1
+        if band <= 0:
+            rows[m, :3] = torch.tensor([2, k_tiles - 1, k_tiles - 1])
+        elif hi >= k_tiles - 2:                           # band touches the first tile: one range
+            rows[m, :3] = torch.tensor([2, k_tiles - 1, lo])
+        else:
+            rows[m] = torch.tensor([4, k_tiles - 1, k_tiles - 1, hi, lo])
+    return rows
+
+
+def listed_tiles_of_rows(rows: torch.Tensor) -> int:
+    n = 0
+    for r in rows.tolist():
+        n += r[1] - r[2] + 1
+        if r[0] == 4:
+            n += r[3] - r[4] + 1
+    return n
+
+
+def impose_lists(att, rows: torch.Tensor):
+    """Overwrite BOTH ping-pong buffers of `att` with the same rows (fixed point under thr=-inf)."""
+    sl = att._skip_list
+    sl.zero_()
+    sl[..., :5] = rows.to(sl.device)[None, None, None]
+
+
+def executed_flops(rows: torch.Tensor, heads: int, batch: int, S: int, Sk: int, bm: int, bn: int, D: int) -> float:
+    """sum over listed tiles of 4*rows*cols*D with ragged edge tiles counted at their real size."""
+    k_tiles = -(-Sk // bn)
+    total = 0.0
+    last_cols = Sk - (k_tiles - 1) * bn
+    for m, r in enumerate(rows.tolist()):
+        nrows = min(bm, S - m * bm)
+        ranges = [(r[1], r[2])] + ([(r[3], r[4])] if r[0] == 4 else [])
+        cols = 0
+        for s, e in ranges:
+            cols += (s - e + 1) * bn
+            if s == k_tiles - 1:
+                cols -= bn - last_cols
+        total += 4.0 * nrows * cols * D
+    return total * heads * batch
+
+
+# ----------------------------------------------------------------------------------------- verification
+def listed_key_mask(list_row: Sequence[int], block_n: int, seqlen_k: int, device) -> torch.Tensor:
+    """bool[seqlen_k]: keys inside the tiles a skip-list row ``[L, start0, end0, ...]`` lists (ranges descending, both
+    ends inclusive; the first range is walked even when L == 0, mainloop_fwd_sm90_tma_gmma_ws.hpp:93-101)."""
+    mask = torch.zeros(seqlen_k, dtype=torch.bool, device=device)
+    n = max(int(list_row[0]), 2)
+    for i in range(1, n, 2):
+        s, e = int(list_row[i]), int(list_row[i + 1])
+        if s >= e:
+            mask[e * block_n: min((s + 1) * block_n, seqlen_k)] = True
+    return mask
+
+
+def sample_rows(seqlen_q: int, n: int, block_m: int, seed: int = 1) -> torch.Tensor:
+    """n distinct query rows: the first and last rows of the tensor, one row either side of every q-tile boundary near the
+    ends (the zero-padded last q-tile, the first q-tile) and uniformly random rows for the rest."""
+    fixed = {0, seqlen_q - 1, min(block_m - 1, seqlen_q - 1), min(block_m, seqlen_q - 1),
+             max(0, (seqlen_q - 1) // block_m * block_m - 1), (seqlen_q - 1) // block_m * block_m}
+    g = torch.Generator().manual_seed(seed)
+    rand = torch.randperm(seqlen_q, generator=g)[: max(0, n)].tolist()
+    rows = sorted(fixed | set(rand[: max(0, n - len(fixed))]))
+    return torch.tensor(rows, dtype=torch.long)
+
+
+@torch.no_grad()
+def sampled_row_check(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, lse: Optional[torch.Tensor],
+                      read_list: Optional[torch.Tensor], block_m: int, block_n: int, heads: Iterable[int],
+                      n_rows: int = 256, batch: int = 0, softmax_scale: Optional[float] = None,
+                      o_rtol: float = 2.0 ** -8, o_atol: float = 1e-4, lse_atol: float = 2e-4, seed: int = 1) -> Dict:
+    """Compare ``n_rows`` sampled query rows of every head in ``heads`` with a plain fp32 torch attention over exactly the
+    keys the row's q-tile lists in ``read_list`` ([B, H, Qt, Kt+1]; None = dense).
+
+    q (B,S,H,D) / k, v (B,Sk,Hk,D) bf16 or e4m3 (upcast to fp32 as they are: descales must be 1), out (B,S,H,D), lse (B,H,S).
+    Bounds: |O - ref| <= o_rtol * max|ref| + o_atol per head, |LSE - ref| <= lse_atol. Returns
+    ``{"rows", "max_err", "max_err_lse", "tol", "ok"}`` (max over heads; "rows" = rows compared in total)."""
+    B, S, H, D = q.shape
+    Sk, Hk = k.shape[1], k.shape[2]
+    scale = D ** -0.5 if softmax_scale is None else softmax_scale
+    rows = sample_rows(S, n_rows, block_m, seed).to(q.device)
+    tiles = (rows // block_m).tolist()
+    res = {"rows": 0, "max_err": 0.0, "max_err_lse": 0.0, "tol": 0.0, "ok": True}
+    for h in heads:
+        hk = h // (H // Hk)
+        kf, vf = k[batch, :, hk].float(), v[batch, :, hk].float()
+        s = (q[batch, rows, h].float() @ kf.T) * scale                      # [n, Sk] fp32
+        if read_list is not None:
+            lists_h = read_list[batch, h].cpu()
+            masks: Dict[int, torch.Tensor] = {}
+            for i, m in enumerate(tiles):
+                if m not in masks:
+                    masks[m] = listed_key_mask(lists_h[m].tolist(), block_n, Sk, q.device)
+                s[i].masked_fill_(~masks[m], float("-inf"))
+        ref_lse = torch.logsumexp(s, dim=-1)
+        ref_o = torch.softmax(s, dim=-1) @ vf
+        err = (out[batch, rows, h].float() - ref_o).abs().max().item()
+        tol = o_rtol * ref_o.abs().max().item() + o_atol
+        res["max_err"] = max(res["max_err"], err)
+        res["tol"] = max(res["tol"], tol)
+        ok = err <= tol
+        if lse is not None:
+            err_l = (lse[batch, h, rows] - ref_lse).abs().max().item()
+            res["max_err_lse"] = max(res["max_err_lse"], err_l)
+            ok = ok and err_l <= lse_atol
+        res["ok"] = res["ok"] and bool(ok)
+        res["rows"] += int(rows.numel())
+    res["max_err"] = float(f"{res['max_err']:.3e}")
+    res["max_err_lse"] = float(f"{res['max_err_lse']:.3e}")
+    res["tol"] = float(f"{res['tol']:.3e}")
+    return res

@@ -121,6 +121,59 @@ def test_argument_validation_returns_codes_without_launching():
     assert lib.la_combine(None, 0, None, None, None, 1, 1, 1, 1, 128, None) == _cabi.LA_ERR_NULL_ARG
 
 
+def test_kernel_selection_is_an_argument_not_process_state():
+    """ABI 4: the 128-row A/B kernel is chosen by LA_FLAG_KERNEL_128ROW (tile sizes follow through la_get_tile_sizes_ex);
+    the C library reads no environment variable — the header promises no global state."""
+    lib = _cabi.load()
+    m, n = ctypes.c_int(), ctypes.c_int()
+    assert lib.la_get_tile_sizes_ex(128, 2, 0, ctypes.byref(m), ctypes.byref(n)) == 0 and (m.value, n.value) == (256, 64)
+    assert lib.la_get_tile_sizes_ex(128, 2, _cabi.LA_FLAG_KERNEL_128ROW, ctypes.byref(m), ctypes.byref(n)) == 0
+    assert (m.value, n.value) == (128, 64)
+    assert lib.la_get_tile_sizes_ex(64, 2, _cabi.LA_FLAG_KERNEL_128ROW, ctypes.byref(m), ctypes.byref(n)) == 0 and m.value == 128
+    assert lib.la_get_tile_sizes_ex(128, 1, _cabi.LA_FLAG_KERNEL_128ROW, ctypes.byref(m), ctypes.byref(n)) == _cabi.LA_ERR_UNSUPPORTED
+    assert lib.la_get_tile_sizes_ex(128, 2, 0x100, ctypes.byref(m), ctypes.byref(n)) == _cabi.LA_ERR_UNSUPPORTED
+    a = _cabi.LaFwdArgs()
+    a.struct_size = ctypes.sizeof(_cabi.LaFwdArgs)
+    a.q = a.k = a.v = a.o = 0x1000
+    a.batch, a.seqlen_q, a.seqlen_k, a.num_heads, a.num_heads_k, a.head_dim, a.head_dim_v = 1, 256, 256, 4, 4, 128, 128
+    a.block_m, a.block_n = 256, 64
+    a.flags = _cabi.LA_FLAG_KERNEL_128ROW
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_TILE_MISMATCH       # lists of this launch use 128-row q-tiles
+    csrc = os.path.join(ROOT, "liteattention_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+    env = dict(os.environ, LA_FWD_KERNEL="v2")                                    # the HOST layer's default flags follow the env
+    code = ("import sys; sys.path.insert(0, %r)\nfrom liteattention_amd import _cabi\n"
+            "assert _cabi.default_flags() == _cabi.LA_FLAG_KERNEL_128ROW and _cabi.get_tile_sizes(128, 2) == (128, 64)\n"
+            "assert _cabi.get_tile_sizes(128, 1) == (256, 64)\n" % ROOT)
+    assert subprocess.run([sys.executable, "-c", code], env=env).returncode == 0
+
+
+def test_varlen_argument_validation():
+    """cu_seqlens (ABI 4): both or neither; dense bf16 only; no q-tile window. All rejected before any HIP call."""
+    lib = _cabi.load()
+    a = _cabi.LaFwdArgs()
+    a.struct_size = ctypes.sizeof(_cabi.LaFwdArgs)
+    a.q = a.k = a.v = a.o = 0x1000
+    a.batch, a.seqlen_q, a.seqlen_k, a.num_heads, a.num_heads_k, a.head_dim, a.head_dim_v = 3, 300, 512, 4, 4, 128, 128
+    a.block_m, a.block_n = 256, 64
+    a.q_row_stride = a.k_row_stride = a.v_row_stride = a.o_row_stride = 4 * 128
+    a.q_head_stride = a.k_head_stride = a.v_head_stride = a.o_head_stride = 128
+    a.cu_seqlens_q = 0x4000
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_NULL_ARG            # cu_seqlens_k missing
+    a.cu_seqlens_k = 0x5000
+    a.total_q = 889
+    a.read_list, a.write_list = 0x2000, 0x3000
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_UNSUPPORTED         # no skip lists with varlen
+    a.read_list = a.write_list = None
+    a.q_tile_count = 1
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_SHAPE               # no q-tile windows with varlen
+    a.q_tile_count = 0
+    a.total_q = -1
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_SHAPE
+
+
 def test_missing_library_fails_loudly(tmp_path):
     """The product must not fall back to anything when the HIP extension is absent: import raises."""
     code = "import sys; sys.path.insert(0, %r)\nimport liteattention_amd\n" % ROOT
