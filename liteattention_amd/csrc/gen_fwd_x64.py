@@ -86,6 +86,7 @@ TBS, VBS, RAGS = [S_TB, S_TB2], [S_VB, S_VB2], [S_RAG, S_RAG2]
 
 KV_TILE = 16384
 V_REGION = 32768
+DMA_BIAS = 3072           # S_KBASE / S_VBASE hold (tensor base - DMA_BIAS); LK / LV[j] hold (+DMA_BIAS - 1024 j): see dma_ops
 
 out = []          # IR: str | ("LDS", str, tag) | ("WAIT", tag) | ("DRAIN",)
 
@@ -396,7 +397,10 @@ def dma_bases(n_k, n_v, st=0):
 
 def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True, st=0):
     """[m0K, K0..K3, m0V, V0..V3]: one M0 per tensor, the piece index rides on the instruction offset (applied to both the
-    global and the LDS address; LK/LV are pre-compensated by -1024*j)."""
+    global and the LDS address). The global side is compensated in the per-lane offsets: LK/LV[j] carry +(3072 - 1024*j) and
+    the tensor bases in S_KBASE / S_VBASE carry -3072 (DMA_BIAS), so every per-lane offset is >= 0 — the VGPR of the SADDR form
+    is an UNSIGNED 32-bit offset, and with plain -1024*j a row clamped to a short sequence (seqlen_k < 13 rows at one head)
+    went negative = +4 GiB (found by the varlen tests: a 1-key sequence faulted)."""
     if "nodma" in OPT:
         return []
     o = []
@@ -428,6 +432,8 @@ def dma_ragged(n_sgpr, is_k, buf_imm):
         emit(f"v_add_co_u32 {v(T[4])}, vcc, {s(base)}, {v(T[4])}")
         emit(f"v_mov_b32 {v(T[6])}, {s(base + 1)}")
         emit(f"v_addc_co_u32 {v(T[5])}, vcc, {v(T[5])}, {v(T[6])}, vcc")
+        emit(f"v_add_co_u32 {v(T[4])}, vcc, {DMA_BIAS}, {v(T[4])}")      # the bases carry -DMA_BIAS
+        emit(f"v_addc_co_u32 {v(T[5])}, vcc, 0, {v(T[5])}, vcc")
         emit(f"s_add_u32 m0, {s(S_DMAW)}, {region + buf_imm + j * 1024}")
         emit("s_nop 0")
         emit(f"global_load_lds_dwordx4 {vr(T[4], 2)}, off")
@@ -633,6 +639,9 @@ def prologue():
     for idx, sg in enumerate(plist):
         emit(f"v_readfirstlane_b32 {s(sg)}, {v(idx)}")
     emit("s_nop 4")
+    for base in (S_KBASE, S_VBASE):                            # DMA_BIAS, see dma_ops
+        emit(f"s_sub_u32 {s(base)}, {s(base)}, {DMA_BIAS}")
+        emit(f"s_subb_u32 {s(base + 1)}, {s(base + 1)}, 0")
     emit(f"s_mov_b32 {s(S_CC)}, {s(S_C)}")
     emit(f"s_mov_b32 {s(S_CC + 1)}, {s(S_C)}")
     emit(f"s_sub_u32 {s(S_NM1)}, {s(S_NTILES)}, 1")
@@ -679,7 +688,7 @@ def prologue():
     emit(f"v_lshlrev_b32 {v(RAGV)}, 4, {v(RAGV)}")            # (cpos ^ (rip<<2)) << 4
     emit(f"s_mov_b32 {s(S_T1)}, {s(S_LASTROW)}")              # seqlen_k < 64: rows of the only tile stay inside the tensor
     for j in range(4):
-        # LK[j] = (16w + 4j + rip)*k_rs + (RAGK ^ (j<<6)) - 1024j ; LV[j] = (16w + 4j + rip)*v_rs + RAGV - 1024j
+        # LK[j] = (16w + 4j + rip)*k_rs + (RAGK ^ (j<<6)) + 3072 - 1024j ; LV[j] = (16w + 4j + rip)*v_rs + RAGV + 3072 - 1024j
         emit(f"v_add_u32 {v(T[4])}, {4 * j}, {v(RIPROW)}")
         emit(f"v_min_i32 {v(T[4])}, {v(T[4])}, {s(S_T1)}")
         emit(f"v_mul_lo_u32 {v(LK[j])}, {v(T[4])}, {s(S_KRS)}")
@@ -687,9 +696,9 @@ def prologue():
         emit(f"v_add_u32 {v(LK[j])}, {v(LK[j])}, {v(T[5])}")
         emit(f"v_mul_lo_u32 {v(LV[j])}, {v(T[4])}, {s(S_VRS)}")
         emit(f"v_add_u32 {v(LV[j])}, {v(LV[j])}, {v(RAGV)}")
-        if j:
-            emit(f"v_subrev_u32 {v(LK[j])}, {1024 * j}, {v(LK[j])}")
-            emit(f"v_subrev_u32 {v(LV[j])}, {1024 * j}, {v(LV[j])}")
+        if DMA_BIAS - 1024 * j:
+            emit(f"v_add_u32 {v(LK[j])}, {DMA_BIAS - 1024 * j}, {v(LK[j])}")
+            emit(f"v_add_u32 {v(LV[j])}, {DMA_BIAS - 1024 * j}, {v(LV[j])}")
 
     emit("; ---- Q fragments -> AGPRs: row q_row0 + 64*wave + 32*qb + l31, d = 16*ks + 8*hh; rows past seqlen_q are ZERO rows")
     emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 6")

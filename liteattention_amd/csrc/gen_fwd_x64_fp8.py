@@ -358,7 +358,9 @@ def dma_bases(n_k, n_v, st=0):
 
 def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True, st=0):
     """[m0K, K0, K1, m0V, V0, V1]: one M0 per tensor, the piece index rides on the instruction offset (applied to the global
-    and the LDS address alike; LK[j] is pre-compensated by -1024 j, LV is the same for both pieces)."""
+    and the LDS address alike). K: the per-lane offsets LK[j] carry +(1024 - 1024 j) and S_KBASE carries -1024, so they stay
+    >= 0 when rows are clamped to a short sequence (the SADDR form's VGPR is an UNSIGNED 32-bit offset; see gen_fwd_x64.py
+    dma_ops). V^T: LV is the same for both pieces (the prepared tile is copied linearly)."""
     o = []
     if do_k:
         o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {kbuf_imm}")
@@ -499,6 +501,8 @@ def prologue():
     for idx, sg in enumerate(plist):
         emit(f"v_readfirstlane_b32 {s(sg)}, {v(idx)}")
     emit("s_nop 4")
+    emit(f"s_sub_u32 {s(S_KBASE)}, {s(S_KBASE)}, 1024")         # bias of the K DMA lane offsets, see dma_ops
+    emit(f"s_subb_u32 {s(S_KBASE + 1)}, {s(S_KBASE + 1)}, 0")
     emit(f"s_sub_u32 {s(S_NM1)}, {s(S_NTILES)}, 1")
     emit(f"s_sub_u32 {s(S_SAFEROW)}, {s(S_LASTROW)}, 63")
     emit(f"s_max_i32 {s(S_SAFEROW)}, {s(S_SAFEROW)}, 0")
@@ -546,8 +550,8 @@ def prologue():
         emit(f"v_min_i32 {v(T[4])}, {v(T[4])}, {s(S_LASTROW)}")   # seqlen_k < 64: rows of the only tile stay inside K
         emit(f"v_mul_lo_u32 {v(LK[j])}, {v(T[4])}, {s(S_KRS)}")
         emit(f"v_lshl_add_u32 {v(LK[j])}, {v(T[5])}, 4, {v(LK[j])}")
-        if j:
-            emit(f"v_subrev_u32 {v(LK[j])}, {1024 * j}, {v(LK[j])}")
+        if not j:
+            emit(f"v_add_u32 {v(LK[j])}, 1024, {v(LK[j])}")            # +1024 - 1024 j; S_KBASE carries -1024
     emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 11")
     emit(f"v_lshl_add_u32 {v(LV)}, {v(LANE)}, 4, {s(S_T0)}")  # 2048 w + 16 lane: linear copy of the prepared tile
 

@@ -90,7 +90,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     if (a->dtype != LA_DTYPE_BF16 && a->dtype != LA_DTYPE_FP8_E4M3) return LA_ERR_DTYPE;   // flash_api.cpp:715
     const bool fp8 = a->dtype == LA_DTYPE_FP8_E4M3;
     const int esize = fp8 ? 1 : 2;
-    if (!a->q || !a->k || !a->v || !a->o) return LA_ERR_NULL_ARG;
+    if (!a->q || !a->o || ((!a->k || !a->v) && a->seqlen_k != 0)) return LA_ERR_NULL_ARG;   // empty K/V tensors may be NULL
     if (a->batch <= 0 || a->seqlen_q <= 0 || a->seqlen_k < 0 || a->num_heads <= 0 || a->num_heads_k <= 0 ||
         a->head_dim <= 0 || a->head_dim_v <= 0)
         return LA_ERR_SHAPE;                                                             // flash_api.cpp:776-778

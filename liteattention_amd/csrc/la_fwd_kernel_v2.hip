@@ -120,17 +120,25 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
     }
     const int h = bh % p.num_heads;
     const int b = bh / p.num_heads;
-    const SeqView sv = seq_view(p, b, h, BN);          // fixed length: the launch-wide sizes; varlen (dense only): sequence b's
-    const int k_tiles = sv.k_tiles;
-    const int hk = h / p.h_ratio;                      // K/V head (GQA/MQA: h_ratio query heads share one)
-    const int64_t list_off = (static_cast<int64_t>(bh) * p.q_tiles + m_block) * (p.k_tiles + 1);
-    if (!SKIPABLE && p.cu_seqlens_q != nullptr) {      // varlen: q-tiles past this sequence's end; sequences without keys
-        if (m_block * BM >= sv.seqlen_q) return;
-        if (k_tiles == 0) {
-            store_empty_rows(p, sv, h, m_block * BM, BM, D, tid, 256);
-            return;
+    // Per-item view of the problem. Fixed length: the launch-wide sizes. Varlen (la_fwd_args.cu_seqlens_*; dense launches only,
+    // so the SKIPABLE instantiation keeps the plain form): sequence b's own rows and lengths.
+    int seqlen_q = p.seqlen_q, seqlen_k = p.seqlen_k, k_tiles = p.k_tiles;
+    int64_t q_off = b * p.q_batch_stride, k_off = b * p.k_batch_stride, v_off = b * p.v_batch_stride, o_off = b * p.o_batch_stride;
+    float* lse_row0 = p.lse + static_cast<int64_t>(bh) * p.seqlen_q;
+    if constexpr (!SKIPABLE) {
+        if (p.cu_seqlens_q != nullptr) {
+            const SeqView sv = seq_view(p, b, h, BN);
+            if (m_block * BM >= sv.seqlen_q) return;           // q-tiles past this sequence's end
+            if (sv.k_tiles == 0) {                             // a sequence without keys: o = 0, lse = +inf
+                store_empty_rows(p, sv, h, m_block * BM, BM, D, tid, 256);
+                return;
+            }
+            seqlen_q = sv.seqlen_q; seqlen_k = sv.seqlen_k; k_tiles = sv.k_tiles;
+            q_off = sv.q_off; k_off = sv.k_off; v_off = sv.v_off; o_off = sv.o_off; lse_row0 = sv.lse_row0;
         }
     }
+    const int hk = h / p.h_ratio;                      // K/V head (GQA/MQA: h_ratio query heads share one)
+    const int64_t list_off = (static_cast<int64_t>(bh) * p.q_tiles + m_block) * (p.k_tiles + 1);
 
     if (SKIPABLE) {
         for (int i = tid; i < 2 * ((k_tiles + 31) / 32); i += 256) doflags[i] = 0u;   // doflags + endflags
@@ -145,9 +153,9 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
     const int q_row = m_block * BM + wave * 32 + l31;
     bf16x8 qf[KS];
     {
-        const uint16_t* qp = p.q + sv.q_off + static_cast<int64_t>(q_row) * p.q_row_stride +
+        const uint16_t* qp = p.q + q_off + static_cast<int64_t>(q_row) * p.q_row_stride +
                              h * p.q_head_stride + hh * 8;
-        const bool ok = q_row < sv.seqlen_q;   // rows past seqlen_q are ZERO rows (TMA OOB fill in the reference)
+        const bool ok = q_row < seqlen_q;   // rows past seqlen_q are ZERO rows (TMA OOB fill in the reference)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             u32x4 t = {0u, 0u, 0u, 0u};
@@ -160,8 +168,8 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
     // 16w .. 16w+15 = pieces PPW*w .. PPW*w+PPW-1. Lane: row rip = lane / CPR inside the piece, LDS chunk
     // position cpos = lane % CPR. The DMA image is lane-linear, so the swizzles go on the SOURCE address:
     // LDS position c' of row r holds data chunk c' ^ swz(r).
-    const unsigned char* const kg = reinterpret_cast<const unsigned char*>(p.k + sv.k_off + hk * p.k_head_stride);
-    const unsigned char* const vg = reinterpret_cast<const unsigned char*>(p.v + sv.v_off + hk * p.v_head_stride);
+    const unsigned char* const kg = reinterpret_cast<const unsigned char*>(p.k + k_off + hk * p.k_head_stride);
+    const unsigned char* const vg = reinterpret_cast<const unsigned char*>(p.v + v_off + hk * p.v_head_stride);
     const int k_rs = static_cast<int>(p.k_row_stride * 2), v_rs = static_cast<int>(p.v_row_stride * 2);   // bytes (< 2^31, checked on the host)
     const int rip = lane / CPR;
     const int cpos = lane % CPR;
@@ -169,7 +177,7 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
     // so piece j XORs (4j << 4) into the byte offset; V: swz(RPP*j + rip) = swz(rip).
     const int k_lane = rip * k_rs + ((cpos ^ k_swz<D>(rip)) << 4);
     const int v_lane = rip * v_rs + ((cpos ^ v_swz<D>(rip)) << 4);
-    const int last_row = sv.seqlen_k - 1;
+    const int last_row = seqlen_k - 1;
     auto dma_tile = [&](int n, int kbuf, bool do_k, int vbuf, bool do_v) {
         const int row_w = n * BN + 16 * wave;                               // wave-uniform first row of this wave's slice
         if (__builtin_expect(row_w + 15 <= last_row, 1)) {
@@ -228,7 +236,7 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
 
     const float c = p.scale_log2;
     const float thr = p.thr;
-    const int tail_valid = sv.seqlen_k - (k_tiles - 1) * BN;   // valid keys in tile k_tiles-1 (1..64)
+    const int tail_valid = seqlen_k - (k_tiles - 1) * BN;   // valid keys in tile k_tiles-1 (1..64)
     unsigned domask = 1u;                                     // wave-uniform "do" bits of 32 consecutive positions; position 0 is never flagged
     float l_run = 0.f;
     f32x16 o_acc[DB];
@@ -382,8 +390,8 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
     const float l_tot = half_swap_sum(l_run);
     const bool bad = (l_tot == 0.f) || (l_tot != l_tot);
     const float inv = bad ? 0.f : 1.f / l_tot;
-    if (q_row < sv.seqlen_q) {
-        uint16_t* op = p.o + sv.o_off + static_cast<int64_t>(q_row) * p.o_row_stride + h * p.o_head_stride;
+    if (q_row < seqlen_q) {
+        uint16_t* op = p.o + o_off + static_cast<int64_t>(q_row) * p.o_row_stride + h * p.o_head_stride;
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
 #pragma unroll
@@ -396,7 +404,7 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
             }
         }
         if (p.lse != nullptr && hh == 0) {
-            sv.lse_row0[q_row] =
+            lse_row0[q_row] =
                 bad ? -INFINITY : m_run * (c * 0.69314718055994530942f) + __logf(l_tot);
         }
     }

@@ -45,7 +45,7 @@ struct FwdParams {
     int64_t total_q;
 };
 
-// Per-item view of the problem: fixed length = the launch-wide sizes; varlen = sequence b's own rows (la_fwd_args.cu_seqlens_*).
+// Varlen launches (la_fwd_args.cu_seqlens_*): sequence b's own rows and lengths.
 struct SeqView {
     int seqlen_q, seqlen_k, k_tiles;
     int64_t q_off, k_off, v_off, o_off;   // element offsets of the sequence's first row in q / k / v / o
@@ -53,18 +53,12 @@ struct SeqView {
 };
 __device__ __forceinline__ SeqView seq_view(const FwdParams& p, int b, int h, int block_n) {
     SeqView s;
-    if (p.cu_seqlens_q == nullptr) {
-        s.seqlen_q = p.seqlen_q; s.seqlen_k = p.seqlen_k; s.k_tiles = p.k_tiles;
-        s.q_off = b * p.q_batch_stride; s.k_off = b * p.k_batch_stride; s.v_off = b * p.v_batch_stride; s.o_off = b * p.o_batch_stride;
-        s.lse_row0 = p.lse + (static_cast<int64_t>(b) * p.num_heads + h) * p.seqlen_q;
-    } else {
-        const int q0 = p.cu_seqlens_q[b], k0 = p.cu_seqlens_k[b];
-        s.seqlen_q = min(max(p.cu_seqlens_q[b + 1] - q0, 0), p.seqlen_q);
-        s.seqlen_k = min(max(p.cu_seqlens_k[b + 1] - k0, 0), p.seqlen_k);
-        s.k_tiles = (s.seqlen_k + block_n - 1) / block_n;
-        s.q_off = q0 * p.q_row_stride; s.k_off = k0 * p.k_row_stride; s.v_off = k0 * p.v_row_stride; s.o_off = q0 * p.o_row_stride;
-        s.lse_row0 = p.lse + static_cast<int64_t>(h) * p.total_q + q0;
-    }
+    const int q0 = p.cu_seqlens_q[b], k0 = p.cu_seqlens_k[b];
+    s.seqlen_q = min(max(p.cu_seqlens_q[b + 1] - q0, 0), p.seqlen_q);
+    s.seqlen_k = min(max(p.cu_seqlens_k[b + 1] - k0, 0), p.seqlen_k);
+    s.k_tiles = (s.seqlen_k + block_n - 1) / block_n;
+    s.q_off = q0 * p.q_row_stride; s.k_off = k0 * p.k_row_stride; s.v_off = k0 * p.v_row_stride; s.o_off = q0 * p.o_row_stride;
+    s.lse_row0 = p.lse + static_cast<int64_t>(h) * p.total_q + q0;
     return s;
 }
 
