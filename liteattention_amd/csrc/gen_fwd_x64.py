@@ -27,6 +27,8 @@ it has grown by more than `tau` (log2 units); P stays <= 2^tau. The skip vote us
 import os
 import sys
 
+from gen_epilogue import store_epilogue
+
 OPT = set(x for x in os.environ.get("LA_X64_OPT", "").split(",") if x)
 
 
@@ -807,7 +809,7 @@ def prologue():
 
 
 def epilogue():
-    emit("; ---- flush the last vote word, export O^T / m_ref / l through LDS")
+    emit("; ---- flush the last vote word")
     nofl = new_label("nolastflush")
     emit(f"s_and_b32 {s(S_T0)}, {s(S_NTILES)}, 31")
     emit(f"s_cmp_eq_u32 {s(S_T0)}, 0")
@@ -815,37 +817,9 @@ def epilogue():
     emit(f"s_sub_u32 {s(S_T2)}, {s(S_NTILES)}, 1")
     flush_domask(S_T2)
     label(nofl)
+    emit("s_nop 15")                                           # the last PV MFMAs have written the accumulators
     emit("s_nop 15")
-    emit("s_nop 15")
-    # O: register group (qb, db, q4) at lds_base + ((qb*4 + db)*4 + q4)*4096 + tid*16 ; tid = wave*64 + lane
-    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 10")
-    emit(f"v_lshl_add_u32 {v(T[0])}, {v(LANE)}, 4, {s(S_T0)}")
-    emit(f"v_add_u32 {v(T[0])}, {s(S_LDS)}, {v(T[0])}")
-    for qb in (0, 1):
-        for db in range(4):
-            if (qb * 4 + db) * 16384 >= 65536:
-                pass
-            for q4 in range(4):
-                off = ((qb * 4 + db) * 4 + q4) * 4096
-                if off >= 65536:      # ds offsets are 16 bits: step the address register
-                    continue
-                emit(f"ds_write_b128 {v(T[0])}, {ar(O_(qb, db) + 4 * q4, 4)} offset:{off}")
-    emit(f"v_add_u32 {v(T[1])}, 0x10000, {v(T[0])}")
-    for qb in (0, 1):
-        for db in range(4):
-            for q4 in range(4):
-                off = ((qb * 4 + db) * 4 + q4) * 4096
-                if off < 65536:
-                    continue
-                emit(f"ds_write_b128 {v(T[1])}, {ar(O_(qb, db) + 4 * q4, 4)} offset:{off - 65536}")
-    # m_ref, l: export + (qb*256 + tid)*8
-    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 9")
-    emit(f"v_lshl_add_u32 {v(T[2])}, {v(LANE)}, 3, {s(S_T0)}")
-    emit(f"v_add_u32 {v(T[2])}, {s(S_EXPORT)}, {v(T[2])}")
-    for qb in (0, 1):
-        emit(f"v_mov_b32 {v(T[4])}, {v(MREF[qb])}")
-        emit(f"v_add_f32 {v(T[5])}, {v(L0[qb])}, {v(L1[qb])}")
-        emit(f"ds_write_b64 {v(T[2])}, {vr(T[4], 2)} offset:{2048 * qb}")
+    store_epilogue(globals(), O_)                              # gen_epilogue.py: 1/l, bf16 O and LSE from the registers
     emit("s_waitcnt lgkmcnt(0)")
 
 

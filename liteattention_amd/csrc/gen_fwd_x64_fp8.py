@@ -26,6 +26,8 @@ results equal the offset-8 ones except for P < 2^-12 (absolute 2.4e-4 of a weigh
 import os
 import sys
 
+from gen_epilogue import store_epilogue
+
 OPT = set(x for x in os.environ.get("LA_X64F8_OPT", "").split(",") if x)
 
 
@@ -654,7 +656,7 @@ def prologue():
 
 
 def epilogue():
-    emit("; ---- flush the last vote word, export O^T / m_ref / l through LDS")
+    emit("; ---- flush the last vote word")
     nofl = new_label("nolastflush")
     emit(f"s_and_b32 {s(S_T0)}, {s(S_NTILES)}, 31")
     emit(f"s_cmp_eq_u32 {s(S_T0)}, 0")
@@ -662,27 +664,11 @@ def epilogue():
     emit(f"s_sub_u32 {s(S_T2)}, {s(S_NTILES)}, 1")
     flush_domask(S_T2)
     label(nofl)
+    emit("s_nop 15")                                           # the last PV MFMAs (16 passes each) have written the accumulators
     emit("s_nop 15")
     emit("s_nop 15")
     emit("s_nop 15")
-    emit("s_nop 15")
-    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 10")
-    emit(f"v_lshl_add_u32 {v(T[0])}, {v(LANE)}, 4, {s(S_T0)}")
-    emit(f"v_add_u32 {v(T[0])}, {s(S_LDS)}, {v(T[0])}")
-    emit(f"v_add_u32 {v(T[1])}, 0x10000, {v(T[0])}")
-    for qb in (0, 1):
-        for db in range(4):
-            for q4 in range(4):
-                off = ((qb * 4 + db) * 4 + q4) * 4096
-                base, o2 = (T[0], off) if off < 65536 else (T[1], off - 65536)
-                emit(f"ds_write_b128 {v(base)}, {ar(O_(qb, db) + 4 * q4, 4)} offset:{o2}")
-    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 9")
-    emit(f"v_lshl_add_u32 {v(T[2])}, {v(LANE)}, 3, {s(S_T0)}")
-    emit(f"v_add_u32 {v(T[2])}, {s(S_EXPORT)}, {v(T[2])}")
-    for qb in (0, 1):
-        emit(f"v_mov_b32 {v(T[4])}, {v(MREF[qb])}")
-        emit(f"v_add_f32 {v(T[5])}, {v(L0[qb])}, {v(L1[qb])}")
-        emit(f"ds_write_b64 {v(T[2])}, {vr(T[4], 2)} offset:{2048 * qb}")
+    store_epilogue(globals(), O_)                              # gen_epilogue.py: v_descale / l, bf16 O and LSE from the registers
     emit("s_waitcnt lgkmcnt(0)")
 
 

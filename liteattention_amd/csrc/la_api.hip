@@ -112,7 +112,8 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         const int gran = (fp8 && i < 9) ? 16 : 8;                                        // 16-byte rows: 16 fp8 / 8 bf16 elements
         if (s % gran != 0 || s < 0) return LA_ERR_STRIDE;
     }
-    if (a->k_row_stride > 0x3fffffff || a->v_row_stride > 0x3fffffff) return LA_ERR_STRIDE;   // byte strides kept in int32
+    if (a->k_row_stride > 0x3fffffff || a->v_row_stride > 0x3fffffff || a->o_row_stride > 0x3fffffff || a->q_row_stride > 0x3fffffff)
+        return LA_ERR_STRIDE;                                                             // byte strides kept in 32 bits
     if (!aligned16(a->q) || !aligned16(a->k) || !aligned16(a->v) || !aligned16(a->o)) return LA_ERR_STRIDE;
 
     const bool varlen = a->cu_seqlens_q != nullptr || a->cu_seqlens_k != nullptr;

@@ -243,10 +243,10 @@ def test_longest_supported_key_sequence_and_the_typed_error_beyond_it(dtype):
     assert (out.float()[0, :, 0] - ref).abs().max().item() <= tol
     assert (lse[0, 0] - torch.logsumexp(sc, -1)).abs().max().item() <= 1e-3
     assert att.get_skip_fraction() == 0.0
-    if L.get_tile_sizes(D, 1 if dtype == "fp8" else 2)[0] == 256:      # the x64 kernels (128 KiB of LDS is the O^T export area);
-        too_long = torch.zeros(1, 7000 * 64, H, D, dtype=q.dtype, device="cuda")   # the 128-row A/B kernels hold ~24 000 tiles
-        with pytest.raises(RuntimeError, match="too long"):
-            L.flash_attn_func(q.cuda(), too_long, too_long)
+    # the expanded list lives in LDS (4.25 bytes per k-tile beside the K/V rings): ~23 000 tiles (1.4 M keys) fit, 40 000 do not
+    too_long = torch.zeros(1, 40000 * 64, H, D, dtype=q.dtype, device="cuda")
+    with pytest.raises(RuntimeError, match="too long"):
+        L.flash_attn_func(q.cuda(), too_long, too_long)
 
 
 # ------------------------------------------------------------------------------------------ ticket queues cover every item
