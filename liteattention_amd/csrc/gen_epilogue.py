@@ -3,7 +3,8 @@
 finalize (softmax.h:275-296) + store (epilogue_fwd.hpp:214-403) straight from the accumulators: every lane owns ONE query row
 (column lane & 31 of the 32x32 accumulator; lanes l and l ^ 32 split the head dim), so 1/l is lane-local after one half-wave
 exchange and the accumulator registers (qb, db, 4t..4t+3) are 4 consecutive d = 32 db + 8 t + 4 hh + [0, 4) of that row: 8 bytes
-of bf16, stored with global_store_dwordx2 (the pattern round 1 measured fastest of three on this part).
+of bf16; pairs of such groups are exchanged between the half-waves (v_permlane32_swap) into 16 contiguous bytes per lane and
+stored with global_store_dwordx4 (16 store instructions per wave instead of 32).
 Round 1 exported O^T as fp32 through a 128 KiB LDS overlay of the K/V rings and finished in C++: 32 ds_write_b128 + 32
 ds_read_b128 per wave and a workgroup barrier per item for no transposition at all, and the overlay pinned 128 KiB of LDS.
 
@@ -21,7 +22,7 @@ def store_epilogue(g, o_reg):
     S_PARAM, S_SEQLENQ, S_EXEC, S_T64 = g["S_PARAM"], g["S_SEQLENQ"], g["S_EXEC"], g["S_T64"]
     # the loop's DMA-base registers are dead here: O base, LSE base and the scalars live in them
     S_OBASE, S_LSEB, S_ORS, S_CLN2, S_OSCALE, S_LSEADD = g["S_TB"], g["S_VB"], g["S_T0"], g["S_T1"], g["S_T2"], g["S_T3"]
-    HH8 = g["MLOC"][0]                                         # dead after the loop: hh * 8 bytes
+    HH16 = g["MLOC"][0]                                        # dead after the loop: hh * 16 bytes
     emit("; ---- finalize + store O (bf16) and LSE straight from the accumulators")
     emit(f"v_mov_b32 {v(T[0])}, {s(S_PARAM)}")
     emit(f"ds_read_b128 {vr(T[4], 4)}, {v(T[0])} offset:96")
@@ -31,7 +32,7 @@ def store_epilogue(g, o_reg):
                      (S_OSCALE, T[10]), (S_LSEADD, T[11])):
         emit(f"v_readfirstlane_b32 {s(dst)}, {v(src)}")
     emit("s_nop 4")
-    emit(f"v_lshlrev_b32 {v(HH8)}, 1, {v(HH4)}")
+    emit(f"v_lshlrev_b32 {v(HH16)}, 2, {v(HH4)}")
     for qb in (0, 1):
         # l = sum over the two half-waves; inv = oscale / l (0 for l == 0 or NaN); lse = m_ref c ln2 + ln l + lse_add
         emit(f"v_add_f32 {v(T[0])}, {v(L0[qb])}, {v(L1[qb])}")
@@ -56,24 +57,45 @@ def store_epilogue(g, o_reg):
         emit(f"v_cmp_gt_i32 vcc, {s(S_SEQLENQ)}, {v(QROW[qb])}")
         emit(f"s_and_saveexec_b64 {sr(S_EXEC)}, vcc")
         emit(f"v_mad_u64_u32 {vr(T[4], 2)}, {sr(S_T64)}, {v(QROW[qb])}, {s(S_ORS)}, 0")
-        emit(f"v_add_co_u32 {v(T[4])}, vcc, {v(T[4])}, {v(HH8)}")
+        emit(f"v_add_co_u32 {v(T[4])}, vcc, {v(T[4])}, {v(HH16)}")
         emit(f"v_addc_co_u32 {v(T[5])}, vcc, 0, {v(T[5])}, vcc")
         emit(f"v_add_co_u32 {v(T[4])}, vcc, {s(S_OBASE)}, {v(T[4])}")
         emit(f"v_mov_b32 {v(T[6])}, {s(S_OBASE + 1)}")
         emit(f"v_addc_co_u32 {v(T[5])}, vcc, {v(T[5])}, {v(T[6])}, vcc")
-        n = 0
-        for db in range(4):
-            for t in range(4):
-                a0 = o_reg(qb, db) + 4 * t
-                r = T[8] if n % 2 == 0 else T[12]                          # two temp sets: a store never waits on the next group
-                n += 1
-                for k in range(4):
-                    emit(f"v_accvgpr_read_b32 {v(r + k)}, a{a0 + k}")
-                for k in range(4):
-                    emit(f"v_mul_f32 {v(r + k)}, {v(r + k)}, {v(T[2])}")
-                emit(f"v_cvt_pk_bf16_f32 {v(r)}, {v(r)}, {v(r + 1)}")
-                emit(f"v_cvt_pk_bf16_f32 {v(r + 1)}, {v(r + 2)}, {v(r + 3)}")
-                emit(f"global_store_dwordx2 {vr(T[4], 2)}, {vr(r, 2)}, off offset:{64 * db + 16 * t}")
+        # 16 groups of 4 floats per q-block -> 8 PAIRS (t even, t + 1) of one d-block: after the bf16 pack, two half-wave swaps
+        # give the lower lanes cols 8t..8t+7 and the upper lanes cols 8t+8..8t+15 of their row = ONE 16-byte store per pair (upper
+        # lanes +16 bytes) instead of two 8-byte ones: the store tail is issue-bound per instruction (cdna_hip_programming.md T21).
+        # Software-pipelined over two register sets (the S buffers v0..v15 are dead here): read(p+1) sits between pack(p) and
+        # swap(p), which also covers the 2 wait states a VALU write needs before v_permlane32_swap reads it.
+        pairs = [(db, t) for db in range(4) for t in (0, 2)]
+
+        def stage_read(i):
+            db, t = pairs[i]
+            r = 8 * (i % 2)
+            return [f"v_accvgpr_read_b32 {v(r + k)}, a{o_reg(qb, db) + 4 * t + k}" for k in range(8)]
+
+        def stage_pack(i):
+            r = 8 * (i % 2)
+            return [f"v_mul_f32 {v(r + k)}, {v(r + k)}, {v(T[2])}" for k in range(8)] + \
+                   [f"v_cvt_pk_bf16_f32 {v(r + k)}, {v(r + 2 * k)}, {v(r + 2 * k + 1)}" for k in range(4)]
+
+        def stage_store(i):
+            db, t = pairs[i]
+            r = 8 * (i % 2)
+            return [f"v_permlane32_swap_b32 {v(r)}, {v(r + 2)}", f"v_permlane32_swap_b32 {v(r + 1)}, {v(r + 3)}",
+                    f"global_store_dwordx4 {vr(T[4], 2)}, {vr(r, 4)}, off offset:{64 * db + 16 * t}"]
+
+        seq = stage_read(0) + stage_pack(0)
+        for i in range(len(pairs)):
+            if i + 1 < len(pairs):
+                seq += stage_read(i + 1)
+            else:
+                seq += ["s_nop 1"]
+            seq += stage_store(i)
+            if i + 1 < len(pairs):
+                seq += stage_pack(i + 1)
+        for op in seq:
+            emit(op)
         # LSE: one lane per row (hh == 0), only if the caller wants it
         nolse = new_label("nolse")
         emit(f"s_cmp_eq_u64 {sr(S_LSEB)}, 0")

@@ -75,16 +75,17 @@ NEGINF, HH4, LANE, RIPROW = 212, 213, 214, 215
 QROW = [216, 217]
 RAGK, RAGV = 218, 219                     # ragged-path swizzled chunk offsets (constants)
 MTHR = [220, 221]                         # m_ref + tau/c: the lazy-rescale trigger level
+TABV = 222                                # LDS address of tab[i + 2], the tile-address table entry step i reads from
 
 # ---------------------------------------------------------------- SGPR map (s32-s34 are ABI-reserved: unused)
 S_KBASE, S_VBASE, S_QBASE = 36, 38, 40    # 64-bit
 S_TB, S_VB, S_EXEC, S_T64, S_T64B = 42, 44, 46, 48, 50   # 64-bit temps
-(S_KRS, S_VRS, S_LASTROW, S_NTILES, S_C, S_THR, S_TAILVALID, S_KTM1, S_SEQ, S_DOFLAGS, S_WAVE, S_I, S_DOMASK,
- S_NA, S_NB, S_NC, S_LDS, S_T0, S_T1, S_T2, S_T3, S_NM1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_PARAM, S_HASNEXT, S_NEGC,
- S_SAFEROW, S_DMAW, S_RAG, S_TAU, S_RESC, S_NCUR) = range(52, 87)
-S_RAG2, S_TB2, S_VB2, S_POS = 87, 88, 90, 92     # second set of DMA bases / ragged flags (the loop is unrolled by two)
+(S_KRS, S_VRS, S_LASTROW, S_NTILES, S_C, S_THR, S_TAILVALID, S_FIRSTLAST, S_TAB, S_DOFLAGS, S_WAVE, S_I, S_DOMASK,
+ S_FREE0, S_FREE1, S_FREE2, S_LDS, S_T0, S_T1, S_T2, S_T3, S_NM1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_PARAM, S_DOWORD, S_NEGC,
+ S_FREE3, S_DMAW, S_FREE4, S_TAU, S_RESC, S_FREE5) = range(52, 87)
+S_FREE6, S_TB2, S_VB2, S_BIT = 87, 88, 90, 92    # second set of DMA bases (the loop is unrolled by two); the rotating vote bit
 S_CC = 94                                        # s[94:95] = (c, c): scalar operand of v_pk_fma_f32
-TBS, VBS, RAGS = [S_TB, S_TB2], [S_VB, S_VB2], [S_RAG, S_RAG2]
+TBS, VBS = [S_TB, S_TB2], [S_VB, S_VB2]
 
 KV_TILE = 16384
 V_REGION = 32768
@@ -258,39 +259,38 @@ def row_max_ops(sset):
     return [x for pair in zip(*per) for x in pair]
 
 
-def stats_ops(pos_sgpr, valid_sgpr, rare_label, back_label, flush_label, flush_back, inval_label=None, inval_back=None):
-    """Half-wave max exchange, true running max, skip vote (one bit per position, OR over both q-blocks), lazy-rescale test.
-    Independent moves sit in the two-wait-state shadows of v_permlane32_swap instead of s_nops."""
+def stats_ops(rare_label, back_label, flush_label, flush_back, inval_label, inval_back):
+    """Half-wave max exchange, skip vote (one bit per position, OR over both q-blocks), true running max, lazy-rescale test.
+    The vote bit of the position rides in S_BIT (shifted left every step; when it falls off the word is flushed), so no
+    position arithmetic is needed; the independent TABV increment sits in the two-wait-state shadow a VALU write needs before
+    v_permlane32_swap reads it."""
     o = []
     a = o.append
     a(f"    v_mov_b32 {v(T[0])}, {v(MLOC[0])}")
     a(f"    v_mov_b32 {v(T[1])}, {v(MLOC[1])}")
-    a(f"    v_mov_b32 {v(T[2])}, {v(MTRUE[0])}")                     # m_prev
+    a(f"    v_add_u32 {v(TABV)}, 16, {v(TABV)}")
     a(f"    v_permlane32_swap_b32 {v(MLOC[0])}, {v(T[0])}")
     a(f"    v_permlane32_swap_b32 {v(MLOC[1])}, {v(T[1])}")
-    a(f"    v_mov_b32 {v(T[3])}, {v(MTRUE[1])}")
+    a("    s_nop 0")
     a(f"    v_max_f32 {v(MLOC[0])}, {v(MLOC[0])}, {v(T[0])}")
     a(f"    v_max_f32 {v(MLOC[1])}, {v(MLOC[1])}, {v(T[1])}")
-    if valid_sgpr is not None:
-        # a clamped duplicate past the end of the walk must not touch the state: its row max becomes -inf (no vote, no
-        # new max) and -m_ref*c becomes -inf (the part of P(i+1) computed in this phase, added to the row sums, is 0)
-        a(f"    s_cmp_eq_u32 {s(valid_sgpr)}, 0")
-        a(f"    s_cbranch_scc1 {inval_label}")
-        o.append(inval_back + ":")
+    # the step past the end of the walk (i == n - 1: tile i + 1 does not exist, S_nxt came from a clamped duplicate) must not
+    # touch the state: its row max becomes -inf (no vote, no new max) and -m_ref*c becomes -inf (the part of P(i+1) computed in
+    # this phase, added to the row sums, is 0)
+    a(f"    s_cmp_eq_u32 {s(S_I)}, {s(S_NM1)}")
+    a(f"    s_cbranch_scc1 {inval_label}")
+    o.append(inval_back + ":")
+    # vote: (m_loc - m_prev) * c > thr   (softmax.h:194), m_prev = the running max BEFORE this tile
+    a(f"    v_sub_f32 {v(T[2])}, {v(MLOC[0])}, {v(MTRUE[0])}")
+    a(f"    v_sub_f32 {v(T[3])}, {v(MLOC[1])}, {v(MTRUE[1])}")
     a(f"    v_max_f32 {v(MTRUE[0])}, {v(MTRUE[0])}, {v(MLOC[0])}")
     a(f"    v_max_f32 {v(MTRUE[1])}, {v(MTRUE[1])}, {v(MLOC[1])}")
-    # vote: (m_loc - m_prev) * c > thr   (softmax.h:194)
-    a(f"    v_sub_f32 {v(T[2])}, {v(MLOC[0])}, {v(T[2])}")
-    a(f"    v_sub_f32 {v(T[3])}, {v(MLOC[1])}, {v(T[3])}")
     a(f"    v_mul_f32 {v(T[2])}, {s(S_C)}, {v(T[2])}")
     a(f"    v_mul_f32 {v(T[3])}, {s(S_C)}, {v(T[3])}")
     a(f"    v_cmp_gt_f32 {sr(S_T64)}, {v(T[2])}, {s(S_THR)}")
     a(f"    v_cmp_gt_f32 vcc, {v(T[3])}, {s(S_THR)}")
-    a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")
-    a("    s_cmp_lg_u64 vcc, 0")
-    a(f"    s_cselect_b32 {s(S_T0)}, 1, 0")
-    a(f"    s_and_b32 {s(S_T1)}, {s(pos_sgpr)}, 31")
-    a(f"    s_lshl_b32 {s(S_T0)}, {s(S_T0)}, {s(S_T1)}")
+    a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")                              # SCC = some row of the wave voted "do"
+    a(f"    s_cselect_b32 {s(S_T0)}, {s(S_BIT)}, 0")
     a(f"    s_or_b32 {s(S_DOMASK)}, {s(S_DOMASK)}, {s(S_T0)}")
     # lazy rescale: m_true > m_ref + tau/c on any lane of either q-block -> rare block
     a(f"    v_cmp_gt_f32 {sr(S_T64)}, {v(MTRUE[0])}, {v(MTHR[0])}")
@@ -298,9 +298,9 @@ def stats_ops(pos_sgpr, valid_sgpr, rare_label, back_label, flush_label, flush_b
     a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")
     a(f"    s_cbranch_vccnz {rare_label}")
     o.append(back_label + ":")
-    # flush the vote word when position & 31 == 31 (a position past the end only ever adds a zero bit)
-    a(f"    s_cmp_eq_u32 {s(S_T1)}, 31")
-    a(f"    s_cbranch_scc1 {flush_label}")
+    # next position's bit; when it falls off the 32-bit word (SCC = 0: result is zero) the word is complete: flush it
+    a(f"    s_lshl_b32 {s(S_BIT)}, {s(S_BIT)}, 1")
+    a(f"    s_cbranch_scc0 {flush_label}")
     o.append(flush_back + ":")
     return o
 
@@ -335,19 +335,18 @@ def inval_block(lbl, back):
     emit(f"s_branch {back}")
 
 
-def flush_block(flush_label, back_label, pos_sgpr):
-    """Out of line: doflags[pos >> 5] |= domask by one lane; domask = 0. Drains lgkmcnt (keeps counted waits valid)."""
+def flush_block(flush_label, back_label):
+    """Out of line: doflags word |= domask by one lane; next word, domask = 0, bit = 1. Drains lgkmcnt (keeps counted waits valid)."""
     label(flush_label)
-    flush_domask(pos_sgpr)
+    flush_domask()
+    emit(f"s_add_u32 {s(S_DOWORD)}, {s(S_DOWORD)}, 4")
+    emit(f"s_mov_b32 {s(S_BIT)}, 1")
     emit("s_waitcnt lgkmcnt(0)")
     emit(f"s_branch {back_label}")
 
 
-def flush_domask(pos_sgpr):
-    emit(f"s_lshr_b32 {s(S_T0)}, {s(pos_sgpr)}, 5")
-    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_T0)}, 2")
-    emit(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_DOFLAGS)}")
-    emit(f"v_mov_b32 {v(T[4])}, {s(S_T0)}")
+def flush_domask():
+    emit(f"v_mov_b32 {v(T[4])}, {s(S_DOWORD)}")
     emit(f"v_mov_b32 {v(T[5])}, {s(S_DOMASK)}")
     emit(f"s_mov_b64 {sr(S_EXEC)}, exec")
     emit("s_mov_b64 exec, 1")
@@ -374,29 +373,6 @@ def rescale_o_block(lbl, back):
     emit(f"s_branch {back}")
 
 
-def dma_bases(n_k, n_v, st=0):
-    """Tile bases into register set `st`: K -> TBS[st], V -> VBS[st], first row clamped to seqlen_k - 64. A ragged last tile
-    (k_tiles - 1, the only one that can be) is staged exactly - per-lane clamped rows - by the C++ shell, at position 0: a
-    valid list is strictly descending and holds it nowhere else. Wherever else it turns up (clamped duplicates past the end
-    of a short walk, malformed lists) the clamp keeps the reads inside the tensor; with LA_X64_OPT=ragfix the first version's
-    in-loop re-staging of such a tile is generated as well (19 instead of 12 SALU per step)."""
-    S_RAG = RAGS[st]
-    ragfix = "ragfix" in OPT
-    o = [f"    s_mov_b32 {s(S_RAG)}, 0"] if ragfix else []
-    for (n_sgpr, rs, base, dst, bit) in ((n_k, S_KRS, S_KBASE, TBS[st], 1), (n_v, S_VRS, S_VBASE, VBS[st], 2)):
-        o += [f"    s_lshl_b32 {s(S_T0)}, {s(n_sgpr)}, 6"]
-        if ragfix:
-            o += [f"    s_cmp_gt_u32 {s(S_T0)}, {s(S_SAFEROW)}",
-                  f"    s_cselect_b32 {s(S_T1)}, {bit}, 0",
-                  f"    s_or_b32 {s(S_RAG)}, {s(S_RAG)}, {s(S_T1)}"]
-        o += [f"    s_min_u32 {s(S_T0)}, {s(S_T0)}, {s(S_SAFEROW)}",
-              f"    s_mul_hi_u32 {s(dst + 1)}, {s(S_T0)}, {s(rs)}",
-              f"    s_mul_i32 {s(dst)}, {s(S_T0)}, {s(rs)}",
-              f"    s_add_u32 {s(dst)}, {s(dst)}, {s(base)}",
-              f"    s_addc_u32 {s(dst + 1)}, {s(dst + 1)}, {s(base + 1)}"]
-    return o
-
-
 def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True, st=0):
     """[m0K, K0..K3, m0V, V0..V3]: one M0 per tensor, the piece index rides on the instruction offset (applied to both the
     global and the LDS address). The global side is compensated in the per-lane offsets: LK/LV[j] carry +(3072 - 1024*j) and
@@ -413,66 +389,6 @@ def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True, st=0):
         o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {V_REGION + vbuf_imm}")
         o += [f"    global_load_lds_dwordx4 {v(LV[j])}, {sr(VBS[st])} offset:{1024 * j}" for j in range(4)]
     return o
-
-
-def dma_ragged(n_sgpr, is_k, buf_imm):
-    """Slow path for a tile with rows past seqlen_k: per-lane clamped rows (rare: only tile k_tiles-1 can be ragged)."""
-    emit(f"s_lshl_b32 {s(S_T0)}, {s(n_sgpr)}, 6")
-    rs, base, region, cst = (S_KRS, S_KBASE, 0, RAGK) if is_k else (S_VRS, S_VBASE, V_REGION, RAGV)
-    for j in range(4):
-        emit(f"v_add_u32 {v(T[3])}, {s(S_T0)}, {v(RIPROW)}")
-        if j:
-            emit(f"v_add_u32 {v(T[3])}, {4 * j}, {v(T[3])}")
-        emit(f"v_min_i32 {v(T[3])}, {v(T[3])}, {s(S_LASTROW)}")
-        emit(f"v_mad_u64_u32 {vr(T[4], 2)}, {sr(S_T64)}, {v(T[3])}, {s(rs)}, 0")
-        if is_k:
-            emit(f"v_xor_b32 {v(T[6])}, {j << 6}, {v(cst)}")
-        else:
-            emit(f"v_mov_b32 {v(T[6])}, {v(cst)}")
-        emit(f"v_add_co_u32 {v(T[4])}, vcc, {v(T[4])}, {v(T[6])}")
-        emit(f"v_addc_co_u32 {v(T[5])}, vcc, 0, {v(T[5])}, vcc")
-        emit(f"v_add_co_u32 {v(T[4])}, vcc, {s(base)}, {v(T[4])}")
-        emit(f"v_mov_b32 {v(T[6])}, {s(base + 1)}")
-        emit(f"v_addc_co_u32 {v(T[5])}, vcc, {v(T[5])}, {v(T[6])}, vcc")
-        emit(f"v_add_co_u32 {v(T[4])}, vcc, {DMA_BIAS}, {v(T[4])}")      # the bases carry -DMA_BIAS
-        emit(f"v_addc_co_u32 {v(T[5])}, vcc, 0, {v(T[5])}, vcc")
-        emit(f"s_add_u32 m0, {s(S_DMAW)}, {region + buf_imm + j * 1024}")
-        emit("s_nop 0")
-        emit(f"global_load_lds_dwordx4 {vr(T[4], 2)}, off")
-
-
-def seq_at(dst_sgpr, offset):
-    """dst = seq[min(i + offset, n-1)] (rare paths only: a dependent LDS read)."""
-    emit(f"s_add_u32 {s(S_T0)}, {s(S_I)}, {offset}")
-    emit(f"s_min_u32 {s(S_T0)}, {s(S_T0)}, {s(S_NM1)}")
-    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_T0)}, 2")
-    emit(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_SEQ)}")
-    emit(f"v_mov_b32 {v(T[3])}, {s(S_T0)}")
-    emit(f"ds_read_b32 {v(T[3])}, {v(T[3])}")
-    emit("s_waitcnt lgkmcnt(0)")
-    emit(f"v_readfirstlane_b32 {s(dst_sgpr)}, {v(T[3])}")
-    emit("s_nop 3")
-
-
-def dma_fixup_block(lbl, back, n_k, kbuf_imm, n_v, vbuf_imm, st=0):
-    """n_k / n_v: SGPR holding the tile number, or ("pos", d) = look up seq[min(i + d, n-1)]."""
-    label(lbl)
-    nov = new_label("fix_nov")
-    emit("s_waitcnt vmcnt(0)")
-    emit(f"s_bitcmp1_b32 {s(RAGS[st])}, 0")
-    emit(f"s_cbranch_scc0 {nov}")
-    if isinstance(n_k, tuple):
-        seq_at(S_T1, n_k[1])
-        n_k = S_T1
-    dma_ragged(n_k, True, kbuf_imm)
-    label(nov)
-    emit(f"s_bitcmp1_b32 {s(RAGS[st])}, 1")
-    emit(f"s_cbranch_scc0 {back}")
-    if isinstance(n_v, tuple):
-        seq_at(S_T1, n_v[1])
-        n_v = S_T1
-    dma_ragged(n_v, False, vbuf_imm)
-    emit(f"s_branch {back}")
 
 
 def weight(it):
@@ -551,17 +467,12 @@ def step(variant):
             post[t].append(k_read(kbuf_read, ord1[t if "klate" not in OPT else f]))
     rare, back = new_label("rare"), new_label("rare_back")
     fl, flback = new_label("flush"), new_label("flush_back")
-    # next step (i+1): V tile = seq[i+2] (S_NB), K tile = seq[min(i+4, n-1)] (read here); position / has_next of this step
-    vq = [f"    s_add_u32 {s(S_T3)}, {s(S_I)}, 4",
-          f"    s_min_u32 {s(S_T3)}, {s(S_T3)}, {s(S_NM1)}",
-          f"    s_lshl_b32 {s(S_T3)}, {s(S_T3)}, 2",
-          f"    s_add_u32 {s(S_T3)}, {s(S_T3)}, {s(S_SEQ)}",
-          f"    v_mov_b32 {v(T[6])}, {s(S_T3)}",
-          ("LDS", f"ds_read_b32 {v(T[7])}, {v(T[6])}", "seq"),
-          f"    s_add_u32 {s(S_POS)}, {s(S_I)}, 1",
-          f"    s_cmp_lt_u32 {s(S_POS)}, {s(S_NTILES)}",
-          f"    s_cselect_b32 {s(S_HASNEXT)}, 1, 0",
-          ]
+    # next step (i+1) stages K(i+4) and V(i+2): their global addresses come from the tile-address table the C++ shell built in
+    # LDS (tab[pos] = {K address, V address} of the tile at walk position pos, rows clamped, DMA_BIAS applied, padded by 4
+    # copies of the last entry): TABV = &tab[i+2]. No tile lookup, no clamp, no 64-bit multiply on the scalar unit.
+    st2 = variant ^ 1
+    vq = [("LDS", f"ds_read_b64 {vr(T[4], 2)}, {v(TABV)} offset:8", "tabv"),
+          ("LDS", f"ds_read_b64 {vr(T[6], 2)}, {v(TABV)} offset:32", "tabk")]
     n_head = len(vq)
     if "norowmax" not in OPT:
         rm = row_max_ops(nxt)
@@ -569,10 +480,9 @@ def step(variant):
         rm = []
     vq += rm[:8]
     rm = rm[8:]
-    vq += [("WAIT", "seq"), f"    v_readfirstlane_b32 {s(S_T3)}, {v(T[7])}"]
-    nb = dma_bases(S_T3, S_NB, st=variant ^ 1) + [f"    s_mov_b32 {s(S_NB)}, {s(S_NC)}", f"    s_mov_b32 {s(S_NC)}, {s(S_T3)}"]
-    # interleave the SALU base arithmetic with the row-max VALU (different issue ports are irrelevant for ONE wave, but
-    # the SALU results are needed late and the VALU chain is latency-bound)
+    vq += [("WAIT", "tabk")]
+    nb = [f"    v_readfirstlane_b32 {s(VBS[st2])}, {v(T[4])}", f"    v_readfirstlane_b32 {s(VBS[st2] + 1)}, {v(T[5])}",
+          f"    v_readfirstlane_b32 {s(TBS[st2])}, {v(T[6])}", f"    v_readfirstlane_b32 {s(TBS[st2] + 1)}, {v(T[7])}"]
     mixed = []
     while rm or nb:
         if rm:
@@ -583,10 +493,10 @@ def step(variant):
     vq += mixed
     if "notail" not in OPT:
         inv, invback = new_label("inval"), new_label("inval_back")
-        vq += stats_ops(S_POS, S_HASNEXT, rare, back, fl, flback, inv, invback)
+        vq += stats_ops(rare, back, fl, flback, inv, invback)
         deferred.append(lambda: inval_block(inv, invback))
         deferred.append(lambda: rare_rescale_block(rare, back))
-        deferred.append(lambda: flush_block(fl, flback, S_POS))
+        deferred.append(lambda: flush_block(fl, flback))
     vq += softmax_stream(nxt, list(range(XPAIRS)))
     # the first two gaps may only hold ops that do not read S_nxt (MFMA -> VALU read hazard): the SALU / seq part
     distribute(vq[:n_head], post, 0, CAP2 if CAP2 > 0 else 6)
@@ -595,31 +505,12 @@ def step(variant):
         for it in pre[t] + [mf[t]] + post[t]:
             out.append(it)
 
-    # ---- tail: rare paths (O rescale, ragged re-stage), drain, barrier
-    slow, slow_back = new_label("slow"), new_label("slow_back")
-    if "ragfix" in OPT:
-        emit(f"s_or_b32 {s(S_T0)}, {s(S_RESC)}, {s(RAGS[variant])}")
-        emit(f"s_cmp_lg_u32 {s(S_T0)}, 0")
-    else:
-        emit(f"s_cmp_lg_u32 {s(S_RESC)}, 0")
-    emit(f"s_cbranch_scc1 {slow}")
-    label(slow_back)
-
-    def slow_block():
-        label(slow)
-        resc, resc_back = new_label("resc"), new_label("resc_back")
-        emit(f"s_cmp_lg_u32 {s(S_RESC)}, 0")
-        emit(f"s_cbranch_scc1 {resc}")
-        label(resc_back)
-        if "ragfix" in OPT:
-            fix = new_label("fix")
-            emit(f"s_cmp_lg_u32 {s(RAGS[variant])}, 0")
-            emit(f"s_cbranch_scc1 {fix}")
-        emit(f"s_branch {slow_back}")
-        rescale_o_block(resc, resc_back)
-        if "ragfix" in OPT:
-            dma_fixup_block(fix, slow_back, ("pos", 3), kbuf_stage, ("pos", 1), vbuf_stage, st=variant)
-    deferred.append(slow_block)
+    # ---- tail: the rare O rescale, drain, barrier
+    resc, resc_back = new_label("resc"), new_label("resc_back")
+    emit(f"s_cmp_lg_u32 {s(S_RESC)}, 0")
+    emit(f"s_cbranch_scc1 {resc}")
+    label(resc_back)
+    deferred.append(lambda: rescale_o_block(resc, resc_back))
     emit(("DRAIN",))
     if "nobarrier" not in OPT:
         emit("s_barrier")
@@ -637,23 +528,17 @@ def prologue():
         emit(f"ds_read_b128 {vr(4 * q, 4)}, {v(T[0])} offset:{16 * q}")
     emit("s_waitcnt lgkmcnt(0)")
     plist = [S_KBASE, S_KBASE + 1, S_VBASE, S_VBASE + 1, S_KRS, S_VRS, S_LASTROW, S_NTILES, S_C, S_THR, S_TAILVALID,
-             S_KTM1, S_SEQ, S_DOFLAGS, S_QBASE, S_QBASE + 1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_LDS, S_NEGC, S_TAU]
+             S_FIRSTLAST, S_TAB, S_DOFLAGS, S_QBASE, S_QBASE + 1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_LDS, S_NEGC, S_TAU]
     for idx, sg in enumerate(plist):
         emit(f"v_readfirstlane_b32 {s(sg)}, {v(idx)}")
     emit("s_nop 4")
-    for base in (S_KBASE, S_VBASE):                            # DMA_BIAS, see dma_ops
-        emit(f"s_sub_u32 {s(base)}, {s(base)}, {DMA_BIAS}")
-        emit(f"s_subb_u32 {s(base + 1)}, {s(base + 1)}, 0")
     emit(f"s_mov_b32 {s(S_CC)}, {s(S_C)}")
     emit(f"s_mov_b32 {s(S_CC + 1)}, {s(S_C)}")
     emit(f"s_sub_u32 {s(S_NM1)}, {s(S_NTILES)}, 1")
-    emit(f"s_sub_u32 {s(S_SAFEROW)}, {s(S_LASTROW)}, 63")
-    emit(f"s_max_i32 {s(S_SAFEROW)}, {s(S_SAFEROW)}, 0")
     emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, 12")
     emit(f"s_add_u32 {s(S_DMAW)}, {s(S_DMAW)}, {s(S_LDS)}")
     emit(f"s_mov_b32 {s(S_I)}, 0")
     emit(f"s_mov_b32 {s(S_RESC)}, 0")
-    emit(f"s_mov_b32 {s(S_RAG)}, 0")
     emit(f"v_mov_b32 {v(NEGINF)}, 0xff800000")
 
     emit("; ---- per-lane constants")
@@ -736,18 +621,17 @@ def prologue():
         emit(f"v_mov_b32 {v(L1[qb])}, 0")
         emit(f"v_mov_b32 {v(ALPHA[qb])}, 1.0")
 
-    emit("; ---- tiles of positions 0..3; K(0) fragments -> AGPRs, S(0) = K(0) Q^T, then K(1) fragments")
-    for p_, dst in ((0, S_NCUR), (1, S_NA), (2, S_NB), (3, S_NC)):
-        emit(f"s_min_u32 {s(S_T0)}, {p_}, {s(S_NM1)}")
-        emit(f"s_lshl_b32 {s(S_T0)}, {s(S_T0)}, 2")
-        emit(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_SEQ)}")
-        emit(f"v_mov_b32 {v(T[6])}, {s(S_T0)}")
-        emit(f"ds_read_b32 {v(T[8 + p_])}, {v(T[6])}")
+    emit("; ---- tile addresses of positions 1..3 from the table; K(0) fragments -> AGPRs, S(0) = K(0) Q^T, then K(1) fragments")
+    emit(f"v_mov_b32 {v(T[6])}, {s(S_TAB)}")
+    emit(f"ds_read_b64 {vr(T[8], 2)}, {v(T[6])} offset:32")          # tab[2].k : K(2), staged below
+    emit(f"ds_read_b64 {vr(T[10], 2)}, {v(T[6])} offset:48")         # tab[3].k : K(3), staged by step 0
+    emit(f"ds_read_b64 {vr(T[12], 2)}, {v(T[6])} offset:24")         # tab[1].v : V(1), staged by step 0
+    emit(f"v_add_u32 {v(TABV)}, 32, {v(T[6])}")                      # step 0 reads tab[2].v and tab[4].k
     for j in range(16):
         emit(k_read(0, j))
     emit(("DRAIN",))
-    for p_, dst in ((0, S_NCUR), (1, S_NA), (2, S_NB), (3, S_NC)):
-        emit(f"v_readfirstlane_b32 {s(dst)}, {v(T[8 + p_])}")
+    emit(f"v_readfirstlane_b32 {s(TBS[0])}, {v(T[8])}")
+    emit(f"v_readfirstlane_b32 {s(TBS[0] + 1)}, {v(T[9])}")
     ord1 = [(f & 1) * 8 + (f >> 1) for f in range(16)]
     for t in range(32):
         out.append(mfma_qk(0, ord1[t >> 1], t & 1))
@@ -755,24 +639,17 @@ def prologue():
         emit(k_read(KV_TILE, j))
     emit(("DRAIN",))
     emit("s_barrier")                                          # every wave has read K(0) and K(1): both K buffers are free
-    # K(2) -> K buffer 0 (tile S_NB). V(1)/K(3) are staged by step 0.
-    for it in dma_bases(S_NB, S_NB):
-        out.append(it)
+    # K(2) -> K buffer 0. V(1)/K(3) are staged by step 0.
     for it in dma_ops(0, 0, do_k=True, do_v=False):
         out.append(it)
         if "m0" in it:
             emit("s_nop 0")
-    if "ragfix" in OPT:
-        emit(f"s_and_b32 {s(S_RAG)}, {s(S_RAG)}, 1")
-        fix, fix_back = new_label("pfix"), new_label("pfix_back")
-        emit(f"s_cmp_lg_u32 {s(S_RAG)}, 0")
-        emit(f"s_cbranch_scc1 {fix}")
-        label(fix_back)
-        deferred.append(lambda: dma_fixup_block(fix, fix_back, S_NB, 0, S_NB, 0))
+    for dst, src in ((TBS[0], T[10]), (TBS[0] + 1, T[11]), (VBS[0], T[12]), (VBS[0] + 1, T[13])):   # step 0 stages K(3), V(1)
+        emit(f"v_readfirstlane_b32 {s(dst)}, {v(src)}")
     emit("s_nop 7")
     # seqlen-k mask: only if n0 == k_tiles-1 and tail_valid < 64  (mask.h:44-78; first walked tile only, mainloop...:1626)
     nomask = new_label("nomask")
-    emit(f"s_cmp_eq_u32 {s(S_NCUR)}, {s(S_KTM1)}")
+    emit(f"s_cmp_eq_u32 {s(S_FIRSTLAST)}, 1")                # the first walked tile is tile k_tiles - 1 (C++ shell)
     emit(f"s_cbranch_scc0 {nomask}")
     emit(f"s_cmp_lt_i32 {s(S_TAILVALID)}, 64")
     emit(f"s_cbranch_scc0 {nomask}")
@@ -799,23 +676,22 @@ def prologue():
         emit(f"v_mov_b32 {v(MREF[qb])}, {v(MTRUE[qb])}")
         emit(f"v_mul_f32 {v(NMS[qb])}, {s(S_NEGC)}, {v(MTRUE[qb])}")
         emit(f"v_add_f32 {v(MTHR[qb])}, {s(S_TAU)}, {v(MTRUE[qb])}")
-    emit(f"s_mov_b32 {s(S_DOMASK)}, 1")
+    emit(f"s_mov_b32 {s(S_DOMASK)}, 1")                        # position 0 is never flagged; position 1 votes into bit 1
+    emit(f"s_mov_b32 {s(S_BIT)}, 2")
+    emit(f"s_mov_b32 {s(S_DOWORD)}, {s(S_DOFLAGS)}")
     for op in softmax_stream(0, list(range(XPAIRS))):
         out.append(op)
-    for it in dma_bases(S_NC, S_NA, st=0):
-        out.append(it)
+
     emit(("DRAIN",))
     emit("s_barrier")
 
 
 def epilogue():
-    emit("; ---- flush the last vote word")
+    emit("; ---- flush the last (partial) vote word")
     nofl = new_label("nolastflush")
-    emit(f"s_and_b32 {s(S_T0)}, {s(S_NTILES)}, 31")
-    emit(f"s_cmp_eq_u32 {s(S_T0)}, 0")
+    emit(f"s_cmp_eq_u32 {s(S_DOMASK)}, 0")
     emit(f"s_cbranch_scc1 {nofl}")
-    emit(f"s_sub_u32 {s(S_T2)}, {s(S_NTILES)}, 1")
-    flush_domask(S_T2)
+    flush_domask()
     label(nofl)
     emit("s_nop 15")                                           # the last PV MFMAs have written the accumulators
     emit("s_nop 15")

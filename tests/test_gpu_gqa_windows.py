@@ -219,11 +219,12 @@ def test_malformed_read_lists_are_memory_safe(dtype, D):
 # ------------------------------------------------------------------------------------------ maximum key length
 @pytest.mark.parametrize("dtype", ["bf16", "fp8"])
 def test_longest_supported_key_sequence_and_the_typed_error_beyond_it(dtype):
-    """The expanded read list of a workgroup lives in LDS beside the K/V rings: ~6 700 key tiles (Sk ~ 429 000) fit. A walk of
-    6 000 tiles must match a torch fp32 reference; one tile count past the limit must raise the typed error, not launch."""
+    """The expanded read list of a workgroup and the tile-address table of its walk live in LDS beside the K/V rings (20.25 bytes
+    per key tile): ~4 800 key tiles (Sk ~ 310 000) fit. A walk of 4 500 tiles must match a torch fp32 reference; a tile count past
+    the limit must raise the typed error, not launch."""
     L = _L()
     D, H, Sq = 128, 1, 300
-    Sk = 6000 * 64 - 17                                   # ragged last tile
+    Sk = 4500 * 64 - 17                                   # ragged last tile
     g = torch.Generator().manual_seed(42)
     q = torch.randn(1, Sq, H, D, generator=g)
     k = torch.randn(1, Sk, H, D, generator=g)
@@ -243,7 +244,6 @@ def test_longest_supported_key_sequence_and_the_typed_error_beyond_it(dtype):
     assert (out.float()[0, :, 0] - ref).abs().max().item() <= tol
     assert (lse[0, 0] - torch.logsumexp(sc, -1)).abs().max().item() <= 1e-3
     assert att.get_skip_fraction() == 0.0
-    # the expanded list lives in LDS (4.25 bytes per k-tile beside the K/V rings): ~23 000 tiles (1.4 M keys) fit, 40 000 do not
     too_long = torch.zeros(1, 40000 * 64, H, D, dtype=q.dtype, device="cuda")
     with pytest.raises(RuntimeError, match="too long"):
         L.flash_attn_func(q.cuda(), too_long, too_long)

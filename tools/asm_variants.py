@@ -1,9 +1,9 @@
 """Builds A/B variants of the hand-scheduled kernels: one library per generator-option setting, under build_variants/.
 
-    python tools/asm_variants.py base= nosm=nosoftmax x_base=x64: x_nodma=x64:nodma ...
-      name=<opts>        gen_fwd_asm.py with LA_ASM_OPT=<opts>      (run with LA_FWD_KERNEL=asm)
-      name=x64:<opts>    gen_fwd_x64.py with LA_X64_OPT=<opts>      (run with LA_FWD_KERNEL=x64)
-    (GPU box)  LA_FWD_KERNEL=.. LITEATTENTION_AMD_LIB=$PWD/build_variants/<name>.so python tools/abl_bench.py
+    python tools/asm_variants.py x_base=x64: x_nodma=x64:nodma f8_base=x64f8: ...
+      name=x64:<opts>    gen_fwd_x64.py with LA_X64_OPT=<opts>
+      name=x64f8:<opts>  gen_fwd_x64_fp8.py with LA_X64F8_OPT=<opts>
+    (GPU box)  LITEATTENTION_AMD_LIB=$PWD/build_variants/<name>.so python tools/abl_bench.py
 Ablation variants compute wrong results; they only price a component.
 """
 import os, subprocess, sys
@@ -22,7 +22,7 @@ def build_one(spec):
     elif opt.startswith("x64:"):
         opt, gen, env_key, macro = opt[4:], "gen_fwd_x64.py", "LA_X64_OPT", "LA_X64_BODY_INC"
     else:
-        gen, env_key, macro = "gen_fwd_asm.py", "LA_ASM_OPT", "LA_ASM_BODY_INC"
+        raise SystemExit(f"{spec}: options must start with x64: (bf16) or x64f8: (fp8)")
     subprocess.run([sys.executable, os.path.join(CSRC, gen), inc], check=True, env=dict(os.environ, **{env_key: opt}),
                    stdout=subprocess.DEVNULL)
     # the other generated include must exist too (default options)
