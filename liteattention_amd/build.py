@@ -59,12 +59,31 @@ def _compile(lib_path: str, defines, verbose: bool) -> str:
     cmd += [f"-D{d}" for d in defines]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     tmp = lib_path + ".tmp"
-    cmd += ["-o", tmp]
+    cmd += ["-o", tmp, "-Rpass-analysis=kernel-resource-usage"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    res = subprocess.run(cmd, check=True, stderr=subprocess.PIPE, text=True)
+    _check_no_scratch(res.stderr, defines)
     os.replace(tmp, lib_path)
     return lib_path
+
+
+def _check_no_scratch(remarks: str, defines) -> None:
+    """The x64 kernels (a C++ shell around an asm body that clobbers nearly the whole register file) must not use scratch:
+    hipcc (ROCm 7.2) has been seen to place the spill store of a value that is live across the body inside a finished
+    divergent loop, where EXEC is 0 - the value is silently lost (wrong parameter words, wild addresses, GPU memory faults).
+    The shells are written so that nothing per-lane is live across the body; this check keeps it that way."""
+    name, bad = None, []
+    for line in remarks.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split()[0]
+        elif "ScratchSize [bytes/lane]:" in line and name and "_x64_kernel" in name:
+            size = int(line.split("ScratchSize [bytes/lane]:")[1].split()[0])
+            if size != 0:
+                bad.append((name, size))
+    if bad and "LA_PROFILE_PHASES" not in defines:
+        raise RuntimeError("x64 kernels must not spill to scratch (see liteattention_amd/csrc/la_fwd_kernel_x64.hip, "
+                           f"COMPILER HAZARD): {bad}")
 
 
 if __name__ == "__main__":

@@ -75,14 +75,15 @@ T = list(range(196, 212))
 NEGINF, HH4, LANE = 212, 213, 214
 QROW = [216, 217]
 MTHR = [220, 221]
+TABV = 222                                # LDS address of tab[i + 2], the tile-address table entry step i reads from
 
 # ---------------------------------------------------------------- SGPR map (s32-s34 are ABI-reserved: unused)
 S_KBASE, S_VBASE, S_QBASE = 36, 38, 40
 S_TB, S_VB, S_EXEC, S_T64, S_T64B = 42, 44, 46, 48, 50
-(S_KRS, S_VRS, S_LASTROW, S_NTILES, S_C, S_THR, S_TAILVALID, S_KTM1, S_SEQ, S_DOFLAGS, S_WAVE, S_I, S_DOMASK,
- S_NA, S_NB, S_NC, S_LDS, S_T0, S_T1, S_T2, S_T3, S_NM1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_PARAM, S_HASNEXT, S_NEGC,
- S_SAFEROW, S_DMAW, S_RAG, S_TAU, S_RESC, S_NCUR) = range(52, 87)
-S_RAG2, S_TB2, S_VB2, S_POS = 87, 88, 90, 92
+(S_KRS, S_VRS, S_LASTROW, S_NTILES, S_C, S_THR, S_TAILVALID, S_FIRSTLAST, S_TAB, S_DOFLAGS, S_WAVE, S_I, S_DOMASK,
+ S_FREE0, S_FREE1, S_FREE2, S_LDS, S_T0, S_T1, S_T2, S_T3, S_NM1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_PARAM, S_DOWORD, S_NEGC,
+ S_FREE3, S_DMAW, S_FREE4, S_TAU, S_RESC, S_FREE5) = range(52, 87)
+S_FREE6, S_TB2, S_VB2, S_BIT = 87, 88, 90, 92     # second set of DMA bases (the loop is unrolled by two); the rotating vote bit
 TBS, VBS = [S_TB, S_TB2], [S_VB, S_VB2]
 
 KV_TILE = 8192
@@ -227,41 +228,40 @@ def row_max_ops(sset):
     return [x for pair in zip(*per) for x in pair]
 
 
-def stats_ops(pos_sgpr, valid_sgpr, rare_label, back_label, flush_label, flush_back, inval_label, inval_back):
+def stats_ops(rare_label, back_label, flush_label, flush_back, inval_label, inval_back):
+    """Half-wave max exchange, skip vote, true running max, lazy-rescale test: as gen_fwd_x64.py stats_ops (rotating vote bit in
+    S_BIT, the step past the end of the walk recognised by i == n - 1, no position arithmetic)."""
     o = []
     a = o.append
     a(f"    v_mov_b32 {v(T[0])}, {v(MLOC[0])}")
     a(f"    v_mov_b32 {v(T[1])}, {v(MLOC[1])}")
-    a(f"    v_mov_b32 {v(T[2])}, {v(MTRUE[0])}")
+    a(f"    v_add_u32 {v(TABV)}, 16, {v(TABV)}")
     a(f"    v_permlane32_swap_b32 {v(MLOC[0])}, {v(T[0])}")
     a(f"    v_permlane32_swap_b32 {v(MLOC[1])}, {v(T[1])}")
-    a(f"    v_mov_b32 {v(T[3])}, {v(MTRUE[1])}")
+    a("    s_nop 0")
     a(f"    v_max_f32 {v(MLOC[0])}, {v(MLOC[0])}, {v(T[0])}")
     a(f"    v_max_f32 {v(MLOC[1])}, {v(MLOC[1])}, {v(T[1])}")
-    a(f"    s_cmp_eq_u32 {s(valid_sgpr)}, 0")
+    a(f"    s_cmp_eq_u32 {s(S_I)}, {s(S_NM1)}")
     a(f"    s_cbranch_scc1 {inval_label}")
     o.append(inval_back + ":")
+    a(f"    v_sub_f32 {v(T[2])}, {v(MLOC[0])}, {v(MTRUE[0])}")              # vote: (m_loc - m_prev) * c > thr (softmax.h:194)
+    a(f"    v_sub_f32 {v(T[3])}, {v(MLOC[1])}, {v(MTRUE[1])}")
     a(f"    v_max_f32 {v(MTRUE[0])}, {v(MTRUE[0])}, {v(MLOC[0])}")
     a(f"    v_max_f32 {v(MTRUE[1])}, {v(MTRUE[1])}, {v(MLOC[1])}")
-    a(f"    v_sub_f32 {v(T[2])}, {v(MLOC[0])}, {v(T[2])}")                  # vote: (m_loc - m_prev) * c > thr (softmax.h:194)
-    a(f"    v_sub_f32 {v(T[3])}, {v(MLOC[1])}, {v(T[3])}")
     a(f"    v_mul_f32 {v(T[2])}, {s(S_C)}, {v(T[2])}")
     a(f"    v_mul_f32 {v(T[3])}, {s(S_C)}, {v(T[3])}")
     a(f"    v_cmp_gt_f32 {sr(S_T64)}, {v(T[2])}, {s(S_THR)}")
     a(f"    v_cmp_gt_f32 vcc, {v(T[3])}, {s(S_THR)}")
-    a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")
-    a("    s_cmp_lg_u64 vcc, 0")
-    a(f"    s_cselect_b32 {s(S_T0)}, 1, 0")
-    a(f"    s_and_b32 {s(S_T1)}, {s(pos_sgpr)}, 31")
-    a(f"    s_lshl_b32 {s(S_T0)}, {s(S_T0)}, {s(S_T1)}")
+    a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")                                 # SCC = some row of the wave voted "do"
+    a(f"    s_cselect_b32 {s(S_T0)}, {s(S_BIT)}, 0")
     a(f"    s_or_b32 {s(S_DOMASK)}, {s(S_DOMASK)}, {s(S_T0)}")
     a(f"    v_cmp_gt_f32 {sr(S_T64)}, {v(MTRUE[0])}, {v(MTHR[0])}")         # lazy rescale trigger
     a(f"    v_cmp_gt_f32 vcc, {v(MTRUE[1])}, {v(MTHR[1])}")
     a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")
     a(f"    s_cbranch_vccnz {rare_label}")
     o.append(back_label + ":")
-    a(f"    s_cmp_eq_u32 {s(S_T1)}, 31")
-    a(f"    s_cbranch_scc1 {flush_label}")
+    a(f"    s_lshl_b32 {s(S_BIT)}, {s(S_BIT)}, 1")                           # falls off the word (SCC = 0): flush it
+    a(f"    s_cbranch_scc0 {flush_label}")
     o.append(flush_back + ":")
     return o
 
@@ -305,18 +305,17 @@ def inval_block(lbl, back):
     emit(f"s_branch {back}")
 
 
-def flush_block(flush_label, back_label, pos_sgpr):
+def flush_block(flush_label, back_label):
     label(flush_label)
-    flush_domask(pos_sgpr)
+    flush_domask()
+    emit(f"s_add_u32 {s(S_DOWORD)}, {s(S_DOWORD)}, 4")
+    emit(f"s_mov_b32 {s(S_BIT)}, 1")
     emit("s_waitcnt lgkmcnt(0)")
     emit(f"s_branch {back_label}")
 
 
-def flush_domask(pos_sgpr):
-    emit(f"s_lshr_b32 {s(S_T0)}, {s(pos_sgpr)}, 5")
-    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_T0)}, 2")
-    emit(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_DOFLAGS)}")
-    emit(f"v_mov_b32 {v(T[4])}, {s(S_T0)}")
+def flush_domask():
+    emit(f"v_mov_b32 {v(T[4])}, {s(S_DOWORD)}")
     emit(f"v_mov_b32 {v(T[5])}, {s(S_DOMASK)}")
     emit(f"s_mov_b64 {sr(S_EXEC)}, exec")
     emit("s_mov_b64 exec, 1")
@@ -342,20 +341,6 @@ def rescale_o_block(lbl, back):
     emit(f"s_mov_b32 {s(S_RESC)}, 0")
     emit("s_nop 7")
     emit(f"s_branch {back}")
-
-
-def dma_bases(n_k, n_v, st=0):
-    """K: kbase + min(64 n, saferow) * k_rs (a ragged last tile is staged only by the shell, at position 0: valid lists hold
-    tile Kt-1 nowhere else; the clamp keeps every other case memory-safe). V^T: tile n of the pre-transposed workspace."""
-    return [f"    s_lshl_b32 {s(S_T0)}, {s(n_k)}, 6",
-            f"    s_min_u32 {s(S_T0)}, {s(S_T0)}, {s(S_SAFEROW)}",
-            f"    s_mul_hi_u32 {s(TBS[st] + 1)}, {s(S_T0)}, {s(S_KRS)}",
-            f"    s_mul_i32 {s(TBS[st])}, {s(S_T0)}, {s(S_KRS)}",
-            f"    s_add_u32 {s(TBS[st])}, {s(TBS[st])}, {s(S_KBASE)}",
-            f"    s_addc_u32 {s(TBS[st] + 1)}, {s(TBS[st] + 1)}, {s(S_KBASE + 1)}",
-            f"    s_lshl_b32 {s(S_T0)}, {s(n_v)}, 13",
-            f"    s_add_u32 {s(VBS[st])}, {s(S_VBASE)}, {s(S_T0)}",
-            f"    s_addc_u32 {s(VBS[st] + 1)}, {s(S_VBASE + 1)}, 0"]
 
 
 def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True, st=0):
@@ -439,21 +424,18 @@ def step(variant):
             post[t] += [k_read(kbuf_read, *K_FRAGS[2 * t]), k_read(kbuf_read, *K_FRAGS[2 * t + 1])]
     rare, back = new_label("rare"), new_label("rare_back")
     fl, flback = new_label("flush"), new_label("flush_back")
-    vq = [f"    s_add_u32 {s(S_T3)}, {s(S_I)}, 4",
-          f"    s_min_u32 {s(S_T3)}, {s(S_T3)}, {s(S_NM1)}",
-          f"    s_lshl_b32 {s(S_T3)}, {s(S_T3)}, 2",
-          f"    s_add_u32 {s(S_T3)}, {s(S_T3)}, {s(S_SEQ)}",
-          f"    v_mov_b32 {v(T[6])}, {s(S_T3)}",
-          ("LDS", f"ds_read_b32 {v(T[7])}, {v(T[6])}", "seq"),
-          f"    s_add_u32 {s(S_POS)}, {s(S_I)}, 1",
-          f"    s_cmp_lt_u32 {s(S_POS)}, {s(S_NTILES)}",
-          f"    s_cselect_b32 {s(S_HASNEXT)}, 1, 0"]
+    # next step stages K(i+4) and V^T(i+2): global addresses from the tile-address table the C++ shell built in LDS
+    # (gen_fwd_x64.py step(): TABV = &tab[i+2], entries {K address, V^T tile address}, padded by 4 copies of the last one)
+    st2 = variant ^ 1
+    vq = [("LDS", f"ds_read_b64 {vr(T[4], 2)}, {v(TABV)} offset:8", "tabv"),
+          ("LDS", f"ds_read_b64 {vr(T[6], 2)}, {v(TABV)} offset:32", "tabk")]
     n_head = len(vq)
     rm = row_max_ops(nxt)
     vq += rm[:8]
     rm = rm[8:]
-    vq += [("WAIT", "seq"), f"    v_readfirstlane_b32 {s(S_T3)}, {v(T[7])}"]
-    nb = dma_bases(S_T3, S_NB, st=variant ^ 1) + [f"    s_mov_b32 {s(S_NB)}, {s(S_NC)}", f"    s_mov_b32 {s(S_NC)}, {s(S_T3)}"]
+    vq += [("WAIT", "tabk")]
+    nb = [f"    v_readfirstlane_b32 {s(VBS[st2])}, {v(T[4])}", f"    v_readfirstlane_b32 {s(VBS[st2] + 1)}, {v(T[5])}",
+          f"    v_readfirstlane_b32 {s(TBS[st2])}, {v(T[6])}", f"    v_readfirstlane_b32 {s(TBS[st2] + 1)}, {v(T[7])}"]
     mixed = []
     while rm or nb:
         if rm:
@@ -463,10 +445,10 @@ def step(variant):
             mixed.append(nb.pop(0))
     vq += mixed
     inv, invback = new_label("inval"), new_label("inval_back")
-    vq += stats_ops(S_POS, S_HASNEXT, rare, back, fl, flback, inv, invback)
+    vq += stats_ops(rare, back, fl, flback, inv, invback)
     deferred.append(lambda: inval_block(inv, invback))
     deferred.append(lambda: rare_rescale_block(rare, back))
-    deferred.append(lambda: flush_block(fl, flback, S_POS))
+    deferred.append(lambda: flush_block(fl, flback))
     vq += softmax_stream(nxt, list(range(XPAIRS)))
     # gap 0 holds only ops that do not read S_nxt (its last MFMA was issued just before this phase)
     post[0] += vq[:n_head]
@@ -499,15 +481,11 @@ def prologue():
         emit(f"ds_read_b128 {vr(4 * q, 4)}, {v(T[0])} offset:{16 * q}")
     emit("s_waitcnt lgkmcnt(0)")
     plist = [S_KBASE, S_KBASE + 1, S_VBASE, S_VBASE + 1, S_KRS, S_VRS, S_LASTROW, S_NTILES, S_C, S_THR, S_TAILVALID,
-             S_KTM1, S_SEQ, S_DOFLAGS, S_QBASE, S_QBASE + 1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_LDS, S_NEGC, S_TAU]
+             S_FIRSTLAST, S_TAB, S_DOFLAGS, S_QBASE, S_QBASE + 1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_LDS, S_NEGC, S_TAU]
     for idx, sg in enumerate(plist):
         emit(f"v_readfirstlane_b32 {s(sg)}, {v(idx)}")
     emit("s_nop 4")
-    emit(f"s_sub_u32 {s(S_KBASE)}, {s(S_KBASE)}, 1024")         # bias of the K DMA lane offsets, see dma_ops
-    emit(f"s_subb_u32 {s(S_KBASE + 1)}, {s(S_KBASE + 1)}, 0")
     emit(f"s_sub_u32 {s(S_NM1)}, {s(S_NTILES)}, 1")
-    emit(f"s_sub_u32 {s(S_SAFEROW)}, {s(S_LASTROW)}, 63")
-    emit(f"s_max_i32 {s(S_SAFEROW)}, {s(S_SAFEROW)}, 0")
     emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, 11")          # 2 KiB of every 8 KiB tile per wave
     emit(f"s_add_u32 {s(S_DMAW)}, {s(S_DMAW)}, {s(S_LDS)}")
     emit(f"s_mov_b32 {s(S_I)}, 0")
@@ -592,18 +570,17 @@ def prologue():
         emit(f"v_mov_b32 {v(L1[qb])}, 0")
         emit(f"v_mov_b32 {v(ALPHA[qb])}, 1.0")
 
-    emit("; ---- tiles of positions 0..3; K(0) fragments -> AGPRs, S(0) = K(0) Q^T, then K(1) fragments")
-    for p_, dst in ((0, S_NCUR), (1, S_NA), (2, S_NB), (3, S_NC)):
-        emit(f"s_min_u32 {s(S_T0)}, {p_}, {s(S_NM1)}")
-        emit(f"s_lshl_b32 {s(S_T0)}, {s(S_T0)}, 2")
-        emit(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_SEQ)}")
-        emit(f"v_mov_b32 {v(T[6])}, {s(S_T0)}")
-        emit(f"ds_read_b32 {v(T[8 + p_])}, {v(T[6])}")
+    emit("; ---- tile addresses of positions 1..3 from the table; K(0) fragments -> AGPRs, S(0) = K(0) Q^T, then K(1) fragments")
+    emit(f"v_mov_b32 {v(T[6])}, {s(S_TAB)}")
+    emit(f"ds_read_b64 {vr(T[8], 2)}, {v(T[6])} offset:32")          # tab[2].k : K(2), staged below
+    emit(f"ds_read_b64 {vr(T[10], 2)}, {v(T[6])} offset:48")         # tab[3].k : K(3), staged by step 0
+    emit(f"ds_read_b64 {vr(T[12], 2)}, {v(T[6])} offset:24")         # tab[1].v : V^T(1), staged by step 0
+    emit(f"v_add_u32 {v(TABV)}, 32, {v(T[6])}")                      # step 0 reads tab[2].v and tab[4].k
     for (j, t) in K_FRAGS:
         emit(k_read(0, j, t))
     emit(("DRAIN",))
-    for p_, dst in ((0, S_NCUR), (1, S_NA), (2, S_NB), (3, S_NC)):
-        emit(f"v_readfirstlane_b32 {s(dst)}, {v(T[8 + p_])}")
+    emit(f"v_readfirstlane_b32 {s(TBS[0])}, {v(T[8])}")
+    emit(f"v_readfirstlane_b32 {s(TBS[0] + 1)}, {v(T[9])}")
     emit("s_nop 7")                                           # v_accvgpr_write (Q) / ds_read (K) -> MFMA operand reads
     for (sx, kb, qb) in QK_ORDER:
         out.append(mfma_qk(0, kb, sx, qb))
@@ -611,16 +588,16 @@ def prologue():
         emit(k_read(KV_TILE, j, t))
     emit(("DRAIN",))
     emit("s_barrier")                                          # every wave has read K(0) and K(1): both K buffers are free
-    for it in dma_bases(S_NB, S_NB):                           # K(2) -> K buffer 0. V^T(1) / K(3) are staged by step 0.
-        out.append(it)
-    for it in dma_ops(0, 0, do_k=True, do_v=False):
+    for it in dma_ops(0, 0, do_k=True, do_v=False):            # K(2) -> K buffer 0. V^T(1) / K(3) are staged by step 0.
         out.append(it)
         if "m0" in it:
             emit("s_nop 0")
+    for dst, src in ((TBS[0], T[10]), (TBS[0] + 1, T[11]), (VBS[0], T[12]), (VBS[0] + 1, T[13])):   # step 0 stages K(3), V^T(1)
+        emit(f"v_readfirstlane_b32 {s(dst)}, {v(src)}")
     emit("s_nop 15")                                           # S(0): the last MFMA's results before the VALU reads them
     emit("s_nop 15")
     nomask = new_label("nomask")
-    emit(f"s_cmp_eq_u32 {s(S_NCUR)}, {s(S_KTM1)}")             # seqlen-k mask: first walked tile only (mask.h:44-78)
+    emit(f"s_cmp_eq_u32 {s(S_FIRSTLAST)}, 1")                  # seqlen-k mask: first walked tile only (mask.h:44-78), if it is tile k_tiles-1
     emit(f"s_cbranch_scc0 {nomask}")
     emit(f"s_cmp_lt_i32 {s(S_TAILVALID)}, 64")
     emit(f"s_cbranch_scc0 {nomask}")
@@ -646,23 +623,21 @@ def prologue():
         emit(f"v_mov_b32 {v(MREF[qb])}, {v(MTRUE[qb])}")
         set_nms(qb)
         emit(f"v_add_f32 {v(MTHR[qb])}, {s(S_TAU)}, {v(MTRUE[qb])}")
-    emit(f"s_mov_b32 {s(S_DOMASK)}, 1")
+    emit(f"s_mov_b32 {s(S_DOMASK)}, 1")                        # position 0 is never flagged; position 1 votes into bit 1
+    emit(f"s_mov_b32 {s(S_BIT)}, 2")
+    emit(f"s_mov_b32 {s(S_DOWORD)}, {s(S_DOFLAGS)}")
     for op in softmax_stream(0, list(range(XPAIRS))):
         out.append(op)
-    for it in dma_bases(S_NC, S_NA, st=0):
-        out.append(it)
     emit(("DRAIN",))
     emit("s_barrier")
 
 
 def epilogue():
-    emit("; ---- flush the last vote word")
+    emit("; ---- flush the last (partial) vote word")
     nofl = new_label("nolastflush")
-    emit(f"s_and_b32 {s(S_T0)}, {s(S_NTILES)}, 31")
-    emit(f"s_cmp_eq_u32 {s(S_T0)}, 0")
+    emit(f"s_cmp_eq_u32 {s(S_DOMASK)}, 0")
     emit(f"s_cbranch_scc1 {nofl}")
-    emit(f"s_sub_u32 {s(S_T2)}, {s(S_NTILES)}, 1")
-    flush_domask(S_T2)
+    flush_domask()
     label(nofl)
     emit("s_nop 15")                                           # the last PV MFMAs (16 passes each) have written the accumulators
     emit("s_nop 15")

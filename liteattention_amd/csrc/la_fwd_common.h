@@ -147,7 +147,9 @@ __device__ __forceinline__ void store_empty_rows(const FwdParams& p, const SeqVi
                                                  int tid, int nthreads) {
     const int chunks = head_dim / 8;
     const int rows = min(nrows, sv.seqlen_q - row0);
-    for (int i = tid; i < rows * chunks; i += nthreads) {
+    for (int base = 0; base < rows * chunks; base += nthreads) {        // wave-uniform trip count (see la_fwd_kernel_x64.hip)
+        const int i = base + tid;
+        if (i >= rows * chunks) continue;
         const int r = row0 + i / chunks, ch = i % chunks;
         const u32x4 z = {0u, 0u, 0u, 0u};
         *reinterpret_cast<u32x4*>(p.o + sv.o_off + static_cast<int64_t>(r) * p.o_row_stride + h * p.o_head_stride + ch * 8) = z;

@@ -141,7 +141,10 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
     const int64_t list_off = (static_cast<int64_t>(bh) * p.q_tiles + m_block) * (p.k_tiles + 1);
 
     if (SKIPABLE) {
-        for (int i = tid; i < 2 * ((k_tiles + 31) / 32); i += 256) doflags[i] = 0u;   // doflags + endflags
+        // doflags + endflags. Wave-uniform trip count with a predicated body: a `for (i = tid; ...)` loop ends with EXEC = 0, and the
+        // register allocator has been seen to place spill stores right there (la_fwd_kernel_x64.hip, "COMPILER HAZARD")
+        for (int base = 0; base < 2 * ((k_tiles + 31) / 32); base += 256)
+            if (base + tid < 2 * ((k_tiles + 31) / 32)) doflags[base + tid] = 0u;
         __syncthreads();
         if (wave == 0) {
             const int n = expand_read_list(p.read_list + list_off, seq, endflags, k_tiles, lane);
