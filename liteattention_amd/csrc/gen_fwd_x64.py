@@ -18,9 +18,12 @@ Register file (per lane):  AGPR  a[0:127]   O^T  (2 q-blocks x 4 d-blocks x 16)
 Step i (S_cur = scores of tile i, partly exponentiated; K fragments of tile i+1 in AGPRs; V(i), K(i+2) in LDS):
   phase 1  32 MFMA  S_nxt = K(i+1) Q^T   ||  rest of P(i) = exp2(S_cur*c - m_ref*c), row sums, bf16 compaction;
                                               LDS-DMA issue of V(i+1), K(i+3); first 8 V^T fragment reads
-  phase 2  32 MFMA  O^T += V(i)^T P(i)^T ||  K(i+2) fragment reads -> AGPRs; remaining V^T fragment reads; row max of
-                                              S_nxt, running max, skip vote, lazy-rescale decision; first part of P(i+1)
+  phase 2  32 MFMA  O^T += V(i)^T P(i)^T ||  K(i+2) fragment reads -> AGPRs; remaining V^T fragment reads; the global addresses
+                                              of the tiles the NEXT step stages, read from the tile-address table the C++ shell
+                                              built in LDS (no tile lookup or address arithmetic on the scalar unit); row max of
+                                              S_nxt, skip vote (rotating bit), running max, lazy-rescale decision; first part of P(i+1)
   tail     rare O rescale, vmcnt/lgkmcnt drain, ONE barrier.
+After the walk: 1/l, LSE and the bf16 O store straight from the accumulators (gen_epilogue.py).
 Lazy rescale: O and l are kept relative to a reference max m_ref that only follows the true running max m_true when
 it has grown by more than `tau` (log2 units); P stays <= 2^tau. The skip vote uses m_true, so lists are bit-exact.
 """

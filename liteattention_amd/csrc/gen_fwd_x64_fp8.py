@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """Generates la_fwd_x64_fp8_body.inc: hand-scheduled gfx950 main loop of the fp8 (e4m3) / head_dim-128 QK-Skip forward with
 ONE wave per SIMD and 64 query rows per wave (q-tile 256 x k-tile 64) - the structure of gen_fwd_x64.py (bf16) on the
-block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales (2x the bf16 MFMA rate; la_fwd_kernel_fp8.hip explains
-the operand layout, which is kept: K rows / Q fragments as 2 x 16-byte chunks per 64-wide contraction step, V^T tiles
+block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales (2x the bf16 MFMA rate; the non-scaled
+v_mfma_f32_32x32x16_fp8_fp8 runs at the bf16 rate). One instruction contracts 64 indices, 32 bytes of A and of B per lane; the
+contraction index is permuted freely (A and B only have to agree), which lets P go from the S^T accumulators straight into
+the B operand. Operand layout: K rows / Q fragments as 2 x 16-byte chunks per 64-wide contraction step, V^T tiles
 pre-transposed by la_prep_v_fp8 so that the PV operand is two plain ds_read_b128).
 
 Why: the 128-row fp8 kernel (two 32-row waves per SIMD, hipcc-scheduled) is VALU-issue-bound at 38 % MFMA utilisation

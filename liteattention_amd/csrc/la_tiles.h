@@ -9,8 +9,8 @@
 // of LDS. bf16 head_dim 128 (the headline path): ONE wave per SIMD owning the whole 512-entry register file and 64
 // query rows (two 32x32 MFMA column blocks), a workgroup is 4 waves -> kBlockM = 256; 256 x 64 = 16 Ki scores per
 // skip decision (reference Hopper tile: 128 x 176 = 22 Ki). fp8 head_dim 128 uses the same structure (kBlockM = 256). bf16
-// head_dim 64 and 256 keep 32 rows per wave, kBlockM = 128. LA_FWD_KERNEL=v2|asm / LA_FP8_KERNEL=v1 select the 128-row A/B
-// kernels for bf16 head_dim 128 / fp8, and la_get_tile_sizes then reports 128 (la_api.hip).
+// head_dim 64 and 256 keep 32 rows per wave, kBlockM = 128. LA_FLAG_KERNEL_128ROW (la_fwd_args.flags) selects the 128-row A/B
+// kernel for bf16 head_dim 128, and la_get_tile_sizes_ex then reports 128 (la_api.hip).
 #pragma once
 
 namespace la {

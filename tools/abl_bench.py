@@ -13,6 +13,8 @@ for _ in range(3): o2 = att(qs, ks, vs)
 err2 = (o2.float() - ref).abs().max().item()
 S, H = 16384, 80
 q, k, v = [torch.randn(1, S, H, 128, device="cuda", generator=g).bfloat16() for _ in range(3)]
+if os.environ.get("LA_ABL_DTYPE") == "fp8":
+    q, k, v = [x.to(torch.float8_e4m3fn) for x in (q, k, v)]
 for _ in range(2): L.flash_attn_func(q, k, v)
 torch.cuda.synchronize(); t = time.perf_counter(); n = 8
 for _ in range(n): L.flash_attn_func(q, k, v)

@@ -1,0 +1,47 @@
+#!/bin/bash
+# GPU box: every profile the round-2 documents cite, in one call. Outputs under gpurun_out/ev_<tag>/ ; summarise with
+#   python tools/summarize_r02.py gpurun_out/ev_<tag> <tag>          (writes profiles/<tag>_*)
+# PMC counters are collected in their own rocprofv3 passes (never together with trace domains), FETCH_SIZE alone (3 TCC slots).
+set -u
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/ev_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+pmc() { # dir-name counters... -- command
+  local name=$1; shift; local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
+  rocprofv3 --pmc "${ctr[@]}" --kernel-include-regex "la_fwd|la_prep" --output-format csv -d $OUT/$name -o p -- "$@" > $OUT/$name.log 2>&1
+}
+want() { [ "${EV_SECTIONS:-all}" = all ] || [[ " $EV_SECTIONS " == *" $1 "* ]]; }    # EV_SECTIONS="traffic_real other" re-runs parts
+# 1. the driver's own command, un-profiled: the bench line of record
+want bench && python $R/bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
+# 2. kernel trace + stats of the same command (shorter loop)
+want bench && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $R/bench.py --no-sweep --no-cpu-baseline --steps 5 --warmup 2 > $OUT/kt.log 2>&1
+# 3. PMC passes, bf16 headline and fp8
+for dt in bf16 fp8; do
+  want pmc || continue
+  B="python $R/bench.py --no-sweep --no-cpu-baseline --no-fp8 --no-verify --steps 3 --warmup 1 --dtype $dt"
+  pmc ${dt}_mfma SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_INSTS_SALU -- $B
+  pmc ${dt}_wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS -- $B
+  pmc ${dt}_fetch FETCH_SIZE -- $B
+  pmc ${dt}_write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- $B
+done
+# 4. bytes vs sparsity: imposed 0 / 42 / 77 % and the real (fragmented) lists of the 50-step run at ~44 % / ~78 %
+for cfg in "imposed 0.0" "imposed 0.42" "imposed 0.77" "real -4.22" "real -2.46"; do
+  set -- $cfg; n=traffic_$1_$2
+  want traffic_$1 || continue
+  P="python $R/tools/traffic_probe.py --$1 $2"
+  pmc ${n}_fetch FETCH_SIZE -- $P
+  pmc ${n}_write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- $P
+  pmc ${n}_busy GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- $P
+done
+# 5. the other instantiations: bench lines + kernel stats + MFMA utilisation
+for t in d64 d256; do
+  want other || continue
+  python $R/tools/${t}_bench.py > $OUT/${t}_bench.txt 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${t}_kt -o kt -- python $R/tools/${t}_bench.py > $OUT/${t}_kt.log 2>&1
+  pmc ${t}_mfma SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -- python $R/tools/${t}_bench.py
+done
+ls $OUT | head -80
+grep -h PROBE $OUT/traffic_*_fetch.log 2>/dev/null
+[ -f $OUT/bench_line.json ] && tail -c 300 $OUT/bench_line.json

@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""Summarise a tools/evidence_r02.sh output directory into profiles/<tag>_* (the committed evidence).
+
+usage: python tools/summarize_r02.py gpurun_out/ev_<tag> <tag>
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE count the L2's memory-side requests in
+KiB (Infinity-Cache hits included), collected in their own --pmc passes; on gfx950 FETCH_SIZE reports exactly half of a wide
+coalesced streaming read, so the read side is doubled. Counters are averaged over the forward-kernel dispatches of a pass (for
+the traffic probes: its last three)."""
+import collections, csv, glob, hashlib, json, os, re, shutil, sys
+csv.field_size_limit(1 << 30)
+src, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+os.makedirs(PROF, exist_ok=True)
+sys.path.insert(0, ROOT)
+
+
+def kernel_source_hash():
+    csrc = os.path.join(ROOT, "liteattention_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".py")):
+            h.update(name.encode() + b"\0" + open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def counters(name, last=None, kernel="la_fwd"):
+    """{counter: mean over dispatches}, {duration stats}, resources of the forward kernel in pass `name`."""
+    files = glob.glob(os.path.join(src, name, "**", "*counter_collection.csv"), recursive=True)
+    by = collections.defaultdict(dict)
+    meta = {}
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"]:
+                by[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
+                meta = {"vgpr": r["VGPR_Count"], "agpr": r["Accum_VGPR_Count"], "sgpr": r["SGPR_Count"], "lds": r["LDS_Block_Size"],
+                        "scratch": r.get("Scratch_Size", "?"), "grid": r["Grid_Size"], "wg": r["Workgroup_Size"]}
+    ids = sorted(by)
+    if last:
+        ids = ids[-last:]
+    acc = collections.defaultdict(list)
+    for i in ids:
+        for k, v in by[i].items():
+            acc[k].append(v)
+    return {k: sum(v) / len(v) for k, v in acc.items()}, meta, len(ids)
+
+
+def derived(pmc, kernel_ms=None):
+    d = {}
+    if "GRBM_GUI_ACTIVE" in pmc:
+        cyc = pmc["GRBM_GUI_ACTIVE"] / 8
+        if kernel_ms:
+            d["clock_GHz"] = cyc / (kernel_ms * 1e6)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in pmc:
+            d["mfma_util"] = pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc)
+        if "SQ_LDS_IDX_ACTIVE" in pmc:
+            d["lds_util"] = pmc["SQ_LDS_IDX_ACTIVE"] / (256 * cyc)
+    if all(k in pmc for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")):
+        tot = pmc["SQ_WAIT_ANY"] + pmc["SQ_WAIT_INST_ANY"] + pmc["SQ_ACTIVE_INST_ANY"]
+        d["wave_state_fracs_parked_stalled_issuing"] = [round(pmc[k] / tot, 4) for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")]
+    if "FETCH_SIZE" in pmc:
+        d["hbm_read_bytes"] = pmc["FETCH_SIZE"] * 2048
+    if "WRITE_SIZE" in pmc:
+        d["hbm_write_bytes"] = pmc["WRITE_SIZE"] * 1024
+    if "TCC_HIT_sum" in pmc:
+        d["l2_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
+    if "hbm_read_bytes" in d and "hbm_write_bytes" in d:
+        d["hbm_bytes_per_launch"] = d["hbm_read_bytes"] + d["hbm_write_bytes"]
+        if kernel_ms:
+            d["hbm_GBps"] = d["hbm_bytes_per_launch"] / (kernel_ms * 1e6)
+    return d
+
+
+def kernel_stats(ktdir):
+    rows = []
+    f = glob.glob(os.path.join(src, ktdir, "**", "*kernel_stats.csv"), recursive=True)
+    for r in (csv.DictReader(open(f[0])) if f else []):
+        rows.append({"name": r["Name"], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6, "min_ms": float(r["MinNs"]) / 1e6,
+                     "max_ms": float(r["MaxNs"]) / 1e6, "pct": float(r["Percentage"])})
+    return rows
+
+
+def short(n):
+    n = n.replace("void ", "")
+    return n[:100] + ("..." if len(n) > 100 else "")
+
+
+sha = kernel_source_hash()
+bench = None
+for l in open(os.path.join(src, "bench_line.json")):
+    if l.startswith('{"metric"'):
+        bench = json.loads(l)
+json.dump(bench, open(os.path.join(PROF, f"{tag}_bench_line.json"), "w"), indent=1)
+kt_line = None
+for l in open(os.path.join(src, "kt.log")):
+    if l.startswith('{"metric"'):
+        kt_line = json.loads(l)
+ks = kernel_stats("kt")
+with open(os.path.join(PROF, f"{tag}_kernel_stats.csv"), "w") as f:
+    f.write("name,calls,avg_ms,min_ms,max_ms,percent\n")
+    for r in ks:
+        f.write(f"\"{r['name']}\",{r['calls']},{r['avg_ms']:.4f},{r['min_ms']:.4f},{r['max_ms']:.4f},{r['pct']:.2f}\n")
+
+for dt in ("bf16", "fp8"):
+    kname = "la_fwd_fp8" if dt == "fp8" else "la_fwd_bf16"
+    avg_ms = next((r["avg_ms"] for r in ks if kname in r["name"]), None)
+    pmc, meta = {}, {}
+    for pas in ("mfma", "wait", "fetch", "write"):
+        c, m, n = counters(f"{dt}_{pas}", kernel=kname)
+        pmc.update(c); meta = m or meta
+    d = derived(pmc, avg_ms)
+    line = kt_line if dt == "bf16" else (kt_line or {}).get("fp8")
+    name = f"{tag}_rocprof_summary" if dt == "bf16" else f"{tag}_fp8_rocprof_summary"
+    md = [f"# rocprofv3 summary `{tag}` ({dt}), kernel sources {sha}", "",
+          "Commands (tools/evidence_r02.sh): `rocprofv3 --kernel-trace --stats -- python bench.py --no-sweep --no-cpu-baseline --steps 5 --warmup 2` "
+          f"for the kernel statistics; PMC in separate `rocprofv3 --pmc ... -- python bench.py --no-sweep --no-cpu-baseline --no-fp8 --no-verify --steps 3 --warmup 1 --dtype {dt}` passes.", ""]
+    if line:
+        md += [f"bench record under the profiler: value={line.get('value')} TFLOP/s, ms_per_step={line.get('ms_per_step')}, "
+               f"kernel_ms(HIP events)={line['roofline']['kernel_ms']}, roofline.frac={line['roofline']['frac']}; "
+               f"rocprofv3 kernel average: {avg_ms:.3f} ms" if avg_ms else "", ""]
+    md += ["## kernel stats (--kernel-trace --stats)", "", "| kernel | calls | avg ms | min ms | max ms | % |", "|---|---|---|---|---|---|"]
+    md += [f"| `{short(r['name'])}` | {r['calls']} | {r['avg_ms']:.3f} | {r['min_ms']:.3f} | {r['max_ms']:.3f} | {r['pct']:.2f} |" for r in ks[:8]]
+    md += ["", "## PMC, forward kernel, average per launch", "", "| counter | value |", "|---|---|"]
+    md += [f"| {k} | {pmc[k]:.5g} |" for k in sorted(pmc)]
+    md += ["", "## derived", ""] + [f"- {k}: {v}" for k, v in d.items()] + ["", f"kernel resources: {meta}"]
+    open(os.path.join(PROF, name + ".md"), "w").write("\n".join(md) + "\n")
+    json.dump({"tag": tag, "dtype": dt, "kernel_source_sha16": sha, "kernel_avg_ms": avg_ms, "pmc_per_launch": pmc, "derived": d,
+               "kernel_resources": meta}, open(os.path.join(PROF, name + ".json"), "w"), indent=1)
+    if "hbm_bytes_per_launch" in d:
+        json.dump({"hbm_bytes_per_launch": d["hbm_bytes_per_launch"], "kernel_source_sha16": sha, "n_gpus": 1,
+                   "source": f"profiles/{name}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)"},
+                  open(os.path.join(PROF, "pmc_summary_fp8.json" if dt == "fp8" else "pmc_summary.json"), "w"), indent=1)
+
+# ---- bytes vs sparsity
+rows = []
+for mode, arg in (("imposed", "0.0"), ("imposed", "0.42"), ("imposed", "0.77"), ("real", "-4.22"), ("real", "-2.46")):
+    n = f"traffic_{mode}_{arg}"
+    pmc = {}
+    for pas in ("fetch", "write", "busy"):
+        c, _, cnt = counters(f"{n}_{pas}", last=3, kernel="la_fwd_bf16")
+        pmc.update(c)
+    probe = None
+    logf = os.path.join(src, f"{n}_fetch.log")
+    for l in (open(logf) if os.path.exists(logf) else []):
+        m = re.search(r"PROBE .*sparsity=([0-9.]+) ms=([0-9.]+) executed_tflops=([0-9.]+)", l)
+        if m:
+            probe = tuple(float(x) for x in m.groups())
+    if not probe or not pmc:
+        continue
+    sp, ms, tf = probe
+    d = derived(pmc, ms)
+    rows.append({"list": f"{mode} {arg}", "sparsity": sp, "kernel_ms_under_pmc": ms, "executed_tflops": tf, "hbm_read_GB": d.get("hbm_read_bytes", 0) / 1e9,
+                 "hbm_write_GB": d.get("hbm_write_bytes", 0) / 1e9, "l2_hit_rate": d.get("l2_hit_rate"), "mfma_util": d.get("mfma_util"),
+                 "clock_GHz": d.get("clock_GHz"), "hbm_GBps": d.get("hbm_GBps")})
+if rows:
+    dense = rows[0]
+    md = [f"# Bytes vs sparsity `{tag}` — B1 S75600 H40 D128 bf16, kernel sources {sha}", "",
+          "`tools/traffic_probe.py` under three `rocprofv3 --pmc` passes per list (FETCH_SIZE alone; WRITE_SIZE + TCC_HIT_sum + TCC_MISS_sum; "
+          "GRBM_GUI_ACTIVE + SQ_VALU_MFMA_BUSY_CYCLES), last 3 forward dispatches of each pass. Read bytes = FETCH_SIZE KiB x 2048 "
+          "(gfx950 correction), i.e. L2 fills from the fabric (Infinity-Cache hits included); algorithmic minimum Q+K+V+O = 3.10 GB.", "",
+          "| list | sparsity s | ms | executed TFLOP/s | L2 fills GB | / dense | (1 - s) | written GB | L2 hit | MFMA busy | clock GHz | fabric GB/s |",
+          "|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    for r in rows:
+        md.append(f"| {r['list']} | {r['sparsity']:.3f} | {r['kernel_ms_under_pmc']:.2f} | {r['executed_tflops']:.0f} | {r['hbm_read_GB']:.1f} | "
+                  f"{r['hbm_read_GB'] / dense['hbm_read_GB']:.3f} | {1 - r['sparsity']:.3f} | {r['hbm_write_GB']:.2f} | {(r['l2_hit_rate'] or 0):.3f} | "
+                  f"{(r['mfma_util'] or 0):.3f} | {(r['clock_GHz'] or 0):.2f} | {(r['hbm_GBps'] or 0):.0f} |")
+    open(os.path.join(PROF, f"{tag}_traffic_vs_sparsity.md"), "w").write("\n".join(md) + "\n")
+    json.dump({"kernel_source_sha16": sha, "rows": rows}, open(os.path.join(PROF, f"{tag}_traffic_vs_sparsity.json"), "w"), indent=1)
+
+# ---- other instantiations
+md = [f"# Other instantiations `{tag}` (bf16 head_dim 64, 256, 192-on-256), kernel sources {sha}", ""]
+for t in ("d64", "d256"):
+    txt = open(os.path.join(src, f"{t}_bench.txt")).read().strip().splitlines() if os.path.exists(os.path.join(src, f"{t}_bench.txt")) else []
+    md += [f"## {t}", "", "bench (`python tools/%s_bench.py`, un-profiled):" % t, "", "```"] + [l for l in txt if "amdgpu.ids" not in l] + ["```", ""]
+    st = kernel_stats(f"{t}_kt")
+    md += ["| kernel | calls | avg ms | % |", "|---|---|---|---|"] + [f"| `{short(r['name'])}` | {r['calls']} | {r['avg_ms']:.3f} | {r['pct']:.2f} |" for r in st[:4]]
+    pmc, meta, n = counters(f"{t}_mfma")
+    avg = next((r["avg_ms"] for r in st if "la_fwd" in r["name"]), None)
+    d = derived(pmc, avg)
+    md += ["", f"PMC (all forward dispatches of the tool averaged): {json.dumps({k: round(v, 4) if isinstance(v, float) else v for k, v in d.items()})}",
+           f"kernel resources: {meta}", ""]
+open(os.path.join(PROF, f"{tag}_other_head_dims.md"), "w").write("\n".join(md) + "\n")
+print(open(os.path.join(PROF, f"{tag}_rocprof_summary.md")).read()[:3000])
