@@ -116,6 +116,44 @@ def cpu_baseline(S, D, bm, bn, rows, target_seconds=15.0):
     return res
 
 
+def denoise50(L, dev, thresholds=(("21%", -5.157), ("42%", -4.220), ("57%", -3.399), ("77%", -2.462))):
+    """Per threshold: 50 calls of LiteAttention.__call__ on the slowly varying workload; kernel time per step by HIP events.
+    Reports the sparsity of the list the LAST step read, its time against the dense kernel on the same tensors, the 50-step total,
+    and the error the skipping itself introduces at the last step (sparse vs dense kernel output; the reference publishes no
+    tolerance for sparse outputs)."""
+    from liteattention_amd.selfcheck import DenoiseWorkload
+    wl = DenoiseWorkload(40, dev)
+    ev = lambda: torch.cuda.Event(enable_timing=True)                                           # noqa: E731
+    dense_ms = []
+    for t in (0, 25, 49):
+        q, k, v = wl.qkv(t)
+        L.flash_attn_func(q, k, v)
+        e0, e1 = ev(), ev()
+        e0.record(); ref = L.flash_attn_func(q, k, v); e1.record(); torch.cuda.synchronize()
+        dense_ms.append(e0.elapsed_time(e1))
+    dense = sorted(dense_ms)[1]
+    runs = []
+    for name, thr in thresholds:
+        att = L.LiteAttention(threshold=thr, max_batch_size=1)
+        ms, last_sparsity = [], 0.0
+        for t in range(wl.steps):
+            q, k, v = wl.qkv(t)
+            if t == wl.steps - 1:
+                last_sparsity = att.get_skip_fraction(batch=1)
+            e0, e1 = ev(), ev()
+            e0.record(); out = att(q, k, v); e1.record(); torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        d = (out.float() - ref.float()).abs()          # ref = dense kernel on the step-49 tensors (same seed -> same q, k, v)
+        runs.append({"target": name, "thr": thr, "sparsity_last_step": round(last_sparsity, 4), "ms_last_step": round(ms[-1], 3),
+                     "t_last_over_dense": round(ms[-1] / dense, 3), "ideal_1_minus_s": round(1 - last_sparsity, 3),
+                     "total_ms_50_steps": round(sum(ms), 1), "speedup_vs_dense_50_steps": round(dense * wl.steps / sum(ms), 3),
+                     "max_abs_err_vs_dense": float(f"{d.max().item():.3e}"), "mean_abs_err_vs_dense": float(f"{d.mean().item():.3e}"),
+                     "mean_abs_dense_output": float(f"{ref.float().abs().mean().item():.3e}")})
+        del att, out, d
+    return {"what": "50 synthetic denoising steps, B=1 S=75600 H=40 D=128 bf16, real skip lists at fixed thresholds "
+                    "(liteattention_amd.selfcheck.DenoiseWorkload)", "dense_ms_per_step": round(dense, 3), "runs": runs}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,6 +165,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp8", action="store_true", help="skip the fp8 (configs[4]) sub-record of the 1-GPU bf16 line")
     ap.add_argument("--no-verify", action="store_true", help="skip the sampled-row check after the timed loop")
+    ap.add_argument("--no-denoise", action="store_true", help="skip the 50-step denoising run (BASELINE.json configs[2]) of the 1-GPU bf16 line")
     ap.add_argument("--overlap-windows", type=int, default=3,
                     help="N > 1: q-tile windows per step whose all-gathers overlap the next window's compute (1 = off)")
     ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
@@ -354,6 +393,14 @@ def main():
                              "roofline": f8["roofline"], "verified": f8.get("verified")}
         except Exception as e:  # noqa: BLE001
             result["fp8"] = {"value": None, "error": repr(e)}
+
+    # ---- BASELINE.json configs[2]: 50 synthetic denoising steps with REAL (fragmented, per-head) skip lists at fixed thresholds
+    # (found by bisection in round 1 for 21 / 42 / 57 / 77 % last-step sparsity with 256-row q-tiles; tools/denoise_bench.py)
+    if world == 1 and args.dtype == "bf16" and not args.no_denoise and S == 75600 and H == 40:
+        try:
+            result["denoise50"] = denoise50(L, dev)
+        except Exception as e:  # noqa: BLE001
+            result["denoise50"] = {"error": repr(e)}
 
     if world == 1 and rank == 0 and not args.no_cpu_baseline and args.dtype == "bf16":
         try:

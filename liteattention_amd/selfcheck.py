@@ -138,3 +138,41 @@ def sampled_row_check(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: to
     res["max_err_lse"] = float(f"{res['max_err_lse']:.3e}")
     res["tol"] = float(f"{res['tol']:.3e}")
     return res
+
+
+# ----------------------------------------------------------------------------------------- 50-step denoising workload
+class DenoiseWorkload:
+    """BASELINE.json configs[2]: synthetic, slowly varying, STRUCTURED q/k/v of a 50-step denoising loop at the Wan2.1 video shape
+    (iid randn gives ~0 % sparsity at any negative threshold). S = 21 frames x 3600 tokens; per head the frame centroids follow an
+    AR(1) walk (scores decay smoothly with frame distance); the last `sink` tokens are global anchor keys (QK-Skip walks keys in
+    descending order and can only drop tiles met after a row's dominant keys); step t: x_t = sqrt(1 - s_t^2) x0 + s_t n_t, s_t linear
+    0.5 -> 0.05, noise seed 10^6 + t. Generator and settings of tools/denoise_bench.py --alpha 6 --sink-gain 0.5, the settings of the
+    committed 50-step runs (profiles/r01e_denoise50.json)."""
+    FRAMES, PER, D = 21, 3600, 128
+
+    def __init__(self, heads: int, device, steps: int = 50, alpha: float = 6.0, rho: float = 0.85, sink: int = 640,
+                 sink_gain: float = 0.5, seed: int = 1234):
+        self.steps, self.device = steps, device
+        S = self.S = self.FRAMES * self.PER
+        g = torch.Generator(device=device).manual_seed(seed)
+        z = torch.randn(self.FRAMES, heads, self.D, device=device, generator=g)
+        u = torch.empty_like(z)
+        u[0] = z[0]
+        for f in range(1, self.FRAMES):
+            u[f] = rho * u[f - 1] + (1 - rho ** 2) ** 0.5 * z[f]
+        u = u / u.norm(dim=-1, keepdim=True)
+        cen = u[torch.arange(S, device=device) // self.PER]
+        q0 = alpha * cen + torch.randn(S, heads, self.D, device=device, generator=g)
+        k0 = alpha * cen + torch.randn(S, heads, self.D, device=device, generator=g)
+        anchor = u.mean(0)
+        anchor = anchor / anchor.norm(dim=-1, keepdim=True)
+        q0 = q0 + alpha * sink_gain * anchor
+        k0[S - sink:] = k0[S - sink:] + alpha * (1 + sink_gain) * anchor
+        v0 = torch.randn(S, heads, self.D, device=device, generator=g)
+        self.base = (q0[None], k0[None], v0[None])
+
+    def qkv(self, t: int):
+        s = 0.5 + (0.05 - 0.5) * t / max(1, self.steps - 1)
+        g = torch.Generator(device=self.device).manual_seed(10 ** 6 + t)
+        return [((1 - s * s) ** 0.5 * x + s * torch.randn(x.shape, device=self.device, generator=g)).to(torch.bfloat16)
+                for x in self.base]
