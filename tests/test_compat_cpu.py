@@ -46,3 +46,68 @@ def test_adapters_reject_options_outside_the_path():
         L.flash_attn_varlen_func(q[0], q[0], q[0], [0, 64], [0, 32, 64])
     with pytest.raises(ValueError):
         L.flash_blocksparse_attn_func(q, q, q, torch.ones(2, 2))
+
+
+def test_shim_import_names_and_reference_signatures():
+    """compat_shims/ (opt-in on sys.path) exposes the operator surface under the reference's own module and function names with
+    the reference's parameter lists (flash_attn/flash_attn_interface.py:998-1462, hopper/_internal/flash_attn_interface.py:487-682,
+    flash_attn/flash_blocksparse_attn_interface.py:185-200). Host-side only: nothing is launched."""
+    import importlib
+    import inspect
+    import os
+    import sys
+    shims = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "compat_shims")
+    assert importlib.util.find_spec("flash_attn") is None                     # never shadowed by accident: opt-in directory
+    sys.path.insert(0, shims)
+    try:
+        import flash_attn
+        import flash_attn_interface as fa3
+        from flash_attn import flash_blocksparse_attn_interface as bs
+        names = lambda f: list(inspect.signature(f).parameters)            # noqa: E731
+        fa2_tail = ["dropout_p", "softmax_scale", "causal", "window_size", "softcap", "alibi_slopes", "deterministic", "return_attn_probs"]
+        assert names(flash_attn.flash_attn_func) == ["q", "k", "v"] + fa2_tail
+        assert names(flash_attn.flash_attn_kvpacked_func) == ["q", "kv"] + fa2_tail
+        assert names(flash_attn.flash_attn_qkvpacked_func) == ["qkv"] + fa2_tail
+        assert names(flash_attn.flash_attn_varlen_func) == ["q", "k", "v", "cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q", "max_seqlen_k"] + fa2_tail + ["block_table"]
+        assert names(flash_attn.flash_attn_varlen_kvpacked_func) == ["q", "kv", "cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q", "max_seqlen_k"] + fa2_tail
+        assert names(flash_attn.flash_attn_varlen_qkvpacked_func) == ["qkv", "cu_seqlens", "max_seqlen"] + fa2_tail
+        assert names(fa3.flash_attn_varlen_func) == ["q", "k", "v", "cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q", "max_seqlen_k", "seqused_q",
+                                                     "seqused_k", "softmax_scale", "causal", "qv", "q_descale", "k_descale", "v_descale",
+                                                     "window_size", "attention_chunk", "softcap", "num_splits", "pack_gqa", "deterministic",
+                                                     "sm_margin"]
+        assert names(fa3.flash_attn_func)[-5:] == ["attn_read_list", "attn_must_do_list", "attn_write_list", "thr", "return_softmax_lse"]
+        assert names(bs.flash_blocksparse_attn_func) == ["qkv", "cu_seqlens", "blockmask", "dropout_p", "max_s", "softmax_scale", "causal",
+                                                         "return_attn_probs", "convert_mask"]
+        assert fa3.flash_attn_func is L.flash_attn_func and fa3.flash_attn_combine is L.flash_attn_combine
+        for fn in (flash_attn.flash_attn_with_kvcache, fa3.flash_attn_with_kvcache, fa3.get_scheduler_metadata):
+            with pytest.raises(NotImplementedError):
+                fn()
+        q = torch.zeros(64, 1, 128, dtype=torch.bfloat16)
+        with pytest.raises(NotImplementedError):
+            flash_attn.flash_attn_varlen_func(q, q, q, [0, 64], [0, 64], 64, 64, causal=True)
+        with pytest.raises(NotImplementedError):
+            fa3.flash_attn_varlen_func(q, q, q, [0, 64], [0, 64], 64, 64, seqused_k=torch.ones(1))
+        with pytest.raises((RuntimeError, NotImplementedError)):                 # CPU tensors: no fallback behind the shim either
+            flash_attn.flash_attn_varlen_func(q, q, q, [0, 64], [0, 64], 64, 64)
+    finally:
+        sys.path.remove(shims)
+        for n in [m for m in sys.modules if m == "flash_attn" or m.startswith("flash_attn.") or m == "flash_attn_interface"]:
+            del sys.modules[n]
+
+
+def test_build_rejects_scratch_in_the_x64_kernels():
+    """build.py::_check_no_scratch: the x64 kernels (an asm body that clobbers nearly the whole register file inside a C++ shell) must
+    not spill — hipcc has placed such spill stores where EXEC is 0 ('A compiler hazard')."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("la_build_t", os.path.join(os.path.dirname(L.__file__), "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    ok = ("f.hip:1:1: remark: Function Name: _ZN2la27la_fwd_bf16_d128_x64_kernelILb1EEEvNS_9FwdParamsE [-Rpass]\n"
+          "f.hip:1:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass]\n"
+          "f.hip:1:1: remark: Function Name: _ZN2la21la_fwd_bf16_v2_kernelILi256ELb1EEEvNS_9FwdParamsE [-Rpass]\n"
+          "f.hip:1:1: remark:     ScratchSize [bytes/lane]: 272 [-Rpass]\n")
+    b._check_no_scratch(ok, ())                                                  # the hipcc-scheduled 128-row kernels may spill
+    bad = ok.replace("ScratchSize [bytes/lane]: 0", "ScratchSize [bytes/lane]: 48")
+    with pytest.raises(RuntimeError, match="must not spill"):
+        b._check_no_scratch(bad, ())
