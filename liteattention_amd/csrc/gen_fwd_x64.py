@@ -705,6 +705,10 @@ def epilogue():
 def main():
     prologue()
     loop, done = new_label("loop"), new_label("done")
+    if opt_val("align", ""):                                   # code-placement experiments: see DESIGN.md section 4.2
+        out.append(f".p2align {opt_val('align', '')}")
+    for _ in range(int(opt_val("pad4", "0"))):
+        emit("s_nop 0")
     label(loop)
     emit(f"s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}")
     emit(f"s_cbranch_scc0 {done}")

@@ -40,7 +40,9 @@ def opt_val(key, default):
     return default
 
 
-XPAIRS = int(opt_val("x", "5"))          # pair-groups (of 16) done in phase 2
+XPAIRS = int(opt_val("x", "4"))          # pair-groups (of 16) done in phase 2. EVEN: two pair-groups share one packed-e4m3 destination register
+                                          # (lo / hi half by op_sel); an odd split leaves a half-written register across the phase boundary
+                                          # (measured x = 2 / 4: 2078-2101 TFLOP/s at 42 %, x = 3 / 5 / 6: 2048-2065)
 NG = 8                                    # MFMAs (gaps) per phase
 TAU = 2.0                                 # lazy-rescale slack in log2 units (must match the shell: param[22] = TAU / c)
 P_OFFSET = 8.0 - TAU
@@ -406,7 +408,7 @@ def step(variant):
         post[g].append(op)
     for f, (db, t) in enumerate([(db, t) for db in range(4) for t in (0, 1)]):
         post[4 + f // 2].append(v_read(vbuf_cur, db, t))
-    distribute(softmax_stream(cur, list(range(XPAIRS, 16))), post, 0)
+    distribute(softmax_stream(cur, list(range(XPAIRS, 16))), post, int(opt_val("smstart", "0")))
     for t in range(NG):
         out.append(mf[t])
         out.extend(post[t])
@@ -652,6 +654,10 @@ def epilogue():
 def main():
     prologue()
     loop, done = new_label("loop"), new_label("done")
+    if opt_val("align", ""):                                   # code-placement experiments: see DESIGN.md section 4.2
+        out.append(f".p2align {opt_val('align', '')}")
+    for _ in range(int(opt_val("pad4", "0"))):
+        emit("s_nop 0")
     label(loop)
     emit(f"s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}")
     emit(f"s_cbranch_scc0 {done}")
