@@ -45,7 +45,7 @@ def opt_val(key, default):
 XPAIRS = int(opt_val("x", "5"))          # pair-groups (of 16; one group = the same pair of both q-blocks) done in phase 2
 CAP1 = int(opt_val("cap1", "0"))          # fillers per MFMA gap the distributor may place (0 = balance evenly)
 CAP2 = int(opt_val("cap2", "0"))
-DMA_GAPS = [int(x) for x in opt_val("dmagaps", "1,2,4,6,8,10,11,13,15,17").split(",")]   # m0K,K0..3,m0V,V0..3 (phase 1)
+DMA_GAPS = [int(x) for x in opt_val("dmagaps", "1,2,4,6,8,10,11,13,15,17").replace(".", ",").split(",")]   # m0K,K0..3,m0V,V0..3 (phase 1)
 
 # ---------------------------------------------------------------- AGPR map
 def O_(qb, db):

@@ -46,7 +46,7 @@ XPAIRS = int(opt_val("x", "4"))          # pair-groups (of 16) done in phase 2. 
 NG = 8                                    # MFMAs (gaps) per phase
 TAU = 2.0                                 # lazy-rescale slack in log2 units (must match the shell: param[22] = TAU / c)
 P_OFFSET = 8.0 - TAU
-DMA_GAPS = [int(x) for x in opt_val("dmagaps", "0,1,1,2,3,3").split(",")]   # m0K,K0,K1,m0V,V0,V1 (phase 1 gaps; an M0 write is never adjacent to its first use)
+DMA_GAPS = [int(x) for x in opt_val("dmagaps", "0,1,1,2,3,3").replace(".", ",").split(",")]   # m0K,K0,K1,m0V,V0,V1 (phase 1 gaps; an M0 write is never adjacent to its first use)
 
 
 # ---------------------------------------------------------------- AGPR map

@@ -295,14 +295,18 @@ __device__ __forceinline__ int expand_read_list(const int* __restrict__ row, int
         // short ranges (the common case of real lists: hundreds of ranges of a few tiles): the lane writes its own tiles;
         // the rest of a LONG range (imposed bands, early denoising steps: 1-2 ranges of hundreds of tiles, which one lane
         // would write one LDS store at a time: 16 k cycles per item, tools/phase_profile.py) is filled by the whole wave
+        // (all loops here have wave-uniform trip counts with predicated bodies: la_fwd_kernel_x64.hip, "COMPILER HAZARD")
         constexpr int kOwn = 4;
-        for (int j = 0; j < min(cnt, kOwn); ++j) seq[first + j] = start - j;
+#pragma unroll
+        for (int j = 0; j < kOwn; ++j)
+            if (j < cnt) seq[first + j] = start - j;
         unsigned long long longs = __ballot(cnt > kOwn);
         while (longs) {
             const int src = __builtin_ctzll(longs);
             longs &= longs - 1;
             const int f = __shfl(first, src), s0 = __shfl(start, src), c = __shfl(cnt, src);
-            for (int j = kOwn + lane; j < c; j += 64) seq[f + j] = s0 - j;
+            for (int j0 = kOwn; j0 < c; j0 += 64)
+                if (j0 + lane < c) seq[f + j0 + lane] = s0 - (j0 + lane);
         }
         if (cnt > 0) atomicOr(&endflags[(first + cnt - 1) >> 5], 1u << ((first + cnt - 1) & 31));
         pos = min(pos + __shfl(incl, 63), k_tiles);
