@@ -73,6 +73,42 @@ class WanLikeSelfAttention(nn.Module):
         return self.o(x.float().flatten(2))
 
 
+class WanLikeCrossAttention(nn.Module):
+    """The text-conditioning attention of a Wan2.x block as the stock pipeline writes it: its `flash_attention()` wrapper imports
+    `flash_attn` / `flash_attn_interface` and calls `flash_attn_varlen_func` on packed (total, H, D) tensors with `cu_seqlens`
+    because the prompts of a batch have different lengths. With `compat_shims/` on the path those imports resolve to the gfx950
+    kernel: one dense launch for the whole ragged batch, no host sync."""
+
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads, self.head_dim = num_heads, dim // num_heads
+        self.q, self.k, self.v, self.o = (nn.Linear(dim, dim) for _ in range(4))
+        self.norm_q, self.norm_k = RMSNorm(dim), RMSNorm(dim)
+
+    def forward(self, x, context, context_lens):
+        import flash_attn_interface                                 # FA3 name, served by compat_shims/flash_attn_interface.py
+        b, s, n, d = *x.shape[:2], self.num_heads, self.head_dim
+        q = self.norm_q(self.q(x)).view(b * s, n, d).bfloat16()
+        lens = [int(l) for l in context_lens]
+        k = torch.cat([self.norm_k(self.k(context[i, :l])) for i, l in enumerate(lens)]).view(-1, n, d).bfloat16()
+        v = torch.cat([self.v(context[i, :l]) for i, l in enumerate(lens)]).view(-1, n, d).bfloat16()
+        cu_q = torch.arange(0, (b + 1) * s, s, dtype=torch.int32, device=x.device)
+        cu_k = torch.tensor([0] + lens, device=x.device).cumsum(0).to(torch.int32)
+        out = flash_attn_interface.flash_attn_varlen_func(q, k, v, cu_q, cu_k, s, max(lens))
+        return self.o(out.view(b, s, n * d).float())
+
+    def reference(self, x, context, context_lens):
+        b, s, n, d = *x.shape[:2], self.num_heads, self.head_dim
+        q = self.norm_q(self.q(x)).view(b, s, n, d).bfloat16().float()
+        outs = []
+        for i, l in enumerate(int(l) for l in context_lens):
+            k = self.norm_k(self.k(context[i, :l])).view(l, n, d).bfloat16().float()
+            v = self.v(context[i, :l]).view(l, n, d).bfloat16().float()
+            p = torch.softmax(torch.einsum("qhd,khd->hqk", q[i], k) * d ** -0.5, -1)
+            outs.append(torch.einsum("hqk,khd->qhd", p, v).reshape(s, n * d))
+        return self.o(torch.stack(outs))
+
+
 def run(frames=5, height=16, width=16, heads=4, steps=6, threshold=-6.0, seed=0, device="cuda", verbose=True):
     torch.manual_seed(seed)
     dim, grid = heads * 128, (frames, height, width)

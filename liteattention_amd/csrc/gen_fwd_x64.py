@@ -92,6 +92,7 @@ TBS, VBS = [S_TB, S_TB2], [S_VB, S_VB2]
 
 KV_TILE = 16384
 V_REGION = 32768
+DMA_POLICY = {"": "", "nt": " nt", "sc0": " sc0", "sc1": " sc1"}[opt_val("dmapol", "")]    # cache-policy experiments on the K/V stream
 DMA_BIAS = 3072           # S_KBASE / S_VBASE hold (tensor base - DMA_BIAS); LK / LV[j] hold (+DMA_BIAS - 1024 j): see dma_ops
 
 out = []          # IR: str | ("LDS", str, tag) | ("WAIT", tag) | ("DRAIN",)
@@ -387,10 +388,10 @@ def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True, st=0):
     o = []
     if do_k:
         o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {kbuf_imm}")
-        o += [f"    global_load_lds_dwordx4 {v(LK[j])}, {sr(TBS[st])} offset:{1024 * j}" for j in range(4)]
+        o += [f"    global_load_lds_dwordx4 {v(LK[j])}, {sr(TBS[st])} offset:{1024 * j}{DMA_POLICY}" for j in range(4)]
     if do_v:
         o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {V_REGION + vbuf_imm}")
-        o += [f"    global_load_lds_dwordx4 {v(LV[j])}, {sr(VBS[st])} offset:{1024 * j}" for j in range(4)]
+        o += [f"    global_load_lds_dwordx4 {v(LV[j])}, {sr(VBS[st])} offset:{1024 * j}{DMA_POLICY}" for j in range(4)]
     return o
 
 

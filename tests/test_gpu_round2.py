@@ -417,3 +417,37 @@ def test_race_screen_1000_iterations(path):
         out, lse = run()
         assert torch.equal(out, out0) and torch.equal(lse, lse0) and torch.equal(att._skip_list, lists0), it
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------ malformed lists
+@pytest.mark.parametrize("dtype,D", [("bf16", 128), ("fp8", 128), ("bf16", 64)])
+def test_garbage_read_lists_are_memory_safe(dtype, D):
+    """The read list is caller-owned memory: whatever it holds (negative or huge tile numbers, ascending or overlapping ranges,
+    a length word beyond the row, zeros), the kernel must stay inside q / k / v / the write list - tile numbers are clamped to
+    [0, Kt), the walk to Kt positions (la_fwd_common.h expand_read_list) - and produce finite numbers. Ragged Sq and Sk, so the
+    clamped last tile turns up at positions other than the first. The write list sits between guard words."""
+    import liteattention_amd as L
+    es = 1 if dtype == "fp8" else 2
+    bm, bn = _tiles(D, es)
+    B, Sq, Sk, H = 2, 1000, 1250, 3
+    qt, kt = math.ceil(Sq / bm), math.ceil(Sk / bn)
+    g = torch.Generator().manual_seed(D + es)
+    cast = (lambda x: x.to(torch.float8_e4m3fn)) if dtype == "fp8" else (lambda x: x.bfloat16())
+    q, k, v = [cast(torch.randn(B, s_, H, D, generator=g)).cuda() for s_ in (Sq, Sk, Sk)]
+    rows = B * H * qt
+    kinds = [torch.randint(-2 ** 31, 2 ** 31 - 1, (rows, kt + 1), generator=g, dtype=torch.int64),       # anything at all
+             torch.randint(-5, kt + 5, (rows, kt + 1), generator=g, dtype=torch.int64),                  # nearly valid numbers, no order
+             torch.zeros(rows, kt + 1, dtype=torch.int64)]                                               # len 0, all tile 0
+    asc = torch.arange(kt + 1).repeat(rows, 1)                                                           # ascending "ranges", len = Kt + 7
+    asc[:, 0] = kt + 7
+    kinds.append(asc)
+    for read in kinds:
+        read = read.to(torch.int32).view(B, H, qt, kt + 1).cuda()
+        guard = torch.full((rows * (kt + 1) + 64,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+        write = guard[32: 32 + rows * (kt + 1)].view(B, H, qt, kt + 1)
+        for thr in (-2.0, float("inf")):
+            out, lse = L.flash_attn_func(q, k, v, attn_read_list=read, attn_write_list=write, thr=thr, return_softmax_lse=True)
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(out.float()).all()) and not bool(torch.isnan(lse).any())
+            assert bool((guard[:32] == 0x5A5A5A5A).all()) and bool((guard[-32:] == 0x5A5A5A5A).all())
+            assert int(write[..., 0].min()) >= 0 and int(write[..., 0].max()) <= kt

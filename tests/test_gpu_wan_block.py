@@ -22,6 +22,27 @@ def test_wan_style_block_runs_and_skipping_stays_close_to_dense():
     assert rows[-1][1] == 0.0 and rows[-1][2] < 1e-6
 
 
+def test_wan_cross_attention_through_the_flash_attn_import_names():
+    """The text cross-attention of the block: ragged prompt lengths, packed tensors, `import flash_attn_interface` from compat_shims/."""
+    import torch
+    import wan_self_attention_demo as demo
+    shims = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "compat_shims")
+    sys.path.insert(0, shims)
+    try:
+        torch.manual_seed(0)
+        blk = demo.WanLikeCrossAttention(3 * 128, 3).cuda()
+        x = torch.randn(2, 700, 3 * 128, device="cuda")
+        ctx = torch.randn(2, 512, 3 * 128, device="cuda")
+        lens = [77, 512]
+        with torch.no_grad():
+            y, y_ref = blk(x, ctx, lens), blk.reference(x, ctx, lens)
+        assert (y - y_ref).abs().max().item() <= 2e-2 * y_ref.abs().max().item()
+    finally:
+        sys.path.remove(shims)
+        for n in [m for m in sys.modules if m == "flash_attn" or m.startswith("flash_attn.") or m == "flash_attn_interface"]:
+            del sys.modules[n]
+
+
 def test_two_steps_capture_into_a_hip_graph_and_replay():
     """HIP graphs instead of a tracing compiler: `LiteAttention.__call__` makes no host sync and allocates only through
     torch's allocator, so a PAIR of denoising steps (one per ping-pong phase) captures into one graph; every replay
