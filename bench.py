@@ -47,13 +47,13 @@ from liteattention_amd.selfcheck import (banded_rows, executed_flops, impose_lis
 
 
 def kernel_source_hash() -> str:
-    """sha256[:16] over the kernel sources: `roofline.traffic` is taken from a committed PMC summary only when that
-    summary was measured on exactly these sources (a stale byte count is worse than null)."""
+    """sha256[:16] over the kernel code (HIP sources, headers and the generated asm bodies): `roofline.traffic` is taken from a
+    committed PMC summary only when that summary was measured on exactly this code (a stale byte count is worse than null)."""
     import hashlib
     csrc = os.path.join(ROOT, "liteattention_amd", "csrc")
     h = hashlib.sha256()
     for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".h", ".py")):
+        if name.endswith((".hip", ".h", ".inc")):      # .inc = the generated asm bodies (the build writes them)
             with open(os.path.join(csrc, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

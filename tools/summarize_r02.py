@@ -19,7 +19,7 @@ def kernel_source_hash():
     csrc = os.path.join(ROOT, "liteattention_amd", "csrc")
     h = hashlib.sha256()
     for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".h", ".py")):
+        if name.endswith((".hip", ".h", ".inc")):      # .inc = the generated asm bodies (the build writes them)
             h.update(name.encode() + b"\0" + open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()[:16]
 
