@@ -72,7 +72,7 @@ typedef enum la_status {
 
 typedef enum la_dtype {
     LA_DTYPE_BF16 = 0,
-    LA_DTYPE_FP16 = 1,           /* reserved: not built in this round                             */
+    LA_DTYPE_FP16 = 1,           /* q/k/v/o fp16; every path of LA_DTYPE_BF16 (lists, varlen, flags) */
     LA_DTYPE_FP8_E4M3 = 2        /* OCP e4m3fn (gfx950), bf16 output                              */
 } la_dtype;
 
@@ -180,11 +180,11 @@ int la_skip_list_stats(const int32_t* list, int32_t n_batch, int32_t num_heads, 
                        int32_t k_tiles, int64_t* out_counts, void* stream);
 
 /* LSE-weighted merge of `num_splits` partial attention results (sequence-parallel K/V splits):
- *   o_partial   fp32 or bf16 [num_splits, B, Sq, H, Dv] contiguous (partial_is_bf16 selects)
+ *   o_partial   [num_splits, B, Sq, H, Dv] contiguous: fp32, or (partial_is_16bit != 0) the element type of o
  *   lse_partial fp32 [num_splits, B, H, Sq] contiguous
- *   o bf16 [B,Sq,H,Dv] contiguous, lse fp32 [B,H,Sq] (may be NULL). */
-int la_combine(const void* o_partial, int32_t partial_is_bf16, const float* lse_partial,
-               void* o, float* lse, int32_t num_splits, int32_t batch, int32_t seqlen_q,
+ *   o [B,Sq,H,Dv] contiguous of o_dtype (LA_DTYPE_BF16 or LA_DTYPE_FP16), lse fp32 [B,H,Sq] (may be NULL). */
+int la_combine(const void* o_partial, int32_t partial_is_16bit, const float* lse_partial,
+               void* o, int32_t o_dtype, float* lse, int32_t num_splits, int32_t batch, int32_t seqlen_q,
                int32_t num_heads, int32_t head_dim_v, void* stream);
 
 const char* la_status_string(int status);

@@ -119,7 +119,7 @@ def load() -> ctypes.CDLL:
     lib.la_skip_list_stats.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                        ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
     lib.la_skip_list_stats.restype = ctypes.c_int
-    lib.la_combine.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+    lib.la_combine.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                ctypes.c_void_p]
     lib.la_combine.restype = ctypes.c_int

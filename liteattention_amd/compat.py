@@ -265,7 +265,7 @@ def flash_blocksparse_attn_qkvpacked_func(qkv, cu_seqlens, blockmask, dropout_p,
     if tuple(blockmask.shape) != (-(-max_s // bm), -(-max_s // bn)):
         raise ValueError(f"blockmask must be [{-(-max_s // bm)}, {-(-max_s // bn)}] for max_s={max_s} and tiles ({bm}, {bn})")
     mask = convert_blockmask(blockmask, causal) if convert_mask else blockmask.to(torch.bool)
-    out = torch.empty((qkv.shape[0], H, D), dtype=torch.bfloat16, device=qkv.device)
+    out = torch.empty((qkv.shape[0], H, D), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((H, qkv.shape[0]), dtype=torch.float32, device=qkv.device) if return_attn_probs else None
     for b in range(len(cu) - 1):
         t0, t1 = cu[b], cu[b + 1]

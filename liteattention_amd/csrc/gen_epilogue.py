@@ -22,6 +22,7 @@ def store_epilogue(g, o_reg):
     S_PARAM, S_SEQLENQ, S_EXEC, S_T64 = g["S_PARAM"], g["S_SEQLENQ"], g["S_EXEC"], g["S_T64"]
     # the loop's DMA-base registers are dead here: O base, LSE base and the scalars live in them
     S_OBASE, S_LSEB, S_ORS, S_CLN2, S_OSCALE, S_LSEADD = g["S_TB"], g["S_VB"], g["S_T0"], g["S_T1"], g["S_T2"], g["S_T3"]
+    cvt = g.get("CVT_OP", "v_cvt_pk_bf16_f32")                 # the 16-bit output type follows the inputs (fp8 inputs: bf16)
     HH16 = g["MLOC"][0]                                        # dead after the loop: hh * 16 bytes
     emit("; ---- finalize + store O (bf16) and LSE straight from the accumulators")
     emit(f"v_mov_b32 {v(T[0])}, {s(S_PARAM)}")
@@ -77,7 +78,7 @@ def store_epilogue(g, o_reg):
         def stage_pack(i):
             r = 8 * (i % 2)
             return [f"v_mul_f32 {v(r + k)}, {v(r + k)}, {v(T[2])}" for k in range(8)] + \
-                   [f"v_cvt_pk_bf16_f32 {v(r + k)}, {v(r + 2 * k)}, {v(r + 2 * k + 1)}" for k in range(4)]
+                   [f"{cvt} {v(r + k)}, {v(r + 2 * k)}, {v(r + 2 * k + 1)}" for k in range(4)]
 
         def stage_store(i):
             db, t = pairs[i]

@@ -42,6 +42,11 @@ def opt_val(key, default):
     return default
 
 
+# 16-bit element type of Q / K / V / P / O: "bf16" (default) or "f16" (LA_X64_DTYPE; the build generates one body per type). Only the
+# MFMA opcode and the fp32 -> 16-bit pack differ: the fragment layout, the transpose reads and the schedule are type-agnostic.
+DTYPE = os.environ.get("LA_X64_DTYPE", "bf16")
+MFMA_OP = {"bf16": "v_mfma_f32_32x32x16_bf16", "f16": "v_mfma_f32_32x32x16_f16"}[DTYPE]
+CVT_OP = {"bf16": "v_cvt_pk_bf16_f32", "f16": "v_cvt_pk_f16_f32"}[DTYPE]          # both round to nearest even
 XPAIRS = int(opt_val("x", "5"))          # pair-groups (of 16; one group = the same pair of both q-blocks) done in phase 2
 CAP1 = int(opt_val("cap1", "0"))          # fillers per MFMA gap the distributor may place (0 = balance evenly)
 CAP2 = int(opt_val("cap2", "0"))
@@ -172,13 +177,13 @@ def mfma_qk(sset, j, qb):
     kb, ks = j >> 3, j & 7
     d = S_(sset, kb, qb)
     c = "0" if ks == 0 else vr(d, 16)
-    return f"    v_mfma_f32_32x32x16_bf16 {vr(d, 16)}, {ar(KA(j), 4)}, {ar(QA(qb, ks), 4)}, {c}"
+    return f"    {MFMA_OP} {vr(d, 16)}, {ar(KA(j), 4)}, {ar(QA(qb, ks), 4)}, {c}"
 
 
 def mfma_pv(sset, slot, m, qb):
     db, kk = m >> 2, m & 3
     pf = S_(sset, kk >> 1, qb) + 8 * (kk & 1)
-    return f"    v_mfma_f32_32x32x16_bf16 {ar(O_(qb, db), 16)}, {vr(VF[slot], 4)}, {vr(pf, 4)}, {ar(O_(qb, db), 16)}"
+    return f"    {MFMA_OP} {ar(O_(qb, db), 16)}, {vr(VF[slot], 4)}, {vr(pf, 4)}, {ar(O_(qb, db), 16)}"
 
 
 PK = "pk" in OPT           # packed-fp32 VALU (v_pk_fma_f32 / v_pk_add_f32). MEASURED ANTI-LEVER beside MFMAs: -64 issue slots
@@ -205,7 +210,7 @@ def softmax_parts(sset, p):
             F.append([f"    v_fma_f32 {v(ta)}, {v(r0)}, {s(S_C)}, {v(NMS[qb])}", f"    v_fma_f32 {v(tb)}, {v(r1)}, {s(S_C)}, {v(NMS[qb])}"])
             A.append([f"    v_add_f32 {v(L0[qb])}, {v(L0[qb])}, {v(r0)}", f"    v_add_f32 {v(L1[qb])}, {v(L1[qb])}, {v(r1)}"])
         E.append([f"    v_exp_f32 {v(r0)}, {v(ta)}", f"    v_exp_f32 {v(r1)}, {v(tb)}"])
-        C.append([f"    v_cvt_pk_bf16_f32 {v(dst)}, {v(r0)}, {v(r1)}"])
+        C.append([f"    {CVT_OP} {v(dst)}, {v(r0)}, {v(r1)}"])
     return F, E, A, C
 
 

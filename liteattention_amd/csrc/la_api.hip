@@ -39,7 +39,7 @@ const char* la_status_string(int status) {
         case LA_OK: return "ok";
         case LA_ERR_NULL_ARG: return "required pointer is NULL";
         case LA_ERR_STRUCT_SIZE: return "la_fwd_args.struct_size mismatch (ABI version skew)";
-        case LA_ERR_DTYPE: return "FlashAttention only supports fp16, bf16, and fp8_e4m3 type; this build instantiates bf16";
+        case LA_ERR_DTYPE: return "FlashAttention only supports fp16, bf16, and fp8_e4m3 type; this build instantiates all three";
         case LA_ERR_HEAD_DIM: return "head_size not instantiated in this build (bf16: 64, 128, 256; fp8: 128)";
         case LA_ERR_SHAPE: return "invalid shape (batch, seqlen_q, heads and head_dim must be positive; number of heads in key/value must divide number of heads in query)";
         case LA_ERR_STRIDE: return "Input tensor must have contiguous last dimension and 16-byte aligned rows";
@@ -72,7 +72,7 @@ int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n
 int64_t la_fwd_workspace_bytes(const la_fwd_args* a) {
     if (a == nullptr) return LA_ERR_NULL_ARG;
     if (a->struct_size != sizeof(la_fwd_args)) return LA_ERR_STRUCT_SIZE;
-    if (a->dtype == LA_DTYPE_BF16)      // ticket counters of the dynamic work distribution (launches with lists)
+    if (a->dtype == LA_DTYPE_BF16 || a->dtype == LA_DTYPE_FP16)      // ticket counters of the dynamic work distribution (launches with lists)
         return (a->read_list != nullptr && !(a->flags & LA_FLAG_STATIC_SCHED)) ? static_cast<int64_t>(kSchedWorkspaceBytes) : 0;
     if (a->dtype != LA_DTYPE_FP8_E4M3) return LA_ERR_DTYPE;
     int bm = 0, bn = 0;
@@ -87,8 +87,9 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (a == nullptr) return LA_ERR_NULL_ARG;
     if (a->struct_size != sizeof(la_fwd_args)) return LA_ERR_STRUCT_SIZE;
-    if (a->dtype != LA_DTYPE_BF16 && a->dtype != LA_DTYPE_FP8_E4M3) return LA_ERR_DTYPE;   // flash_api.cpp:715
+    if (a->dtype != LA_DTYPE_BF16 && a->dtype != LA_DTYPE_FP16 && a->dtype != LA_DTYPE_FP8_E4M3) return LA_ERR_DTYPE;   // flash_api.cpp:715
     const bool fp8 = a->dtype == LA_DTYPE_FP8_E4M3;
+    const bool f16 = a->dtype == LA_DTYPE_FP16;      // same kernels as bf16 with the fp16 MFMA and conversions
     const int esize = fp8 ? 1 : 2;
     if (!a->q || !a->o || ((!a->k || !a->v) && a->seqlen_k != 0)) return LA_ERR_NULL_ARG;   // empty K/V tensors may be NULL
     if (a->batch <= 0 || a->seqlen_q <= 0 || a->seqlen_k < 0 || a->num_heads <= 0 || a->num_heads_k <= 0 ||
@@ -206,9 +207,9 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         p.work_counter = static_cast<unsigned*>(a->workspace);
     if (x64) {
         if (la::fwd_lds_bytes_x64(p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
-        err = la::launch_fwd_bf16_d128_x64(p, skipable, stream);
+        err = la::launch_fwd_bf16_d128_x64(p, skipable, f16, stream);
     } else {
-        err = la::launch_fwd_bf16_v2(p, a->head_dim, skipable, stream);
+        err = la::launch_fwd_bf16_v2(p, a->head_dim, skipable, f16, stream);
     }
     if (err != hipSuccess) {
         g_last_hip_error = static_cast<int>(err);
@@ -229,14 +230,15 @@ int la_skip_list_stats(const int32_t* list, int32_t n_batch, int32_t num_heads, 
     return LA_OK;
 }
 
-int la_combine(const void* o_partial, int32_t partial_is_bf16, const float* lse_partial, void* o, float* lse,
+int la_combine(const void* o_partial, int32_t partial_is_16bit, const float* lse_partial, void* o, int32_t o_dtype, float* lse,
                int32_t num_splits, int32_t batch, int32_t seqlen_q, int32_t num_heads, int32_t head_dim_v,
                void* stream_) {
     if (!o_partial || !lse_partial || !o) return LA_ERR_NULL_ARG;
+    if (o_dtype != LA_DTYPE_BF16 && o_dtype != LA_DTYPE_FP16) return LA_ERR_DTYPE;
     if (num_splits <= 0 || batch <= 0 || seqlen_q <= 0 || num_heads <= 0 || head_dim_v <= 0) return LA_ERR_SHAPE;
     if (head_dim_v % 8 != 0) return LA_ERR_HEAD_DIM;
     if (!aligned16(o_partial) || !aligned16(o)) return LA_ERR_STRIDE;
-    const hipError_t err = la::launch_combine(o_partial, partial_is_bf16 != 0, lse_partial, static_cast<uint16_t*>(o), lse,
+    const hipError_t err = la::launch_combine(o_partial, partial_is_16bit != 0, o_dtype == LA_DTYPE_FP16, lse_partial, static_cast<uint16_t*>(o), lse,
                                               num_splits, batch, seqlen_q, num_heads, head_dim_v,
                                               static_cast<hipStream_t>(stream_));
     if (err != hipSuccess) { g_last_hip_error = static_cast<int>(err); return LA_ERR_LAUNCH; }

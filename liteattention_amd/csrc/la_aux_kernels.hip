@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "la_fwd_common.h"
 #include "la_kernel_params.h"
 
 namespace la {
@@ -83,7 +84,7 @@ hipError_t launch_empty_k_fill(uint16_t* o, float* lse, int64_t o_batch_stride, 
 }
 
 // One thread = 8 consecutive d of one (b, s, h) row. Memory-bound; 16-byte accesses.
-template <bool PARTIAL_BF16>
+template <bool PARTIAL_16BIT, bool F16>     // 16-bit partials have the element type of o (bf16, or fp16 when F16)
 __global__ void __launch_bounds__(256) combine_kernel(const void* __restrict__ o_partial,
                                                        const float* __restrict__ lse_partial,
                                                        uint16_t* __restrict__ o, float* __restrict__ lse_out,
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(256) combine_kernel(const void* __restrict__ o
                                                        int dv) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x8 __attribute__((ext_vector_type(8)));
-    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    typedef typename Elem16<F16>::x8 ex8;
     const int chunks = dv / 8;
     const int64_t total = static_cast<int64_t>(batch) * seqlen_q * num_heads * chunks;
     const int64_t split_elems = static_cast<int64_t>(batch) * seqlen_q * num_heads * dv;
@@ -116,8 +117,8 @@ __global__ void __launch_bounds__(256) combine_kernel(const void* __restrict__ o
             denom += w;
             const int64_t off = sp * split_elems + row * dv + ch * 8;
             f32x8 x;
-            if (PARTIAL_BF16) {
-                const bf16x8 t = *reinterpret_cast<const bf16x8*>(static_cast<const uint16_t*>(o_partial) + off);
+            if (PARTIAL_16BIT) {
+                const ex8 t = *reinterpret_cast<const ex8*>(static_cast<const uint16_t*>(o_partial) + off);
                 x = __builtin_convertvector(t, f32x8);
             } else {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(static_cast<const float*>(o_partial) + off);
@@ -128,12 +129,19 @@ __global__ void __launch_bounds__(256) combine_kernel(const void* __restrict__ o
         }
         const float inv = denom > 0.f ? 1.f / denom : 0.f;
         acc *= inv;
-        *reinterpret_cast<bf16x8*>(o + row * dv + ch * 8) = __builtin_convertvector(acc, bf16x8);
+        *reinterpret_cast<ex8*>(o + row * dv + ch * 8) = __builtin_convertvector(acc, ex8);
         if (lse_out != nullptr && ch == 0) lse_out[lse_idx] = denom > 0.f ? m_safe + __logf(denom) : -INFINITY;
     }
 }
 
-hipError_t launch_combine(const void* o_partial, bool partial_is_bf16, const float* lse_partial, uint16_t* o,
+template <bool P16, bool F16>
+static void launch_combine_t(unsigned blocks, hipStream_t stream, const void* o_partial, const float* lse_partial, uint16_t* o,
+                             float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v) {
+    hipLaunchKernelGGL((combine_kernel<P16, F16>), dim3(blocks), dim3(256), 0, stream, o_partial, lse_partial, o, lse, num_splits,
+                       batch, seqlen_q, num_heads, head_dim_v);
+}
+
+hipError_t launch_combine(const void* o_partial, bool partial_is_16bit, bool f16, const float* lse_partial, uint16_t* o,
                           float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v,
                           hipStream_t stream) {
     const int64_t total = static_cast<int64_t>(batch) * seqlen_q * num_heads * (head_dim_v / 8);
@@ -141,12 +149,15 @@ hipError_t launch_combine(const void* o_partial, bool partial_is_bf16, const flo
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
     (void)hipGetLastError();
-    if (partial_is_bf16)
-        hipLaunchKernelGGL(combine_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, o_partial,
-                           lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v);
+    const unsigned g = static_cast<unsigned>(blocks);
+    if (partial_is_16bit && f16)
+        launch_combine_t<true, true>(g, stream, o_partial, lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v);
+    else if (partial_is_16bit)
+        launch_combine_t<true, false>(g, stream, o_partial, lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v);
+    else if (f16)
+        launch_combine_t<false, true>(g, stream, o_partial, lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v);
     else
-        hipLaunchKernelGGL(combine_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, o_partial,
-                           lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v);
+        launch_combine_t<false, false>(g, stream, o_partial, lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v);
     return hipGetLastError();
 }
 

@@ -16,6 +16,25 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// The 16-bit element type of Q / K / V / P / O: bf16 or fp16 (flash_api.cpp:715 accepts both). Only the MFMA opcode and the
+// fp32 -> 16-bit conversions (round to nearest even in both) differ; fragment layouts and LDS images are type-agnostic.
+template <bool F16> struct Elem16;
+template <> struct Elem16<false> {
+    typedef bf16x8 x8;
+    typedef bf16x4 x4;
+    static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Elem16<true> {
+    typedef f16x8 x8;
+    typedef f16x4 x4;
+    static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

@@ -71,9 +71,12 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
 
 }  // namespace
 
-template <int D, bool SKIPABLE>
+template <int D, bool SKIPABLE, bool F16>
 __global__ void __launch_bounds__(256, D > 128 ? 1 : 2)      // head_dim 256: O 128 + Q 64 + S 64 registers -> one wave per SIMD
-la_fwd_bf16_v2_kernel(const FwdParams p) {
+la_fwd_bf16_v2_kernel(const FwdParams p) {                   // (the name is historical: F16 selects fp16 instead of bf16 elements)
+    typedef Elem16<F16> E;
+    typedef typename E::x8 ex8;
+    typedef typename E::x4 ex4;
     constexpr int BM = 128;
     constexpr int ROW_BYTES = D * 2;                 // 256 / 128
     constexpr int TILE_BYTES = BN * ROW_BYTES;       // 16 / 8 KiB
@@ -154,7 +157,7 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
 
     // ---- Q fragments (B operand of S^T = K Q^T): query row l31, d = 16*ks + 8*hh + [0,8)
     const int q_row = m_block * BM + wave * 32 + l31;
-    bf16x8 qf[KS];
+    ex8 qf[KS];
     {
         const uint16_t* qp = p.q + q_off + static_cast<int64_t>(q_row) * p.q_row_stride +
                              h * p.q_head_stride + hh * 8;
@@ -163,7 +166,7 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
         for (int ks = 0; ks < KS; ++ks) {
             u32x4 t = {0u, 0u, 0u, 0u};
             if (ok) t = *reinterpret_cast<const u32x4*>(qp + ks * 16);
-            qf[ks] = __builtin_bit_cast(bf16x8, t);
+            qf[ks] = __builtin_bit_cast(ex8, t);
         }
     }
 
@@ -257,8 +260,8 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
             const unsigned char* kt = k_lds + kbuf * TILE_BYTES + kb * 32 * ROW_BYTES + k_rd_row;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + (((2 * ks + hh) ^ k_rd_sw) << 4));
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+                const ex8 kf = *reinterpret_cast<const ex8*>(kt + (((2 * ks + hh) ^ k_rd_sw) << 4));
+                s[kb] = E::mfma(kf, qf[ks], s[kb]);
             }
         }
     };
@@ -319,7 +322,7 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
         qk_tile(cur ^ 1, s_nxt);
         const float m_scaled = m_run * c;
         float psum = 0.f;
-        bf16x8 pf[4];   // B operand of O^T += V^T P^T: k-step kk = accumulator regs 8*(kk&1).. of block kk>>1
+        ex8 pf[4];   // B operand of O^T += V^T P^T: k-step kk = accumulator regs 8*(kk&1).. of block kk>>1
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -333,7 +336,7 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
                 f32x8 t;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t[e] = s_cur[kb][8 * half + e];
-                pf[2 * kb + half] = __builtin_convertvector(t, bf16x8);
+                pf[2 * kb + half] = __builtin_convertvector(t, ex8);
             }
         }
         l_run = l_run * alpha + psum;
@@ -349,8 +352,7 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     LDS_PTR(s16x4, vt + v_rd[db] + kk * 16 * ROW_BYTES + 8 * ROW_BYTES));
                 const s16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf[kk],
-                                                                    o_acc[db], 0, 0, 0);
+                o_acc[db] = E::mfma(__builtin_bit_cast(ex8, vf), pf[kk], o_acc[db]);
             }
         }
         alpha = stats(s_nxt, i + 1, has_next);
@@ -399,11 +401,9 @@ la_fwd_bf16_v2_kernel(const FwdParams p) {
         for (int db = 0; db < DB; ++db) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                typedef float f32x4 __attribute__((ext_vector_type(4)));
-                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                 f32x4 x = {o_acc[db][4 * t] * inv, o_acc[db][4 * t + 1] * inv, o_acc[db][4 * t + 2] * inv,
                            o_acc[db][4 * t + 3] * inv};
-                *reinterpret_cast<bf16x4*>(op + 32 * db + 8 * t + 4 * hh) = __builtin_convertvector(x, bf16x4);
+                *reinterpret_cast<ex4*>(op + 32 * db + 8 * t + 4 * hh) = __builtin_convertvector(x, ex4);
             }
         }
         if (p.lse != nullptr && hh == 0) {
@@ -432,13 +432,13 @@ size_t fwd_lds_bytes_v2(int head_dim, int k_tiles, int* seq_cap_out) {
            2 * static_cast<size_t>((k_tiles + 31) / 32) * 4 + 16;
 }
 
-template <int D, bool SKIPABLE>
+template <int D, bool SKIPABLE, bool F16>
 static hipError_t launch_v2(const FwdParams& p, hipStream_t stream) {
     const int total = p.batch * p.num_heads * p.q_tile_count;
     FwdParams pp = p;
     const size_t lds = fwd_lds_bytes_v2(D, p.k_tiles, &pp.seq_cap);
     (void)hipGetLastError();   // drop any stale sticky error of this thread: only OUR launch is reported
-    auto kfn = la_fwd_bf16_v2_kernel<D, SKIPABLE>;
+    auto kfn = la_fwd_bf16_v2_kernel<D, SKIPABLE, F16>;
     const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (err != hipSuccess) return err;
@@ -449,11 +449,16 @@ static hipError_t launch_v2(const FwdParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, hipStream_t stream) {
-    if (head_dim == 128) return skipable ? launch_v2<128, true>(p, stream) : launch_v2<128, false>(p, stream);
-    if (head_dim == 64) return skipable ? launch_v2<64, true>(p, stream) : launch_v2<64, false>(p, stream);
-    if (head_dim == 256) return skipable ? launch_v2<256, true>(p, stream) : launch_v2<256, false>(p, stream);
+template <bool F16>
+static hipError_t launch_v2_dtype(const FwdParams& p, int head_dim, bool skipable, hipStream_t stream) {
+    if (head_dim == 128) return skipable ? launch_v2<128, true, F16>(p, stream) : launch_v2<128, false, F16>(p, stream);
+    if (head_dim == 64) return skipable ? launch_v2<64, true, F16>(p, stream) : launch_v2<64, false, F16>(p, stream);
+    if (head_dim == 256) return skipable ? launch_v2<256, true, F16>(p, stream) : launch_v2<256, false, F16>(p, stream);
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, bool f16, hipStream_t stream) {
+    return f16 ? launch_v2_dtype<true>(p, head_dim, skipable, stream) : launch_v2_dtype<false>(p, head_dim, skipable, stream);
 }
 
 }  // namespace la

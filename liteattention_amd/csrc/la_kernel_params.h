@@ -77,9 +77,9 @@ inline hipError_t prepare_work_queue(FwdParams& p, bool skipable, int total, int
 }
 
 size_t fwd_lds_bytes_v2(int head_dim, int k_tiles, int* seq_cap_out);
-hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, hipStream_t stream);   // 128-row template: head_dim 64 / 256, and 128 as the A/B kernel
+hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, bool f16, hipStream_t stream);   // 128-row template: head_dim 64 / 256, and 128 as the A/B kernel
 size_t fwd_lds_bytes_x64(int k_tiles, int* seq_cap_out);
-hipError_t launch_fwd_bf16_d128_x64(const FwdParams& p, bool skipable, hipStream_t stream);  // 1 wave/SIMD, 64 rows/wave, q-tile 256
+hipError_t launch_fwd_bf16_d128_x64(const FwdParams& p, bool skipable, bool f16, hipStream_t stream);  // 1 wave/SIMD, 64 rows/wave, q-tile 256
 size_t fwd_lds_bytes_x64_fp8(int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_fp8_d128_x64(const FwdParams& p, bool skipable, hipStream_t stream);   // 1 wave/SIMD, 64 rows/wave; p.v = V^T workspace
 size_t fp8_workspace_bytes(int batch, int num_heads_k, int k_tiles);
@@ -88,7 +88,7 @@ hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_ro
 hipError_t launch_empty_k_fill(uint16_t* o, float* lse, int64_t o_batch_stride, int64_t o_row_stride, int64_t o_head_stride,
                                int batch, int seqlen_q, int num_heads, int head_dim_v, hipStream_t stream);
 hipError_t launch_skip_list_stats(const int32_t* list, int rows, int k_tiles, int64_t* out, hipStream_t stream);
-hipError_t launch_combine(const void* o_partial, bool partial_is_bf16, const float* lse_partial, uint16_t* o,
+hipError_t launch_combine(const void* o_partial, bool partial_is_16bit, bool f16, const float* lse_partial, uint16_t* o,
                           float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v,
                           hipStream_t stream);
 

@@ -124,9 +124,7 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     (no collective is in flight beside window 0)."""
     if not q.is_cuda:
         raise RuntimeError("lite_attention::fwd has no CPU implementation (HIP device tensors required)")
-    if q.dtype not in (torch.bfloat16, torch.float8_e4m3fn):
-        if q.dtype == torch.float16:
-            raise NotImplementedError("fp16 is not instantiated in this build (bf16 and fp8_e4m3 are)")
+    if q.dtype not in (torch.bfloat16, torch.float16, torch.float8_e4m3fn):
         raise RuntimeError("FlashAttention only supports fp16, bf16, and fp8_e4m3 type")          # :715
     is_fp8 = q.dtype == torch.float8_e4m3fn
     if k.dtype != q.dtype or v.dtype != q.dtype:
@@ -200,11 +198,13 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
             o = out
         return (o, *res[1:])
 
+    out_dtype = torch.bfloat16 if is_fp8 else q.dtype                                            # :859
     if out is None:
-        out = torch.empty((B, Sq, H, Dv), dtype=torch.bfloat16, device=q.device)                 # :872-886
+        out = torch.empty((B, Sq, H, Dv), dtype=out_dtype, device=q.device)                      # :872-886
     else:
-        if out.dtype != torch.bfloat16 or tuple(out.shape) != (B, Sq, H, Dv) or out.stride(-1) != 1:
-            raise RuntimeError("out must be bf16 of shape (batch, seqlen_q, nheads, headdim_v) with contiguous last dimension")
+        if out.dtype != out_dtype or tuple(out.shape) != (B, Sq, H, Dv) or out.stride(-1) != 1:  # :863
+            raise RuntimeError("For FP16/BF16 input, output must have the same dtype as inputs (BF16 for FP8 input), shape "
+                               "(batch, seqlen_q, nheads, headdim_v) and a contiguous last dimension")
     softmax_lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)                  # :887-892
     empty = torch.empty(0, dtype=torch.float32, device=q.device)
 
@@ -230,7 +230,7 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
 
     a = _cabi.LaFwdArgs()
     a.struct_size = ctypes.sizeof(_cabi.LaFwdArgs)
-    a.dtype = _cabi.LA_DTYPE_FP8_E4M3 if is_fp8 else _cabi.LA_DTYPE_BF16
+    a.dtype = _cabi.LA_DTYPE_FP8_E4M3 if is_fp8 else (_cabi.LA_DTYPE_FP16 if q.dtype == torch.float16 else _cabi.LA_DTYPE_BF16)
     for name, t in zip(("q", "k", "v"), descales):
         if t is not None:
             setattr(a, f"{name}_descale", t.data_ptr())
@@ -287,14 +287,16 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
 def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, q_descale, k_descale, v_descale,
                     softmax_scale, attn_read_list, attn_write_list):
     """Packed variable-length batches (flash_api.cpp:672-674, 736-760): q (total_q, H, D), k/v (total_k, Hk, D), cu_seqlens_*
-    int32 [B+1] on the device, max_seqlen_* size the grid. ONE launch, no host sync. Dense bf16 only. lse is (H, total_q)."""
+    int32 [B+1] on the device, max_seqlen_* size the grid. ONE launch, no host sync. Dense bf16 / fp16 only. lse is (H, total_q)."""
     if cu_seqlens_q is None or cu_seqlens_k is None:
         raise RuntimeError("cu_seqlens_q and cu_seqlens_k must be given together")
     if attn_read_list is not None or attn_write_list is not None:
         raise NotImplementedError("skip lists with cu_seqlens: the reference's varlen entry point has none either "
                                   "(hopper/_internal/flash_attn_interface.py:638-682)")
-    if q.dtype != torch.bfloat16 or q_descale is not None or k_descale is not None or v_descale is not None:
-        raise NotImplementedError("varlen is built for bf16 (fp8 needs a per-sequence V^T prepare pass)")
+    if q.dtype not in (torch.bfloat16, torch.float16) or q_descale is not None or k_descale is not None or v_descale is not None:
+        raise NotImplementedError("varlen is built for bf16 and fp16 (fp8 needs a per-sequence V^T prepare pass)")
+    if k.dtype != q.dtype or v.dtype != q.dtype:
+        raise RuntimeError("query and key must have the same dtype")
     if q.dim() != 3 or k.dim() != 3 or v.dim() != 3:
         raise RuntimeError("varlen: q, k, v must be 3D tensors (total_tokens, nheads, headdim)")
     for name, cu in (("cu_seqlens_q", cu_seqlens_q), ("cu_seqlens_k", cu_seqlens_k)):
@@ -328,9 +330,9 @@ def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
             o = out
         return (o, *res[1:])
     if out is None:
-        out = torch.empty((Tq, H, D), dtype=torch.bfloat16, device=q.device)
-    elif out.dtype != torch.bfloat16 or tuple(out.shape) != (Tq, H, D) or out.stride(-1) != 1:
-        raise RuntimeError("out must be bf16 of shape (total_q, nheads, headdim) with contiguous last dimension")
+        out = torch.empty((Tq, H, D), dtype=q.dtype, device=q.device)
+    elif out.dtype != q.dtype or tuple(out.shape) != (Tq, H, D) or out.stride(-1) != 1:
+        raise RuntimeError("out must have the input dtype, shape (total_q, nheads, headdim) and a contiguous last dimension")
     softmax_lse = torch.empty((H, Tq), dtype=torch.float32, device=q.device)
     empty = torch.empty(0, dtype=torch.float32, device=q.device)
     if Tq == 0 or max_seqlen_q <= 0:
@@ -339,7 +341,7 @@ def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
     block_m, block_n = _cabi.get_tile_sizes(D, 2, flags)
     a = _cabi.LaFwdArgs()
     a.struct_size = ctypes.sizeof(_cabi.LaFwdArgs)
-    a.dtype = _cabi.LA_DTYPE_BF16
+    a.dtype = _cabi.LA_DTYPE_FP16 if q.dtype == torch.float16 else _cabi.LA_DTYPE_BF16
     a.q, a.k, a.v, a.o, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), softmax_lse.data_ptr()
     a.q_row_stride, a.q_head_stride = q.stride(0), q.stride(1)
     a.k_row_stride, a.k_head_stride = k.stride(0), k.stride(1)
@@ -455,16 +457,24 @@ def flash_attn_func(q, k, v, softmax_scale=None, causal=False, qv=None, q_descal
 
 
 def flash_attn_combine(out_partial: torch.Tensor, lse_partial: torch.Tensor, out: Optional[torch.Tensor] = None,
-                       return_lse: bool = True):
+                       out_dtype: Optional[torch.dtype] = None, return_lse: bool = True):
     """LSE-weighted merge of per-split partial results (sequence-parallel K/V splits).
 
-    out_partial: (num_splits, batch, seqlen, nheads, headdim) fp32 or bf16; lse_partial:
+    out_partial: (num_splits, batch, seqlen, nheads, headdim) fp32, bf16 or fp16; lse_partial:
     (num_splits, batch, nheads, seqlen) fp32 (the layout ``flash_attn_func`` returns). Counterpart of
-    the reference's flash_attn_combine (hopper/_internal/flash_attn_interface.py, fwd_combine op)."""
+    the reference's flash_attn_combine (hopper/_internal/flash_attn_interface.py:684, fwd_combine op,
+    flash_api.cpp:1620-1680). ``out_dtype``: bf16 or fp16; default = the dtype of 16-bit partials, bf16 for fp32 partials
+    (the reference would return fp32 there; an fp32 result is not built)."""
     if not out_partial.is_cuda:
         raise RuntimeError("flash_attn_combine has no CPU implementation")
-    if out_partial.dtype not in (torch.float32, torch.bfloat16):
-        raise RuntimeError("out_partial must be fp32 or bf16")
+    if out_partial.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise RuntimeError("out_partial must be fp32, bf16 or fp16")
+    if out_dtype is None:
+        out_dtype = out.dtype if out is not None else (torch.bfloat16 if out_partial.dtype == torch.float32 else out_partial.dtype)
+    if out_dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError("Output type must be FP16 or BF16 (an FP32 result is not built)")
+    if out_partial.dtype != torch.float32 and out_partial.dtype != out_dtype:
+        raise RuntimeError("16-bit partial results must have the output dtype")
     if lse_partial.dtype != torch.float32:
         raise RuntimeError("lse_partial must be fp32")
     out_partial = out_partial.contiguous()
@@ -473,12 +483,16 @@ def flash_attn_combine(out_partial: torch.Tensor, lse_partial: torch.Tensor, out
     if tuple(lse_partial.shape) != (ns, B, H, S):
         raise RuntimeError("lse_partial must have shape (num_splits, batch, nheads, seqlen)")
     if out is None:
-        out = torch.empty((B, S, H, Dv), dtype=torch.bfloat16, device=out_partial.device)
+        out = torch.empty((B, S, H, Dv), dtype=out_dtype, device=out_partial.device)
+    elif out.dtype != out_dtype or tuple(out.shape) != (B, S, H, Dv) or not out.is_contiguous():
+        raise RuntimeError("out must be contiguous (batch, seqlen, nheads, headdim) of out_dtype")
     lse = torch.empty((B, H, S), dtype=torch.float32, device=out_partial.device) if return_lse else None
     with torch.cuda.device(out_partial.device):
         stream = torch.cuda.current_stream(out_partial.device).cuda_stream
-        rc = _cabi.load().la_combine(out_partial.data_ptr(), int(out_partial.dtype == torch.bfloat16),
-                                     lse_partial.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None,
+        rc = _cabi.load().la_combine(out_partial.data_ptr(), int(out_partial.dtype != torch.float32),
+                                     lse_partial.data_ptr(), out.data_ptr(),
+                                     _cabi.LA_DTYPE_FP16 if out_dtype == torch.float16 else _cabi.LA_DTYPE_BF16,
+                                     lse.data_ptr() if lse is not None else None,
                                      ns, B, S, H, Dv, ctypes.c_void_p(stream))
     if rc != _cabi.LA_OK:
         raise RuntimeError(f"la_combine: {_cabi.status_string(rc)}")

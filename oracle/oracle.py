@@ -139,7 +139,8 @@ def qkskip_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, block_m: in
             a.must_do_is_1d = 0
             a.must_do_list = _chk(must_do_list, "must_do_list")
     a.thr = thr
-    a.p_round = 2 if p_round == "fp8" else int(p_round)   # "fp8": e4m3 P with the 2^8 offset (reference Max_offset)
+    # "fp8": e4m3 P with the 2^8 offset (reference Max_offset); "f16": P rounded to fp16; True / False: bf16 / fp32 P
+    a.p_round = 2 if p_round == "fp8" else (3 if p_round == "f16" else int(p_round))
     keep = []
     for name, t in (("q_descale", q_descale), ("k_descale", k_descale), ("v_descale", v_descale)):
         if t is not None:
@@ -195,6 +196,17 @@ def attention_dense_ref_chunked(q, k, v, softmax_scale=None, chunk: int = 2048):
         outs.append(o)
         lses.append(l)
     return torch.cat(outs, dim=1), torch.cat(lses, dim=2)
+
+
+def round_like_p(x: torch.Tensor, p_round) -> torch.Tensor:
+    """The C oracle's rounding of P applied to a float32 tensor (p_round as in qkskip_fwd: True/"bf16", "fp8", "f16")."""
+    y = x.detach().to(torch.float32).contiguous().clone()
+    mode = 2 if p_round == "fp8" else (3 if p_round == "f16" else int(bool(p_round)))
+    lib = load_lib()
+    lib.la_oracle_round.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]
+    lib.la_oracle_round.restype = None
+    lib.la_oracle_round(y.data_ptr(), y.numel(), mode)
+    return y
 
 
 def attention_combine_ref(out_partial: torch.Tensor, lse_partial: torch.Tensor):

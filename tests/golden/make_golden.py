@@ -51,6 +51,8 @@ DENSE_CASES = [  # name, seed, B, Sq, Sk, H, D, dtype
     ("bf16_b2_s333_h3_d128", 1, 2, 333, 333, 3, 128, "bfloat16"),
     ("bf16_s512_h2_d128", 2, 1, 512, 512, 2, 128, "bfloat16"),
     ("bf16_sq113_sk203_h2_d128", 3, 1, 113, 203, 2, 128, "bfloat16"),
+    ("fp16_b2_s333_h3_d128", 4, 2, 333, 333, 3, 128, "float16"),     # the reference's third dtype (flash_api.cpp:715)
+    ("fp16_sq130_sk517_h2_d64", 5, 1, 130, 517, 2, 64, "float16"),
 ]
 
 

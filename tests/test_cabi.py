@@ -70,8 +70,11 @@ def test_argument_validation_returns_codes_without_launching():
     a = _cabi.LaFwdArgs()
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_STRUCT_SIZE
     a.struct_size = ctypes.sizeof(_cabi.LaFwdArgs)
-    a.dtype = _cabi.LA_DTYPE_FP16
+    a.dtype = 7                                                                # not one of LA_DTYPE_*
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_DTYPE
+    assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == _cabi.LA_ERR_DTYPE
+    a.dtype = _cabi.LA_DTYPE_FP16                                              # built: passes the dtype check like bf16
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_NULL_ARG
     a.dtype = _cabi.LA_DTYPE_BF16
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_NULL_ARG
     a.q = a.k = a.v = a.o = 0x1000
@@ -118,7 +121,10 @@ def test_argument_validation_returns_codes_without_launching():
     a.read_list, a.write_list = 0x2000, 0x3000
     assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 1024                  # bf16 with lists: the optional ticket counter
     assert lib.la_skip_list_stats(None, 1, 1, 1, 1, None, None) == _cabi.LA_ERR_NULL_ARG
-    assert lib.la_combine(None, 0, None, None, None, 1, 1, 1, 1, 128, None) == _cabi.LA_ERR_NULL_ARG
+    assert lib.la_combine(None, 0, None, None, _cabi.LA_DTYPE_BF16, None, 1, 1, 1, 1, 128, None) == _cabi.LA_ERR_NULL_ARG
+    assert lib.la_combine(0x1000, 0, 0x1000, 0x1000, _cabi.LA_DTYPE_FP8_E4M3, None, 1, 1, 1, 1, 128, None) == _cabi.LA_ERR_DTYPE
+    a.dtype = _cabi.LA_DTYPE_FP16
+    assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 1024                  # fp16 = bf16 here
 
 
 def test_kernel_selection_is_an_argument_not_process_state():

@@ -4,11 +4,11 @@ import math
 import pytest
 import torch
 
-from helpers import DENSE_CASES, load_dense_case, ref_tolerance, structured_qkv
+from helpers import DENSE_CASES, FP16_CASES, load_dense_case, ref_tolerance, structured_qkv
 from oracle import oracle as orc
 
 
-@pytest.mark.parametrize("name", DENSE_CASES)
+@pytest.mark.parametrize("name", DENSE_CASES + FP16_CASES)
 def test_dense_eager_oracle_matches_reference_outputs(name):
     """attention_dense_ref restates attention_ref (test_util.py:226-348): same numbers as the reference run."""
     c = load_dense_case(name)
@@ -21,7 +21,7 @@ def test_dense_eager_oracle_matches_reference_outputs(name):
     assert abs((out_pt.float() - c["out_ref"]).abs().max().item() - c["pt_maxerr"]) <= 1e-6
 
 
-@pytest.mark.parametrize("name", DENSE_CASES)
+@pytest.mark.parametrize("name", DENSE_CASES + FP16_CASES)
 @pytest.mark.parametrize("tiles", [(128, 64), (128, 176)])
 def test_tiled_oracle_dense_matches_reference_outputs(name, tiles):
     """The tiled C walk with every tile listed equals the reference's eager result (fp32 P: round-off only;
@@ -34,8 +34,9 @@ def test_tiled_oracle_dense_matches_reference_outputs(name, tiles):
     assert n_tiles == B * H * math.ceil(Sq / bm) * math.ceil(Sk / bn)
     assert (o32 - c["out_ref"]).abs().max().item() <= 5e-6
     assert (lse32 - c["lse_ref"]).abs().max().item() <= 2e-5
-    if c["dtype"] == torch.bfloat16:
-        o16, lse16, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=bm, block_n=bn, p_round=True)
+    if c["dtype"] in (torch.bfloat16, torch.float16):       # P rounded to the element type before P.V (softmax.h:271)
+        o16, lse16, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=bm, block_n=bn,
+                                       p_round="f16" if c["dtype"] == torch.float16 else True)
         assert (o16 - c["out_ref"]).abs().max().item() <= ref_tolerance(c["out_ref"], c["pt_maxerr"])
         assert torch.equal(lse16, lse32)   # row sums use the un-rounded P (softmax.h:271)
 
@@ -225,3 +226,16 @@ def test_gqa_oracle_matches_reference_outputs(name):
     if not fp8:
         out, lse = orc.attention_dense_ref(c["q"], c["k"], c["v"])
         assert (out - c["out_ref"]).abs().max().item() <= 1e-6 and (lse - c["lse_ref"]).abs().max().item() <= 2e-5
+
+
+def test_p_roundings_match_torch_casts():
+    """The oracle's bf16 / fp16 / e4m3 roundings of P are torch's casts bit for bit: ties, subnormals, and the range P takes."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.cat([torch.rand(20000, generator=g), torch.rand(20000, generator=g) * 1e-4, torch.rand(20000, generator=g) * 2e-7,
+                   torch.linspace(0, 256, 20001), torch.logspace(-30, 8, 4001, base=2.0),
+                   torch.tensor([0.0, 1.0, 2.0 ** -24, 2.0 ** -25, 1.5 * 2.0 ** -24, 3.0 * 2.0 ** -25, 1.0 + 2.0 ** -11,
+                                 1.0 + 3 * 2.0 ** -11, 1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8, 2.0 ** -14, 2.0 ** -14 - 2.0 ** -25])])
+    assert torch.equal(orc.round_like_p(x, "f16"), x.half().float())
+    assert torch.equal(orc.round_like_p(x, True), x.bfloat16().float())
+    x8 = x.clamp_max(448.0)
+    assert torch.equal(orc.round_like_p(x8, "fp8"), x8.to(torch.float8_e4m3fn).float())
