@@ -168,7 +168,7 @@ def main():
     ap.add_argument("--no-denoise", action="store_true", help="skip the 50-step denoising run (BASELINE.json configs[2]) of the 1-GPU bf16 line")
     ap.add_argument("--overlap-windows", type=int, default=3,
                     help="N > 1: q-tile windows per step whose all-gathers overlap the next window's compute (1 = off)")
-    ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
+    ap.add_argument("--dtype", choices=["bf16", "fp16", "fp8"], default="bf16",
                     help="bf16 = headline (BASELINE.json configs[2,3]); fp8 = configs[4] (e4m3 Q/K/V, bf16 out)")
     args = ap.parse_args()
 
@@ -211,7 +211,7 @@ def main():
         """Headline measurement (+ optional sparsity sweep, + verification) for one input dtype on this rank's heads."""
         fp8 = dtype_name == "fp8"
         peak = MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS
-        q, k, v = [x.to(torch.float8_e4m3fn) for x in qkv_bf16] if fp8 else qkv_bf16
+        q, k, v = [x.to(torch.float8_e4m3fn) for x in qkv_bf16] if fp8 else ([x.half() for x in qkv_bf16] if dtype_name == "fp16" else qkv_bf16)
         bm, bn = L.get_tile_sizes(D, 1 if fp8 else 2)
         q_tiles, k_tiles = -(-S // bm), -(-S // bn)
         use_dist = dist if distributed else None
@@ -267,7 +267,8 @@ def main():
         step_s, kern_s = timed(steps, warmup)
         flops_job = flops_rank * world
         listed_frac = listed_tiles_of_rows(rows) / (q_tiles * k_tiles)
-        kernel_name = ("la_prep_v_fp8_kernel + la_fwd_fp8_d128_x64_kernel<true>" if fp8 else "la_fwd_bf16_d128_x64_kernel<true>")
+        kernel_name = ("la_prep_v_fp8_kernel + la_fwd_fp8_d128_x64_kernel<true>" if fp8 else
+                       f"la_fwd_bf16_d128_x64_kernel<true, {'true' if dtype_name == 'fp16' else 'false'}>")   # <SKIPABLE, F16>
         # algorithmic minimum HBM bytes of one launch: Q + K + V once at the input width, O once in bf16 (lists and LSE are <2 %)
         esz = 1 if fp8 else 2
         alg_bytes = B * S * Hl * D * (3 * esz + 2)
@@ -288,7 +289,7 @@ def main():
                  if att.overlap_windows > 1 else " + 1 RCCL all-gather of O per step")),
         }
         # traffic: only from a PMC summary measured on exactly these kernel sources
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary_fp8.json" if fp8 else "pmc_summary.json")
+        pmc = os.path.join(ROOT, "profiles", {"fp8": "pmc_summary_fp8.json", "fp16": "pmc_summary_fp16.json"}.get(dtype_name, "pmc_summary.json"))
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:

@@ -15,6 +15,7 @@ pmc() { # dir-name counters... -- command
 want() { [ "${EV_SECTIONS:-all}" = all ] || [[ " $EV_SECTIONS " == *" $1 "* ]]; }    # EV_SECTIONS="traffic_real other" re-runs parts
 # 1. the driver's own command, un-profiled: the bench line of record
 want bench && python $R/bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
+want bench && python $R/bench.py --dtype fp16 --no-denoise --no-cpu-baseline > $OUT/bench_line_fp16.json 2>> $OUT/bench_line.err
 # 2. kernel trace + stats of the same command (shorter loop)
 want kt && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $R/bench.py --no-sweep --no-cpu-baseline --no-denoise --steps 5 --warmup 2 > $OUT/kt.log 2>&1
 # 3. PMC passes, bf16 headline and fp8

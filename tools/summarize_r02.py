@@ -91,6 +91,10 @@ for l in open(os.path.join(src, "bench_line.json")):
     if l.startswith('{"metric"'):
         bench = json.loads(l)
 json.dump(bench, open(os.path.join(PROF, f"{tag}_bench_line.json"), "w"), indent=1)
+if os.path.exists(os.path.join(src, "bench_line_fp16.json")):          # the fp16 instantiation on the same box
+    for l in open(os.path.join(src, "bench_line_fp16.json")):
+        if l.startswith('{"metric"'):
+            json.dump(json.loads(l), open(os.path.join(PROF, f"{tag}_bench_line_fp16.json"), "w"), indent=1)
 kt_line = None
 for l in open(os.path.join(src, "kt.log")):
     if l.startswith('{"metric"'):
