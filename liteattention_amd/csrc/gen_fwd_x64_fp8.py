@@ -43,6 +43,8 @@ def opt_val(key, default):
 XPAIRS = int(opt_val("x", "4"))          # pair-groups (of 16) done in phase 2. EVEN: two pair-groups share one packed-e4m3 destination register
                                           # (lo / hi half by op_sel); an odd split leaves a half-written register across the phase boundary
                                           # (measured x = 2 / 4: 2078-2101 TFLOP/s at 42 %, x = 3 / 5 / 6: 2048-2065)
+PK = "pk" in OPT                          # A/B: packed fp32 FMA / add in the softmax (v_pk_fma_f32, v_pk_add_f32). MEASURED ANTI-LEVER here too:
+                                          # 64 fewer instructions per step, bit-identical results, 1891 vs 2068 TFLOP/s at 42 % (round 2, tools/ab.py --fp8)
 NG = 8                                    # MFMAs (gaps) per phase
 TAU = 2.0                                 # lazy-rescale slack in log2 units (must match the shell: param[22] = TAU / c)
 P_OFFSET = 8.0 - TAU
@@ -187,9 +189,17 @@ def softmax_parts(sset, p):
         dst = S_(sset, qb, 0) + 4 * kb + (r >> 2)         # 32 e4m3 bytes of a q-block = its first 8 registers
         hi = " op_sel:[0,0,1]" if (r >> 1) & 1 else ""
         ta, tb = T[8 + 2 * qb], T[9 + 2 * qb]
-        F.append([f"    v_fma_f32 {v(ta)}, {v(r0)}, {s(S_C)}, {v(NMS[qb])}", f"    v_fma_f32 {v(tb)}, {v(r1)}, {s(S_C)}, {v(NMS[qb])}"])
+        if PK:
+            # packed fp32: one instruction = the two FMAs / the two adds of the pair, lane for lane the same IEEE operations
+            # (c from the low dword of s[S_C:S_C+1] for both halves; -m.c from the NMS register of this q-block for both)
+            assert r0 % 2 == 0 and ta % 2 == 0 and tb == ta + 1 and L1[qb] == L0[qb] + 1 and L0[qb] % 2 == 0 and S_C % 2 == 0
+            nb, nsel = NMS[qb] & ~1, NMS[qb] & 1
+            F.append([f"    v_pk_fma_f32 {vr(ta, 2)}, {vr(r0, 2)}, {sr(S_C)}, {vr(nb, 2)} op_sel:[0,0,{nsel}] op_sel_hi:[1,0,{nsel}]"])
+            A.append([f"    v_pk_add_f32 {vr(L0[qb], 2)}, {vr(L0[qb], 2)}, {vr(r0, 2)}"])
+        else:
+            F.append([f"    v_fma_f32 {v(ta)}, {v(r0)}, {s(S_C)}, {v(NMS[qb])}", f"    v_fma_f32 {v(tb)}, {v(r1)}, {s(S_C)}, {v(NMS[qb])}"])
+            A.append([f"    v_add_f32 {v(L0[qb])}, {v(L0[qb])}, {v(r0)}", f"    v_add_f32 {v(L1[qb])}, {v(L1[qb])}, {v(r1)}"])
         E.append([f"    v_exp_f32 {v(r0)}, {v(ta)}", f"    v_exp_f32 {v(r1)}, {v(tb)}"])
-        A.append([f"    v_add_f32 {v(L0[qb])}, {v(L0[qb])}, {v(r0)}", f"    v_add_f32 {v(L1[qb])}, {v(L1[qb])}, {v(r1)}"])
         C.append([f"    v_cvt_pk_fp8_f32 {v(dst)}, {v(r0)}, {v(r1)}{hi}"])
     return F, E, A, C
 
@@ -207,8 +217,12 @@ def softmax_stream(sset, groups):
         Ap, Cp = (parts[g - 1][2], parts[g - 1][3]) if g > 0 else (None, None)
         E = parts[g][1]
         for qb in (0, 1):
-            fill0 = ([Fn[qb][0]] if Fn else []) + (list(Ap[qb][:1]) if Ap else [])
-            fill1 = ([Fn[qb][1]] if Fn else []) + (list(Ap[qb][1:]) if Ap else []) + (list(Cp[qb]) if Cp else [])
+            if PK:       # the packed FMA of group g+1 overwrites both temps: it goes behind the second exp
+                fill0 = list(Ap[qb]) if Ap else []
+                fill1 = (list(Fn[qb]) if Fn else []) + (list(Cp[qb]) if Cp else [])
+            else:
+                fill0 = ([Fn[qb][0]] if Fn else []) + (list(Ap[qb][:1]) if Ap else [])
+                fill1 = ([Fn[qb][1]] if Fn else []) + (list(Ap[qb][1:]) if Ap else []) + (list(Cp[qb]) if Cp else [])
             o += [E[qb][0]] + fill0 + [E[qb][1]] + fill1
     for qb in (0, 1):
         o += parts[-1][2][qb]
