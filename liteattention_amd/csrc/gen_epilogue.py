@@ -23,6 +23,7 @@ def store_epilogue(g, o_reg):
     # the loop's DMA-base registers are dead here: O base, LSE base and the scalars live in them
     S_OBASE, S_LSEB, S_ORS, S_CLN2, S_OSCALE, S_LSEADD = g["S_TB"], g["S_VB"], g["S_T0"], g["S_T1"], g["S_T2"], g["S_T3"]
     cvt = g.get("CVT_OP", "v_cvt_pk_bf16_f32")                 # the 16-bit output type follows the inputs (fp8 inputs: bf16)
+    n_qb, n_db = g.get("NQB", 2), g.get("DB", 4)               # q-blocks per wave, 32-wide d-blocks (head_dim 256: 1 and 8)
     HH16 = g["MLOC"][0]                                        # dead after the loop: hh * 16 bytes
     emit("; ---- finalize + store O (bf16) and LSE straight from the accumulators")
     emit(f"v_mov_b32 {v(T[0])}, {s(S_PARAM)}")
@@ -34,7 +35,7 @@ def store_epilogue(g, o_reg):
         emit(f"v_readfirstlane_b32 {s(dst)}, {v(src)}")
     emit("s_nop 4")
     emit(f"v_lshlrev_b32 {v(HH16)}, 2, {v(HH4)}")
-    for qb in (0, 1):
+    for qb in range(n_qb):
         # l = sum over the two half-waves; inv = oscale / l (0 for l == 0 or NaN); lse = m_ref c ln2 + ln l + lse_add
         emit(f"v_add_f32 {v(T[0])}, {v(L0[qb])}, {v(L1[qb])}")
         emit(f"v_mov_b32 {v(T[1])}, {v(T[0])}")
@@ -68,7 +69,7 @@ def store_epilogue(g, o_reg):
         # lanes +16 bytes) instead of two 8-byte ones: the store tail is issue-bound per instruction (cdna_hip_programming.md T21).
         # Software-pipelined over two register sets (the S buffers v0..v15 are dead here): read(p+1) sits between pack(p) and
         # swap(p), which also covers the 2 wait states a VALU write needs before v_permlane32_swap reads it.
-        pairs = [(db, t) for db in range(4) for t in (0, 2)]
+        pairs = [(db, t) for db in range(n_db) for t in (0, 2)]
 
         def stage_read(i):
             db, t = pairs[i]

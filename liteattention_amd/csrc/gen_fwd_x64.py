@@ -47,34 +47,50 @@ def opt_val(key, default):
 DTYPE = os.environ.get("LA_X64_DTYPE", "bf16")
 MFMA_OP = {"bf16": "v_mfma_f32_32x32x16_bf16", "f16": "v_mfma_f32_32x32x16_f16"}[DTYPE]
 CVT_OP = {"bf16": "v_cvt_pk_bf16_f32", "f16": "v_cvt_pk_f16_f32"}[DTYPE]          # both round to nearest even
+# Head dim of the body: 128 (two 32-row q-blocks per wave, q-tile 256) or 256 (LA_X64_D=256: ONE q-block per wave, q-tile 128 - O^T
+# alone is 128 registers per q-block there). Both have 32 + 32 MFMAs per step; the 256 form does half the softmax per step and
+# reads twice the K/V fragment bytes per FLOP. See the register-map comments below for what moves.
+D = int(os.environ.get("LA_X64_D", "128"))
+assert D in (128, 256)
+NQB = 2 if D == 128 else 1                # 32-row q-blocks per wave
+KS = D // 16                              # k-steps of S^T = K Q^T
+DB = D // 32                              # 32-wide d-blocks of O^T
+ROW = 2 * D                               # bytes per K / V row
+NKF, NVF = 2 * KS, 4 * DB                 # K fragments (A operands of QK) / V^T fragments (A operands of PV) per tile
+PW = 16 * ROW // 1024                     # 1-KiB DMA pieces per wave per tile (a wave stages 16 of the 64 rows)
 XPAIRS = int(opt_val("x", "5"))          # pair-groups (of 16; one group = the same pair of both q-blocks) done in phase 2
 CAP1 = int(opt_val("cap1", "0"))          # fillers per MFMA gap the distributor may place (0 = balance evenly)
 CAP2 = int(opt_val("cap2", "0"))
-DMA_GAPS = [int(x) for x in opt_val("dmagaps", "1,2,4,6,8,10,11,13,15,17").replace(".", ",").split(",")]   # m0K,K0..3,m0V,V0..3 (phase 1)
+DMA_GAPS = [int(x) for x in opt_val("dmagaps", "1,2,4,6,8,10,11,13,15,17" if D == 128 else
+                                    "1,2,3,4,5,7,8,9,10,11,13,14,15,16,17,19,20,21,22,23").replace(".", ",").split(",")]   # m0K,K0..3,m0V,V0..3 (phase 1)
 
 # ---------------------------------------------------------------- AGPR map
 def O_(qb, db):
-    return 64 * qb + 16 * db
+    return 16 * DB * qb + 16 * db
 
 
 def QA(qb, ks):
-    return 128 + 32 * qb + 4 * ks
+    return 128 + 4 * KS * qb + 4 * ks
 
 
-def KA(j):
-    return 192 + 4 * j
+def KFRAG(j):
+    """Operand of K fragment j = kb * KS + ks. head_dim 128: a[192:255]. head_dim 256: 32 fragments; key block 0 in a[192:255],
+    key block 1 in v[64:127] (the S buffers are half the size there; an MFMA A operand may be either file)."""
+    return f"a[{192 + 4 * j}:{192 + 4 * j + 3}]" if j < 16 else f"v[{64 + 4 * (j - 16)}:{64 + 4 * (j - 16) + 3}]"
 
 
 # ---------------------------------------------------------------- VGPR map
 def S_(sset, kb, qb):
-    return 64 * sset + 32 * kb + 16 * qb
+    return 32 * NQB * sset + 16 * NQB * kb + 16 * qb
 
 
 VF = [128 + 4 * i for i in range(8)]
 KADDR = list(range(160, 168))
 VADDR = list(range(168, 172))
-LK = list(range(172, 176))
-LV = list(range(176, 180))
+# per-lane DMA source offsets, one per piece: head_dim 256 has 8 pieces per tensor; the second four sit in the registers the
+# second q-block's running state has at head_dim 128 (MTRUE[1], MREF[1], NMS[1], L0[1], L1[1], MLOC[1], MLOC2[1], ALPHA[1])
+LK = list(range(172, 176)) + ([181, 183, 185, 188] if D == 256 else [])
+LV = list(range(176, 180)) + ([189, 191, 193, 195] if D == 256 else [])
 # (L0[qb], L1[qb]) and (NMS[0], NMS[1]) are even-aligned 64-bit pairs: operands of the packed-fp32 VALU ops
 MTRUE, MREF, NMS, L0, L1, MLOC, MLOC2, ALPHA = ([180, 181], [182, 183], [184, 185], [186, 188], [187, 189], [190, 191],
                                                 [192, 193], [194, 195])
@@ -95,8 +111,8 @@ S_FREE6, S_TB2, S_VB2, S_BIT = 87, 88, 90, 92    # second set of DMA bases (the 
 S_CC = 94                                        # s[94:95] = (c, c): scalar operand of v_pk_fma_f32
 TBS, VBS = [S_TB, S_TB2], [S_VB, S_VB2]
 
-KV_TILE = 16384
-V_REGION = 32768
+KV_TILE = 64 * ROW
+V_REGION = 2 * KV_TILE
 DMA_POLICY = {"": "", "nt": " nt", "sc0": " sc0", "sc1": " sc1"}[opt_val("dmapol", "")]    # cache-policy experiments on the K/V stream
 DMA_BIAS = 3072           # S_KBASE / S_VBASE hold (tensor base - DMA_BIAS); LK / LV[j] hold (+DMA_BIAS - 1024 j): see dma_ops
 
@@ -161,23 +177,27 @@ def finalize(items):
 
 # ---------------------------------------------------------------- building blocks (return item lists)
 def k_read(kbuf_imm, j):
-    kb, ks = j >> 3, j & 7
-    return ("LDS", f"ds_read_b128 {ar(KA(j), 4)}, {v(KADDR[ks])} offset:{kbuf_imm + kb * 8192}", ("k", j))
+    """K fragment j: rows 32 kb + (lane & 31), 16-byte chunk 2 ks + hh (XOR-swizzled by the row: KADDR[ks & 7]); the chunks of
+    k-steps 8..15 (head_dim 256) are the same addresses + 256 bytes (the swizzle stays inside a 256-byte half row)."""
+    kb, ks = j // KS, j % KS
+    return ("LDS", f"ds_read_b128 {KFRAG(j)}, {v(KADDR[ks & 7])} offset:{kbuf_imm + kb * 32 * ROW + (ks >> 3) * 256}", ("k", j))
 
 
 def v_read(slot, vbuf_imm, m):
+    """V^T fragment m = 4 db + kk: keys 16 kk .. 16 kk + 15, d-block db (VADDR[db & 3]; d-blocks 4..7 of head_dim 256: + 256 bytes)."""
     db, kk = m >> 2, m & 3
     if "vfake" in OPT:      # pricing only: ONE b128 read per fragment, as a pre-transposed V^T image would need
         return [("LDS", f"ds_read_b128 {vr(VF[slot], 4)}, {v(KADDR[2 * kk])} offset:{V_REGION + vbuf_imm + db * 4096}", ("v", m, 1))]
-    return [("LDS", f"ds_read_b64_tr_b16 {vr(VF[slot], 2)}, {v(VADDR[db])} offset:{vbuf_imm + kk * 4096}", ("v", m, 0)),
-            ("LDS", f"ds_read_b64_tr_b16 {vr(VF[slot] + 2, 2)}, {v(VADDR[db])} offset:{vbuf_imm + kk * 4096 + 2048}", ("v", m, 1))]
+    off = vbuf_imm + kk * 16 * ROW + (db >> 2) * 256
+    return [("LDS", f"ds_read_b64_tr_b16 {vr(VF[slot], 2)}, {v(VADDR[db & 3])} offset:{off}", ("v", m, 0)),
+            ("LDS", f"ds_read_b64_tr_b16 {vr(VF[slot] + 2, 2)}, {v(VADDR[db & 3])} offset:{off + 8 * ROW}", ("v", m, 1))]
 
 
 def mfma_qk(sset, j, qb):
-    kb, ks = j >> 3, j & 7
+    kb, ks = j // KS, j % KS
     d = S_(sset, kb, qb)
     c = "0" if ks == 0 else vr(d, 16)
-    return f"    {MFMA_OP} {vr(d, 16)}, {ar(KA(j), 4)}, {ar(QA(qb, ks), 4)}, {c}"
+    return f"    {MFMA_OP} {vr(d, 16)}, {KFRAG(j)}, {ar(QA(qb, ks), 4)}, {c}"
 
 
 def mfma_pv(sset, slot, m, qb):
@@ -195,7 +215,7 @@ def softmax_parts(sset, p):
     Packed form: ONE v_pk_fma_f32 (c from s[S_CC:S_CC+1], -m_ref*c broadcast from one half of v[NMS0:NMS1] by op_sel)
     and ONE v_pk_add_f32 into the (L0, L1) pair do the work of two fmas / two adds."""
     F, E, A, C = [], [], [], []
-    for qb in (0, 1):
+    for qb in range(NQB):
         e0 = 2 * p
         kb, r = e0 >> 4, e0 & 15
         r0 = S_(sset, kb, qb) + r
@@ -230,13 +250,13 @@ def softmax_stream(sset, groups):
     if "expblock" in OPT:
         return [op for p in groups for op in softmax_group(sset, p)]
     parts = [softmax_parts(sset, p) for p in groups]
-    o = parts[0][0][0] + parts[0][0][1]                     # F(first), both q-blocks
+    o = [x for per_qb in parts[0][0] for x in per_qb]       # F(first), every q-block
     n = len(parts)
     for g in range(n):
         Fn = parts[g + 1][0] if g + 1 < n else None
         Ap, Cp = (parts[g - 1][2], parts[g - 1][3]) if g > 0 else (None, None)
         E = parts[g][1]
-        for qb in (0, 1):
+        for qb in range(NQB):
             # between / after the two exps of a q-block: the add(s) and the cvt of group g-1 (the cvt after BOTH of its
             # adds: it may overwrite r0 in place), and the fma(s) of group g+1 (their temporaries were just consumed)
             fill0 = list(Ap[qb][:1]) if Ap else []
@@ -245,9 +265,9 @@ def softmax_stream(sset, groups):
                 fill0 = [Fn[qb][0]] + fill0
                 fill1 = [x for x in fill1 if x is not Fn[qb][0]]
             o += [E[qb][0]] + fill0 + [E[qb][1]] + fill1
-    for qb in (0, 1):
+    for qb in range(NQB):
         o += parts[-1][2][qb]
-    for qb in (0, 1):
+    for qb in range(NQB):
         o += parts[-1][3][qb]
     return o
 
@@ -255,7 +275,7 @@ def softmax_stream(sset, groups):
 def row_max_ops(sset):
     """In-lane max of the 32 scores of each q-block into MLOC[qb] (two max3 chains each), interleaved over q-blocks."""
     per = []
-    for qb in (0, 1):
+    for qb in range(NQB):
         regs = [S_(sset, 0, qb) + r for r in range(16)] + [S_(sset, 1, qb) + r for r in range(16)]
         ops = [f"    v_max_f32 {v(MLOC[qb])}, {v(regs[0])}, {v(regs[1])}", f"    v_max_f32 {v(MLOC2[qb])}, {v(regs[2])}, {v(regs[3])}"]
         rest = regs[4:]
@@ -275,14 +295,17 @@ def stats_ops(rare_label, back_label, flush_label, flush_back, inval_label, inva
     v_permlane32_swap reads it."""
     o = []
     a = o.append
-    a(f"    v_mov_b32 {v(T[0])}, {v(MLOC[0])}")
-    a(f"    v_mov_b32 {v(T[1])}, {v(MLOC[1])}")
+    QBS = range(NQB)
+    for qb in QBS:
+        a(f"    v_mov_b32 {v(T[qb])}, {v(MLOC[qb])}")
     a(f"    v_add_u32 {v(TABV)}, 16, {v(TABV)}")
-    a(f"    v_permlane32_swap_b32 {v(MLOC[0])}, {v(T[0])}")
-    a(f"    v_permlane32_swap_b32 {v(MLOC[1])}, {v(T[1])}")
+    if NQB == 1:
+        a("    s_nop 0")                         # 2 wait states between the VALU write of T[0] and the swap that reads it
+    for qb in QBS:
+        a(f"    v_permlane32_swap_b32 {v(MLOC[qb])}, {v(T[qb])}")
     a("    s_nop 0")
-    a(f"    v_max_f32 {v(MLOC[0])}, {v(MLOC[0])}, {v(T[0])}")
-    a(f"    v_max_f32 {v(MLOC[1])}, {v(MLOC[1])}, {v(T[1])}")
+    for qb in QBS:
+        a(f"    v_max_f32 {v(MLOC[qb])}, {v(MLOC[qb])}, {v(T[qb])}")
     # the step past the end of the walk (i == n - 1: tile i + 1 does not exist, S_nxt came from a clamped duplicate) must not
     # touch the state: its row max becomes -inf (no vote, no new max) and -m_ref*c becomes -inf (the part of P(i+1) computed in
     # this phase, added to the row sums, is 0)
@@ -290,21 +313,28 @@ def stats_ops(rare_label, back_label, flush_label, flush_back, inval_label, inva
     a(f"    s_cbranch_scc1 {inval_label}")
     o.append(inval_back + ":")
     # vote: (m_loc - m_prev) * c > thr   (softmax.h:194), m_prev = the running max BEFORE this tile
-    a(f"    v_sub_f32 {v(T[2])}, {v(MLOC[0])}, {v(MTRUE[0])}")
-    a(f"    v_sub_f32 {v(T[3])}, {v(MLOC[1])}, {v(MTRUE[1])}")
-    a(f"    v_max_f32 {v(MTRUE[0])}, {v(MTRUE[0])}, {v(MLOC[0])}")
-    a(f"    v_max_f32 {v(MTRUE[1])}, {v(MTRUE[1])}, {v(MLOC[1])}")
-    a(f"    v_mul_f32 {v(T[2])}, {s(S_C)}, {v(T[2])}")
-    a(f"    v_mul_f32 {v(T[3])}, {s(S_C)}, {v(T[3])}")
-    a(f"    v_cmp_gt_f32 {sr(S_T64)}, {v(T[2])}, {s(S_THR)}")
-    a(f"    v_cmp_gt_f32 vcc, {v(T[3])}, {s(S_THR)}")
-    a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")                              # SCC = some row of the wave voted "do"
+    for qb in QBS:
+        a(f"    v_sub_f32 {v(T[2 + qb])}, {v(MLOC[qb])}, {v(MTRUE[qb])}")
+    for qb in QBS:
+        a(f"    v_max_f32 {v(MTRUE[qb])}, {v(MTRUE[qb])}, {v(MLOC[qb])}")
+    for qb in QBS:
+        a(f"    v_mul_f32 {v(T[2 + qb])}, {s(S_C)}, {v(T[2 + qb])}")
+    if NQB == 2:
+        a(f"    v_cmp_gt_f32 {sr(S_T64)}, {v(T[2])}, {s(S_THR)}")
+        a(f"    v_cmp_gt_f32 vcc, {v(T[3])}, {s(S_THR)}")
+        a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")                          # SCC = some row of the wave voted "do"
+    else:
+        a(f"    v_cmp_gt_f32 vcc, {v(T[2])}, {s(S_THR)}")
+        a("    s_cmp_lg_u64 vcc, 0")                                      # SCC = some row of the wave voted "do"
     a(f"    s_cselect_b32 {s(S_T0)}, {s(S_BIT)}, 0")
     a(f"    s_or_b32 {s(S_DOMASK)}, {s(S_DOMASK)}, {s(S_T0)}")
     # lazy rescale: m_true > m_ref + tau/c on any lane of either q-block -> rare block
-    a(f"    v_cmp_gt_f32 {sr(S_T64)}, {v(MTRUE[0])}, {v(MTHR[0])}")
-    a(f"    v_cmp_gt_f32 vcc, {v(MTRUE[1])}, {v(MTHR[1])}")
-    a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")
+    if NQB == 2:
+        a(f"    v_cmp_gt_f32 {sr(S_T64)}, {v(MTRUE[0])}, {v(MTHR[0])}")
+        a(f"    v_cmp_gt_f32 vcc, {v(MTRUE[1])}, {v(MTHR[1])}")
+        a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")
+    else:
+        a(f"    v_cmp_gt_f32 vcc, {v(MTRUE[0])}, {v(MTHR[0])}")
     a(f"    s_cbranch_vccnz {rare_label}")
     o.append(back_label + ":")
     # next position's bit; when it falls off the 32-bit word (SCC = 0: result is zero) the word is complete: flush it
@@ -317,18 +347,18 @@ def stats_ops(rare_label, back_label, flush_label, flush_back, inval_label, inva
 def rare_rescale_block(rare_label, back_label):
     """Out of line: m_ref follows m_true; alpha = exp2((m_ref_old - m_true)*c); l *= alpha; O rescale flagged."""
     label(rare_label)
-    for qb in (0, 1):
+    for qb in range(NQB):
         emit(f"v_sub_f32 {v(T[2 + qb])}, {v(MREF[qb])}, {v(MTRUE[qb])}")
-    for qb in (0, 1):
+    for qb in range(NQB):
         emit(f"v_mul_f32 {v(T[2 + qb])}, {s(S_C)}, {v(T[2 + qb])}")
-    for qb in (0, 1):
+    for qb in range(NQB):
         emit(f"v_exp_f32 {v(ALPHA[qb])}, {v(T[2 + qb])}")
-    for qb in (0, 1):
+    for qb in range(NQB):
         emit(f"v_mov_b32 {v(MREF[qb])}, {v(MTRUE[qb])}")
-    for qb in (0, 1):
+    for qb in range(NQB):
         emit(f"v_mul_f32 {v(NMS[qb])}, {s(S_NEGC)}, {v(MREF[qb])}")
         emit(f"v_add_f32 {v(MTHR[qb])}, {s(S_TAU)}, {v(MREF[qb])}")
-    for qb in (0, 1):
+    for qb in range(NQB):
         emit(f"v_mul_f32 {v(L0[qb])}, {v(L0[qb])}, {v(ALPHA[qb])}")
         emit(f"v_mul_f32 {v(L1[qb])}, {v(L1[qb])}, {v(ALPHA[qb])}")
     emit(f"s_mov_b32 {s(S_RESC)}, 1")
@@ -338,7 +368,7 @@ def rare_rescale_block(rare_label, back_label):
 def inval_block(lbl, back):
     """Out of line (last step of a walk): -m_ref*c := -inf, so exp2(S*c - inf) = 0 for the tile that does not exist."""
     label(lbl)
-    for qb in (0, 1):
+    for qb in range(NQB):
         emit(f"v_mov_b32 {v(MLOC[qb])}, {v(NEGINF)}")
         emit(f"v_mov_b32 {v(NMS[qb])}, {v(NEGINF)}")
     emit(f"s_branch {back}")
@@ -369,14 +399,14 @@ def rescale_o_block(lbl, back):
     label(lbl)
     emit("s_nop 15")
     emit("s_nop 15")
-    for qb in (0, 1):
-        for base in range(0, 64, 8):
+    for qb in range(NQB):
+        for base in range(0, 16 * DB, 8):
             for k in range(8):
-                emit(f"v_accvgpr_read_b32 {v(T[k])}, a{64 * qb + base + k}")
+                emit(f"v_accvgpr_read_b32 {v(T[k])}, a{O_(qb, 0) + base + k}")
             for k in range(8):
                 emit(f"v_mul_f32 {v(T[k])}, {v(T[k])}, {v(ALPHA[qb])}")
             for k in range(8):
-                emit(f"v_accvgpr_write_b32 a{64 * qb + base + k}, {v(T[k])}")
+                emit(f"v_accvgpr_write_b32 a{O_(qb, 0) + base + k}, {v(T[k])}")
     emit(f"s_mov_b32 {s(S_RESC)}, 0")
     emit("s_nop 7")
     emit(f"s_branch {back}")
@@ -391,12 +421,16 @@ def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True, st=0):
     if "nodma" in OPT:
         return []
     o = []
-    if do_k:
-        o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {kbuf_imm}")
-        o += [f"    global_load_lds_dwordx4 {v(LK[j])}, {sr(TBS[st])} offset:{1024 * j}{DMA_POLICY}" for j in range(4)]
-    if do_v:
-        o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {V_REGION + vbuf_imm}")
-        o += [f"    global_load_lds_dwordx4 {v(LV[j])}, {sr(VBS[st])} offset:{1024 * j}{DMA_POLICY}" for j in range(4)]
+    # head_dim 256: 8 pieces per tensor in two groups of 4 (the instruction offset is a 13-bit signed field: 0..3072 only), M0 moved
+    # by 4 KiB for the second group; the lane offsets of piece j carry +(3072 - 1024 (j & 3))
+    for grp in range(PW // 4):
+        if do_k:
+            o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {kbuf_imm + 4096 * grp}")
+            o += [f"    global_load_lds_dwordx4 {v(LK[4 * grp + j])}, {sr(TBS[st])} offset:{1024 * j}{DMA_POLICY}" for j in range(4)]
+    for grp in range(PW // 4):
+        if do_v:
+            o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {V_REGION + vbuf_imm + 4096 * grp}")
+            o += [f"    global_load_lds_dwordx4 {v(LV[4 * grp + j])}, {sr(VBS[st])} offset:{1024 * j}{DMA_POLICY}" for j in range(4)]
     return o
 
 
@@ -440,15 +474,15 @@ def step(variant):
     kbuf_stage = nxt * KV_TILE               # K(i+3) goes where K(i+1) was
     vbuf_cur = cur * KV_TILE                 # V(i)
     vbuf_stage = nxt * KV_TILE               # V(i+1)
-    ord1 = [(f & 1) * 8 + (f >> 1) for f in range(16)]       # K fragment order: alternate key blocks
-    ord2 = [(f & 3) * 4 + (f >> 2) for f in range(16)]       # V^T fragment order: kk outer, d-block inner
+    ord1 = [(f & 1) * KS + (f >> 1) for f in range(NKF)]     # K fragment order: alternate key blocks
+    ord2 = [(f % DB) * 4 + (f // DB) for f in range(NVF)]    # V^T fragment order: kk outer, d-block inner
 
     # ---- phase 1: QK^T(i+1) || rest of softmax(i), DMA issue (V(i+1), K(i+3)), first V^T fragments
     pre = [[] for _ in range(32)]
     post = [[] for _ in range(32)]
     mf = []
     for t in range(32):
-        mf.append(mfma_qk(nxt, ord1[t >> 1], t & 1) if "nomfma1" not in OPT else "    s_nop 0")
+        mf.append(mfma_qk(nxt, ord1[t // NQB], t % NQB) if "nomfma1" not in OPT else "    s_nop 0")
     for g, op in zip(DMA_GAPS, dma_ops(kbuf_stage, vbuf_stage, st=variant)):
         post[g].append(op)
     if "novread" not in OPT:
@@ -466,13 +500,13 @@ def step(variant):
     post = [[] for _ in range(32)]
     mf = []
     for t in range(32):
-        f = t >> 1
-        if (t & 1) == 0 and "novread" not in OPT and "nowaitv" not in OPT:
+        f, qb = t // NQB, t % NQB
+        if qb == 0 and "novread" not in OPT and "nowaitv" not in OPT:
             pre[t].append(("WAIT", ("v", ord2[f], 1)))
-        mf.append(mfma_pv(cur, f % 8, ord2[f], t & 1) if "nomfma2" not in OPT else "    s_nop 0")
-        if (t & 1) == 1 and f + 8 < 16 and "novread" not in OPT:
+        mf.append(mfma_pv(cur, f % 8, ord2[f], qb) if "nomfma2" not in OPT else "    s_nop 0")
+        if qb == NQB - 1 and f + 8 < NVF and "novread" not in OPT:
             post[t] += v_read(f % 8, vbuf_cur, ord2[f + 8])
-        if "nokread" not in OPT and (t < 16 if "klate" not in OPT else (t & 1) == 0):
+        if "nokread" not in OPT and (t < NKF if "klate" not in OPT else (t & 1) == 0):
             post[t].append(k_read(kbuf_read, ord1[t if "klate" not in OPT else f]))
     rare, back = new_label("rare"), new_label("rare_back")
     fl, flback = new_label("flush"), new_label("flush_back")
@@ -544,7 +578,7 @@ def prologue():
     emit(f"s_mov_b32 {s(S_CC)}, {s(S_C)}")
     emit(f"s_mov_b32 {s(S_CC + 1)}, {s(S_C)}")
     emit(f"s_sub_u32 {s(S_NM1)}, {s(S_NTILES)}, 1")
-    emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, 12")
+    emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, {12 if D == 128 else 13}")      # a wave stages 16 rows = 4 / 8 KiB of a tile
     emit(f"s_add_u32 {s(S_DMAW)}, {s(S_DMAW)}, {s(S_LDS)}")
     emit(f"s_mov_b32 {s(S_I)}, 0")
     emit(f"s_mov_b32 {s(S_RESC)}, 0")
@@ -555,7 +589,7 @@ def prologue():
     emit(f"v_lshlrev_b32 {v(HH4)}, 2, {v(T[0])}")
     emit(f"v_and_b32 {v(T[1])}, 31, {v(LANE)}")               # l31
     emit(f"v_and_b32 {v(T[2])}, 15, {v(LANE)}")               # a16 / cpos
-    emit(f"v_lshlrev_b32 {v(T[3])}, 8, {v(T[1])}")            # l31 * 256
+    emit(f"v_lshlrev_b32 {v(T[3])}, {8 if D == 128 else 9}, {v(T[1])}")            # l31 * ROW
     emit(f"v_add_u32 {v(T[3])}, {s(S_LDS)}, {v(T[3])}")
     for ks in range(8):
         emit(f"v_add_u32 {v(T[4])}, {2 * ks}, {v(T[0])}")
@@ -563,7 +597,7 @@ def prologue():
         emit(f"v_lshl_add_u32 {v(KADDR[ks])}, {v(T[4])}, 4, {v(T[3])}")
     emit(f"v_lshrrev_b32 {v(T[4])}, 2, {v(T[2])}")            # kq = a16 >> 2
     emit(f"v_add_u32 {v(T[5])}, {v(HH4)}, {v(T[4])}")         # key0
-    emit(f"v_lshlrev_b32 {v(T[5])}, 8, {v(T[5])}")
+    emit(f"v_lshlrev_b32 {v(T[5])}, {8 if D == 128 else 9}, {v(T[5])}")
     emit(f"v_add_u32 {v(T[5])}, {s(S_LDS)}, {v(T[5])}")
     emit(f"v_add_u32 {v(T[5])}, {V_REGION}, {v(T[5])}")
     emit(f"v_lshrrev_b32 {v(T[6])}, 4, {v(LANE)}")            # g = lane >> 4 = rip
@@ -576,32 +610,49 @@ def prologue():
         emit(f"v_xor_b32 {v(T[7])}, {db}, {v(T[4])}")
         emit(f"v_lshl_add_u32 {v(VADDR[db])}, {v(T[7])}, 6, {v(T[5])}")
     emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 4")
-    emit(f"v_add_u32 {v(RIPROW)}, {s(S_T0)}, {v(T[6])}")      # 16*wave + rip
-    emit(f"v_xor_b32 {v(RAGK)}, {v(T[2])}, {v(T[6])}")
-    emit(f"v_lshlrev_b32 {v(RAGK)}, 4, {v(RAGK)}")            # (cpos ^ rip) << 4
-    emit(f"v_lshlrev_b32 {v(RAGV)}, 2, {v(T[6])}")
-    emit(f"v_xor_b32 {v(RAGV)}, {v(T[2])}, {v(RAGV)}")
-    emit(f"v_lshlrev_b32 {v(RAGV)}, 4, {v(RAGV)}")            # (cpos ^ (rip<<2)) << 4
+    if D == 128:
+        # DMA image: a 1-KiB piece = 4 rows of 256 bytes; lane -> (row in piece rip = lane >> 4, chunk cpos = lane & 15)
+        emit(f"v_add_u32 {v(RIPROW)}, {s(S_T0)}, {v(T[6])}")      # 16*wave + rip
+        emit(f"v_xor_b32 {v(RAGK)}, {v(T[2])}, {v(T[6])}")
+        emit(f"v_lshlrev_b32 {v(RAGK)}, 4, {v(RAGK)}")            # (cpos ^ rip) << 4
+        emit(f"v_lshlrev_b32 {v(RAGV)}, 2, {v(T[6])}")
+        emit(f"v_xor_b32 {v(RAGV)}, {v(T[2])}, {v(RAGV)}")
+        emit(f"v_lshlrev_b32 {v(RAGV)}, 4, {v(RAGV)}")            # (cpos ^ (rip<<2)) << 4
+    else:
+        # head_dim 256: a piece = 2 rows of 512 bytes; lane -> (rip = lane >> 5, cpos = lane & 31). The K swizzle XORs the chunk with
+        # row & 15 = 2 j + rip, the V swizzle with (row & 3) << 2 = (2 (j & 1) + rip) << 2: both stay inside bits 0..3 of cpos
+        emit(f"v_add_u32 {v(RIPROW)}, {s(S_T0)}, {v(T[0])}")      # 16*wave + rip   (T[0] = lane >> 5)
+        emit(f"v_xor_b32 {v(RAGK)}, {v(T[1])}, {v(T[0])}")
+        emit(f"v_lshlrev_b32 {v(RAGK)}, 4, {v(RAGK)}")            # (cpos ^ rip) << 4   (T[1] = lane & 31)
+        emit(f"v_lshlrev_b32 {v(RAGV)}, 2, {v(T[0])}")
+        emit(f"v_xor_b32 {v(RAGV)}, {v(T[1])}, {v(RAGV)}")
+        emit(f"v_lshlrev_b32 {v(RAGV)}, 4, {v(RAGV)}")            # (cpos ^ (rip<<2)) << 4
     emit(f"s_mov_b32 {s(S_T1)}, {s(S_LASTROW)}")              # seqlen_k < 64: rows of the only tile stay inside the tensor
-    for j in range(4):
-        # LK[j] = (16w + 4j + rip)*k_rs + (RAGK ^ (j<<6)) + 3072 - 1024j ; LV[j] = (16w + 4j + rip)*v_rs + RAGV + 3072 - 1024j
-        emit(f"v_add_u32 {v(T[4])}, {4 * j}, {v(RIPROW)}")
+    RSTEP = 16 // PW                                           # rows per piece
+    for j in range(PW):
+        # LK[j] = (16w + RSTEP j + rip)*k_rs + (RAGK ^ ((RSTEP j) << 4)) + 3072 - 1024 (j & 3); LV[j] likewise with the V swizzle
+        bias = DMA_BIAS - 1024 * (j & 3)
+        emit(f"v_add_u32 {v(T[4])}, {RSTEP * j}, {v(RIPROW)}")
         emit(f"v_min_i32 {v(T[4])}, {v(T[4])}, {s(S_T1)}")
         emit(f"v_mul_lo_u32 {v(LK[j])}, {v(T[4])}, {s(S_KRS)}")
-        emit(f"v_xor_b32 {v(T[5])}, {j << 6}, {v(RAGK)}")
+        emit(f"v_xor_b32 {v(T[5])}, {(RSTEP * j) << 4}, {v(RAGK)}")
         emit(f"v_add_u32 {v(LK[j])}, {v(LK[j])}, {v(T[5])}")
         emit(f"v_mul_lo_u32 {v(LV[j])}, {v(T[4])}, {s(S_VRS)}")
-        emit(f"v_add_u32 {v(LV[j])}, {v(LV[j])}, {v(RAGV)}")
-        if DMA_BIAS - 1024 * j:
-            emit(f"v_add_u32 {v(LK[j])}, {DMA_BIAS - 1024 * j}, {v(LK[j])}")
-            emit(f"v_add_u32 {v(LV[j])}, {DMA_BIAS - 1024 * j}, {v(LV[j])}")
+        if D == 128:
+            emit(f"v_add_u32 {v(LV[j])}, {v(LV[j])}, {v(RAGV)}")
+        else:
+            emit(f"v_xor_b32 {v(T[5])}, {((RSTEP * j) & 3) << 6}, {v(RAGV)}")
+            emit(f"v_add_u32 {v(LV[j])}, {v(LV[j])}, {v(T[5])}")
+        if bias:
+            emit(f"v_add_u32 {v(LK[j])}, {bias}, {v(LK[j])}")
+            emit(f"v_add_u32 {v(LV[j])}, {bias}, {v(LV[j])}")
 
     emit("; ---- Q fragments -> AGPRs: row q_row0 + 64*wave + 32*qb + l31, d = 16*ks + 8*hh; rows past seqlen_q are ZERO rows")
-    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 6")
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, {5 + NQB - 1}")     # 32 NQB rows per wave
     emit(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_QROW0)}")
     emit(f"s_sub_u32 {s(S_T1)}, {s(S_SEQLENQ)}, 1")
     emit(f"v_lshlrev_b32 {v(T[6])}, 4, {v(T[0])}")            # hh * 16 bytes
-    for qb in (0, 1):
+    for qb in range(NQB):
         emit(f"v_add_u32 {v(QROW[qb])}, {s(S_T0)}, {v(T[1])}")
         if qb:
             emit(f"v_add_u32 {v(QROW[qb])}, 32, {v(QROW[qb])}")
@@ -612,19 +663,19 @@ def prologue():
         emit(f"v_add_co_u32 {v(T[4])}, vcc, {s(S_QBASE)}, {v(T[4])}")
         emit(f"v_mov_b32 {v(T[7])}, {s(S_QBASE + 1)}")
         emit(f"v_addc_co_u32 {v(T[5])}, vcc, {v(T[5])}, {v(T[7])}, vcc")
-        for ks in range(8):
-            emit(f"global_load_dwordx4 {vr(32 * qb + 4 * ks, 4)}, {vr(T[4], 2)}, off offset:{32 * ks}")
+        for ks in range(KS):
+            emit(f"global_load_dwordx4 {vr(4 * KS * qb + 4 * ks, 4)}, {vr(T[4], 2)}, off offset:{32 * ks}")
     emit("s_waitcnt vmcnt(0)")
-    for qb in (0, 1):
+    for qb in range(NQB):
         emit(f"v_cmp_gt_i32 vcc, {s(S_SEQLENQ)}, {v(QROW[qb])}")
-        for r in range(32):
-            emit(f"v_cndmask_b32 {v(32 * qb + r)}, 0, {v(32 * qb + r)}, vcc")
+        for r in range(4 * KS):
+            emit(f"v_cndmask_b32 {v(4 * KS * qb + r)}, 0, {v(4 * KS * qb + r)}, vcc")
     for r in range(64):
         emit(f"v_accvgpr_write_b32 a{128 + r}, {v(r)}")
     emit("; ---- state")
     for r in range(128):
         emit(f"v_accvgpr_write_b32 a{r}, 0")
-    for qb in (0, 1):
+    for qb in range(NQB):
         emit(f"v_mov_b32 {v(MTRUE[qb])}, 0xff800000")
         emit(f"v_mov_b32 {v(L0[qb])}, 0")
         emit(f"v_mov_b32 {v(L1[qb])}, 0")
@@ -636,15 +687,15 @@ def prologue():
     emit(f"ds_read_b64 {vr(T[10], 2)}, {v(T[6])} offset:48")         # tab[3].k : K(3), staged by step 0
     emit(f"ds_read_b64 {vr(T[12], 2)}, {v(T[6])} offset:24")         # tab[1].v : V(1), staged by step 0
     emit(f"v_add_u32 {v(TABV)}, 32, {v(T[6])}")                      # step 0 reads tab[2].v and tab[4].k
-    for j in range(16):
+    for j in range(NKF):
         emit(k_read(0, j))
     emit(("DRAIN",))
     emit(f"v_readfirstlane_b32 {s(TBS[0])}, {v(T[8])}")
     emit(f"v_readfirstlane_b32 {s(TBS[0] + 1)}, {v(T[9])}")
-    ord1 = [(f & 1) * 8 + (f >> 1) for f in range(16)]
+    ord1 = [(f & 1) * KS + (f >> 1) for f in range(NKF)]
     for t in range(32):
-        out.append(mfma_qk(0, ord1[t >> 1], t & 1))
-    for j in range(16):
+        out.append(mfma_qk(0, ord1[t // NQB], t % NQB))
+    for j in range(NKF):
         emit(k_read(KV_TILE, j))
     emit(("DRAIN",))
     emit("s_barrier")                                          # every wave has read K(0) and K(1): both K buffers are free
@@ -667,21 +718,21 @@ def prologue():
             key = 32 * kb + (r & 3) + 8 * (r >> 2)
             emit(f"v_add_u32 {v(T[0])}, {key}, {v(HH4)}")
             emit(f"v_cmp_gt_i32 vcc, {s(S_TAILVALID)}, {v(T[0])}")            # key < tail_valid -> keep
-            for qb in (0, 1):
+            for qb in range(NQB):
                 emit(f"v_cndmask_b32 {v(S_(0, kb, qb) + r)}, {v(NEGINF)}, {v(S_(0, kb, qb) + r)}, vcc")
     label(nomask)
     for op in row_max_ops(0):
         out.append(op)
     # first-tile stats: m_true = m_ref = row max; position 0 is never flagged (softmax.h:153)
-    emit(f"v_mov_b32 {v(T[0])}, {v(MLOC[0])}")
-    emit(f"v_mov_b32 {v(T[1])}, {v(MLOC[1])}")
+    for qb in range(NQB):
+        emit(f"v_mov_b32 {v(T[qb])}, {v(MLOC[qb])}")
     emit("s_nop 1")
-    emit(f"v_permlane32_swap_b32 {v(MLOC[0])}, {v(T[0])}")
-    emit(f"v_permlane32_swap_b32 {v(MLOC[1])}, {v(T[1])}")
+    for qb in range(NQB):
+        emit(f"v_permlane32_swap_b32 {v(MLOC[qb])}, {v(T[qb])}")
     emit("s_nop 1")
-    for qb in (0, 1):
+    for qb in range(NQB):
         emit(f"v_max_f32 {v(MTRUE[qb])}, {v(MLOC[qb])}, {v(T[qb])}")
-    for qb in (0, 1):
+    for qb in range(NQB):
         emit(f"v_mov_b32 {v(MREF[qb])}, {v(MTRUE[qb])}")
         emit(f"v_mul_f32 {v(NMS[qb])}, {s(S_NEGC)}, {v(MTRUE[qb])}")
         emit(f"v_add_f32 {v(MTHR[qb])}, {s(S_TAU)}, {v(MTRUE[qb])}")
@@ -731,7 +782,8 @@ def main():
     text = "\n".join(lines)
     path = sys.argv[1] if len(sys.argv) > 1 else "la_fwd_x64_body.inc"
     with open(path, "w") as f:
-        f.write("// GENERATED by gen_fwd_x64.py — do not edit. Inline-asm body of la_fwd_bf16_d128_x64_kernel.\n")
+        f.write("// GENERATED by gen_fwd_x64.py — do not edit. Inline-asm body of la_fwd_bf16_d128_x64_kernel.\n" if D == 128 else
+                f"// GENERATED by gen_fwd_x64.py (LA_X64_D={D}) — do not edit. Inline-asm body of la_fwd_bf16_x64_kernel<.., {D}>.\n")
         f.write('R"ASM(\n' + text + '\n)ASM"\n')
     print(f"wrote {path}: {len(lines)} lines, {text.count('v_mfma')} MFMAs")
 

@@ -17,8 +17,9 @@ thread_local int g_last_hip_error = 0;     // per-thread error detail of the las
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Kernel selection is a pure function of the arguments (no environment variables, no process-wide statics):
-//   bf16 head_dim 128: the 256-row hand-scheduled kernel (x64) unless LA_FLAG_KERNEL_128ROW asks for the 128-row one (v2);
-//   bf16 head_dim 64 / 256: v2; fp8 head_dim 128: x64-fp8. The skip lists are indexed by the selected kernel's tile, so
+//   bf16 / fp16 head_dim 128: the 256-row hand-scheduled kernel (x64) unless LA_FLAG_KERNEL_128ROW asks for the 128-row one (v2);
+//   head_dim 256: the hand-scheduled kernel in its 32-rows-per-wave form (q-tile 128) unless LA_FLAG_KERNEL_128ROW asks for the
+//   hipcc-scheduled v2 instantiation (same tiles); head_dim 64: v2; fp8 head_dim 128: x64-fp8. The skip lists are indexed by the selected kernel's tile, so
 //   la_get_tile_sizes_ex and la_fwd must agree on it: both call uses_128row().
 constexpr uint32_t kKnownFlags = LA_FLAG_V_PREPARED | LA_FLAG_STATIC_SCHED | LA_FLAG_KERNEL_128ROW | LA_FLAG_EXACT_RESCALE;
 bool uses_128row(int head_dim, int element_size, uint32_t flags) {
@@ -198,7 +199,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     }
     // head_dim 128: the 256-row x64 kernel unless LA_FLAG_KERNEL_128ROW; head_dim 64 / 256: the 128-row v2 template.
     const bool skipable = a->read_list != nullptr;                                      // is_skipable, flash_api.cpp:931
-    const bool x64 = a->head_dim == 128 && !uses_128row(a->head_dim, 2, a->flags);
+    const bool x64 = (a->head_dim == 128 || a->head_dim == 256) && !(a->flags & LA_FLAG_KERNEL_128ROW);
     hipError_t err;
     // optional workspace (la_fwd_workspace_bytes): with it, launches that walk lists use persistent workgroups and the
     // ticket queues; without it, the static one-workgroup-per-item map (same results either way)
@@ -206,8 +207,8 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         !(a->flags & LA_FLAG_STATIC_SCHED))
         p.work_counter = static_cast<unsigned*>(a->workspace);
     if (x64) {
-        if (la::fwd_lds_bytes_x64(p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
-        err = la::launch_fwd_bf16_d128_x64(p, skipable, f16, stream);
+        if (la::fwd_lds_bytes_x64(p.k_tiles, nullptr, a->head_dim) > 160 * 1024) return LA_ERR_SEQLEN;
+        err = la::launch_fwd_bf16_d128_x64(p, a->head_dim, skipable, f16, stream);
     } else {
         err = la::launch_fwd_bf16_v2(p, a->head_dim, skipable, f16, stream);
     }

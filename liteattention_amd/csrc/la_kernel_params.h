@@ -78,8 +78,8 @@ inline hipError_t prepare_work_queue(FwdParams& p, bool skipable, int total, int
 
 size_t fwd_lds_bytes_v2(int head_dim, int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, bool f16, hipStream_t stream);   // 128-row template: head_dim 64 / 256, and 128 as the A/B kernel
-size_t fwd_lds_bytes_x64(int k_tiles, int* seq_cap_out);
-hipError_t launch_fwd_bf16_d128_x64(const FwdParams& p, bool skipable, bool f16, hipStream_t stream);  // 1 wave/SIMD, 64 rows/wave, q-tile 256
+size_t fwd_lds_bytes_x64(int k_tiles, int* seq_cap_out, int head_dim);
+hipError_t launch_fwd_bf16_d128_x64(const FwdParams& p, int head_dim, bool skipable, bool f16, hipStream_t stream);  // 1 wave/SIMD; head_dim 128: 64 rows/wave, q-tile 256; 256: 32 rows/wave, q-tile 128
 size_t fwd_lds_bytes_x64_fp8(int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_fp8_d128_x64(const FwdParams& p, bool skipable, hipStream_t stream);   // 1 wave/SIMD, 64 rows/wave; p.v = V^T workspace
 size_t fp8_workspace_bytes(int batch, int num_heads_k, int k_tiles);
