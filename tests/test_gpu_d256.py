@@ -1,0 +1,160 @@
+"""GPU: head_dim 256 on the hand-scheduled kernel (32 query rows per wave, q-tile 128 x k-tile 64; generator run with LA_X64_D=256).
+The reference builds this head size by default (hopper/setup.py:57-61, instantiations/flash_fwd_hdim256_bf16_sm90.cu). Cases:
+dense ragged shapes and skip lists over several steps against the oracle, bf16 and fp16; the persistent multi-item loop with ticket
+stealing (more items than CUs) dynamic == static; LA_FLAG_KERNEL_128ROW (the hipcc-scheduled instantiation) as an independent
+second implementation with the same tiles; the longest supported key sequence."""
+import pytest
+import torch
+
+from helpers import structured_qkv
+from test_gpu_parity import _compare_lists
+
+pytestmark = pytest.mark.gpu
+D = 256
+
+
+def _L():
+    import liteattention_amd as L
+    assert L.get_tile_sizes(D, 2) == (128, 64)
+    return L
+
+
+def _orc():
+    from oracle import oracle as orc
+    return orc
+
+
+def _randn(B, Sq, Sk, H, seed, dtype=torch.bfloat16, Hk=None):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(B, Sq, H, D, generator=g).to(dtype), torch.randn(B, Sk, Hk or H, D, generator=g).to(dtype),
+            torch.randn(B, Sk, Hk or H, D, generator=g).to(dtype))
+
+
+def _tol(o_ref, dtype=torch.bfloat16, ulps=0.5):
+    """`ulps` units in the last place of the largest output (bf16 8 bits, fp16 11) + 1e-3."""
+    return ulps * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * o_ref.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (1, 17, 17, 1), (2, 129, 65, 3), (1, 1000, 1000, 2), (1, 300, 2100, 2), (1, 128, 64, 1),
+                                   (2, 257, 640, 4)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_dense_d256_matches_oracle(shape, dtype):
+    L, orc = _L(), _orc()
+    B, Sq, Sk, H = shape
+    q, k, v = _randn(B, Sq, Sk, H, seed=Sq * 7 + Sk, dtype=dtype)
+    out = torch.full((B, Sq, H, D), float("nan"), dtype=dtype, device="cuda")
+    from liteattention_amd.flash_attn_interface import mha_fwd
+    o2, lse, *_ = mha_fwd(q.cuda(), k.cuda(), v.cuda(), out=out)
+    assert o2 is out and torch.isfinite(out.float()).all()
+    o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=128, block_n=64, p_round="f16" if dtype == torch.float16 else True)
+    assert (out.float().cpu() - o_ref).abs().max().item() <= _tol(o_ref, dtype)
+    assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
+
+
+def test_gqa_and_strided_inputs_d256():
+    L, orc = _L(), _orc()
+    q, k, v = _randn(2, 200, 333, 6, seed=3, Hk=2)
+    big = torch.zeros(2, 333, 2, 2 * D, dtype=torch.bfloat16)
+    big[..., :D] = k
+    ks = big.cuda()[..., :D]                                   # row stride 2 * 2 * 256 elements, head stride 512
+    out, lse = L.flash_attn_func(q.cuda(), ks, v.cuda(), softmax_scale=0.05, return_softmax_lse=True)
+    o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=128, block_n=64, softmax_scale=0.05)
+    assert (out.float().cpu() - o_ref).abs().max().item() <= _tol(o_ref)
+    assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("use_must_do", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_multi_step_lists_d256_match_oracle(use_must_do, dtype):
+    L, orc = _L(), _orc()
+    thr = -2.0
+    B, S, H = 2, 1536, 2
+    BM, BN = 128, 64
+    Qt, Kt = S // BM, S // BN
+    att = L.LiteAttention(threshold=thr, max_batch_size=B)
+    must_do = [700, 400] if use_must_do else None
+    md_row = orc.expand_must_do_ref(must_do if use_must_do else [0, 0], BN, Kt + 1)
+    margins = torch.empty(B, H, Qt, Kt)
+    total_border, listed = 0, []
+    for step in range(5):
+        q, k, v = structured_qkv(B, S, H, D, seed=100, alpha=7.0, dtype=torch.float32)
+        g = torch.Generator().manual_seed(1000 + step)
+        q = (q + 0.05 * torch.randn(q.shape, generator=g)).to(dtype)
+        k = (k + 0.05 * torch.randn(k.shape, generator=g)).to(dtype)
+        v = v.to(dtype)
+        rd_idx = att._phase if att._skip_list is not None else 0
+        out, lse = att(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True, must_do_list=must_do)
+        rd, wr = att._skip_list[rd_idx].cpu(), att._skip_list[1 - rd_idx].cpu()
+        wr_orc = torch.zeros_like(wr)
+        o_ref, lse_ref, n_tiles = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN, read_list=rd, write_list=wr_orc, must_do_list=md_row,
+                                                 thr=thr, margins=margins, p_round="f16" if dtype == torch.float16 else True)
+        # structured inputs at head_dim 256 give rows with one or two dominant keys: P of such a key is rounded to 16 bits relative to
+        # the lazily updated reference max here and to the true running max in the oracle - different roundings of the same weight,
+        # 2^-9 relative each, not averaged away (measured: <= 0.9 ulp of the largest output; the hipcc-scheduled kernel, which
+        # rescales every step like the oracle, <= 0.5). One ulp is the bound; LSE and the lists do not see P's rounding.
+        assert (out.float().cpu() - o_ref).abs().max().item() <= _tol(o_ref, dtype, ulps=1.0)
+        assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
+        bad, border = _compare_lists(orc, rd, wr, wr_orc, margins, thr, B)
+        assert bad == 0, f"step {step}: {bad} rows differ from the oracle with no borderline tile"
+        total_border += border
+        listed.append(orc.listed_tiles(wr[:B]))
+        assert n_tiles == orc.listed_tiles(rd[:B])
+    assert listed == sorted(listed, reverse=True) and listed[-1] < 0.97 * B * H * Qt * Kt     # tiles really were dropped
+    assert total_border <= 2
+
+
+def test_persistent_loop_with_stealing_d256_dynamic_equals_static():
+    """B * H * q_tiles = 1024 items on 256 CUs, lists of different lengths per q-tile: the ticket path (re-iteration, stealing between
+    the per-XCD queues) must give bit-identical outputs and lists to the static one-workgroup-per-item map."""
+    L = _L()
+    B, S, H = 1, 8192, 16
+    q, k, v = [x.cuda() for x in structured_qkv(B, S, H, D, seed=7, alpha=7.0)]
+    res = []
+    for static in (False, True):
+        att = L.LiteAttention(threshold=-2.0, max_batch_size=B)
+        outs = []
+        for step in range(3):
+            from liteattention_amd.flash_attn_interface import mha_fwd
+            rd, wr = att._get_read_write_lists(q, v)
+            o, lse, *_ = mha_fwd(q, k, v, attn_read_list=rd, attn_write_list=wr, thr=att.threshold, _static_sched=static)
+            outs.append((o.clone(), lse.clone(), wr.clone()))
+        res.append(outs)
+    for (o1, l1, w1), (o2, l2, w2) in zip(*res):
+        assert torch.equal(o1, o2) and torch.equal(l1, l2) and torch.equal(w1, w2)
+    assert L.skip_list_stats(res[0][-1][2], 1)[0].item() < 0.9 * H * (S // 128) * (S // 64)
+
+
+def test_hand_scheduled_and_hipcc_scheduled_d256_kernels_agree(monkeypatch):
+    """LA_FLAG_KERNEL_128ROW selects the hipcc-scheduled 128-row template at head_dim 256 (same tiles): a second implementation of
+    the same walk. Write lists must be identical; outputs differ only by the lazy rescale (tau = 8 vs every step)."""
+    L = _L()
+    B, S, H = 1, 2048, 3
+    q, k, v = [x.cuda() for x in structured_qkv(B, S, H, D, seed=11, alpha=7.0)]
+    runs = {}
+    for name in ("x64", "v2"):
+        if name == "v2":
+            monkeypatch.setenv("LA_FWD_KERNEL", "v2")
+        att = L.LiteAttention(threshold=-2.0, max_batch_size=B)
+        for _ in range(3):
+            o, lse = att(q, k, v, return_softmax_lse=True)
+        runs[name] = (o, lse, att._skip_list.clone())
+    assert torch.equal(runs["x64"][2], runs["v2"][2])
+    assert (runs["x64"][0].float() - runs["v2"][0].float()).abs().max().item() <= 2.0 ** -7 * runs["v2"][0].float().abs().max().item()
+    assert (runs["x64"][1] - runs["v2"][1]).abs().max().item() <= 1e-4
+
+
+def test_longest_key_sequence_d256():
+    """128 KiB of the 160 KiB LDS are K/V rings at head_dim 256: 20.25 bytes per key tile for the walk leave ~1 570 tiles (100 k keys)."""
+    L = _L()
+    from liteattention_amd import _cabi
+    g = torch.Generator(device="cuda").manual_seed(0)
+    Sk = 1500 * 64
+    q = torch.randn(1, 128, 1, D, device="cuda", generator=g).bfloat16()
+    k = torch.randn(1, Sk, 1, D, device="cuda", generator=g).bfloat16()
+    v = torch.randn(1, Sk, 1, D, device="cuda", generator=g).bfloat16()
+    out, lse = L.flash_attn_func(q, k, v, return_softmax_lse=True)
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2))
+    assert (out.float() - ref.transpose(1, 2)).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-3
+    k2 = torch.zeros(1, 2000 * 64, 1, D, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match=_cabi.status_string(_cabi.LA_ERR_SEQLEN)[:20]):
+        L.flash_attn_func(q, k2, k2)

@@ -3,6 +3,7 @@
     python tools/asm_variants.py x_base=x64: x_nodma=x64:nodma f8_base=x64f8: ...
       name=x64:<opts>    gen_fwd_x64.py with LA_X64_OPT=<opts>
       name=x64f8:<opts>  gen_fwd_x64_fp8.py with LA_X64F8_OPT=<opts>
+      name=x64d256:<opts> gen_fwd_x64.py with LA_X64_D=256 LA_X64_OPT=<opts>
     (GPU box)  LITEATTENTION_AMD_LIB=$PWD/build_variants/<name>.so python tools/abl_bench.py
 Ablation variants compute wrong results; they only price a component.
 """
@@ -17,13 +18,17 @@ sys.path.insert(0, ROOT)
 def build_one(spec):
     name, _, opt = spec.partition("=")
     inc = os.path.join(OUT, f"{name}.inc")
+    extra_env = {}
     if opt.startswith("x64f8:"):          # name=x64f8:<opts> -> gen_fwd_x64_fp8.py with LA_X64F8_OPT (bench with --dtype fp8)
         opt, gen, env_key, macro = opt[6:], "gen_fwd_x64_fp8.py", "LA_X64F8_OPT", "LA_X64F8_BODY_INC"
     elif opt.startswith("x64:"):
         opt, gen, env_key, macro = opt[4:], "gen_fwd_x64.py", "LA_X64_OPT", "LA_X64_BODY_INC"
+    elif opt.startswith("x64d256:"):      # the head_dim-256 form of the bf16 generator (bench with tools/d256_bench.py)
+        opt, gen, env_key, macro = opt[8:], "gen_fwd_x64.py", "LA_X64_OPT", "LA_X64_D256_BODY_INC"
+        extra_env["LA_X64_D"] = "256"
     else:
-        raise SystemExit(f"{spec}: options must start with x64: (bf16) or x64f8: (fp8)")
-    subprocess.run([sys.executable, os.path.join(CSRC, gen), inc], check=True, env=dict(os.environ, **{env_key: opt}),
+        raise SystemExit(f"{spec}: options must start with x64: (bf16), x64d256: (bf16 head_dim 256) or x64f8: (fp8)")
+    subprocess.run([sys.executable, os.path.join(CSRC, gen), inc], check=True, env=dict(os.environ, **{env_key: opt}, **extra_env),
                    stdout=subprocess.DEVNULL)
     # the other generated include must exist too (default options)
     so = os.path.join(OUT, f"{name}.so")
