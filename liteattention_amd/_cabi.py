@@ -136,6 +136,13 @@ def status_string(code: int) -> str:
     return load().la_status_string(code).decode()
 
 
+def is_instantiated(head_dim: int, element_size: int, flags: int = None) -> bool:
+    """Does la_fwd have a kernel for exactly this head_dim (under the kernel-selection flags)? The library is the one table."""
+    m, n = ctypes.c_int(0), ctypes.c_int(0)
+    f = 0 if element_size == 1 else (default_flags() if flags is None else flags) & LA_FLAG_KERNEL_128ROW
+    return load().la_get_tile_sizes_ex(int(head_dim), int(element_size), f, ctypes.byref(m), ctypes.byref(n)) == LA_OK
+
+
 def get_tile_sizes(head_dim: int, element_size: int, flags: int = None) -> Tuple[int, int]:
     """(kBlockM, kBlockN) of the kernel la_fwd runs for this head_dim / element size (and kernel-selection flags; default:
     ``default_flags()``, what ``mha_fwd`` passes). fp8 has no 128-row kernel: the flag is dropped for 1-byte elements."""

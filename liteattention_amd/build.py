@@ -21,7 +21,8 @@ SOURCES = ["la_fwd_kernel_v2.hip", "la_fwd_kernel_x64.hip", "la_prep_fp8.hip", "
 HEADERS = ["la_kernel_params.h", "la_tiles.h", "la_fwd_common.h", "gen_fwd_x64.py", "gen_fwd_x64_fp8.py", "gen_epilogue.py"]
 X64_GEN, X64_INC = "gen_fwd_x64.py", "la_fwd_x64_body.inc"      # the hand-scheduled main loop, included by la_fwd_kernel_x64.hip
 X64_F16_INC = "la_fwd_x64_f16_body.inc"                        # the same generator with LA_X64_DTYPE=f16 (fp16 MFMA / conversions)
-X64_D256_INC, X64_D256_F16_INC = "la_fwd_x64_d256_body.inc", "la_fwd_x64_d256_f16_body.inc"     # ... with LA_X64_D=256 (32 rows per wave)
+X64_BODIES = [(128, "bf16", X64_INC), (128, "f16", X64_F16_INC)] + [
+    (d, t, f"la_fwd_x64_d{d}_{'f16_' if t == 'f16' else ''}body.inc") for d in (96, 192, 256) for t in ("bf16", "f16")]   # LA_X64_D / LA_X64_DTYPE
 X64F8_GEN, X64F8_INC = "gen_fwd_x64_fp8.py", "la_fwd_x64_fp8_body.inc"     # fp8: the same structure on the block-scaled MFMA
 
 
@@ -52,15 +53,12 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str = Non
 
 
 def _compile(lib_path: str, defines, verbose: bool) -> str:
-    subprocess.run([sys.executable, os.path.join(CSRC, X64_GEN), os.path.join(CSRC, X64_INC)], check=True,
-                   stdout=None if verbose else subprocess.DEVNULL)
-    subprocess.run([sys.executable, os.path.join(CSRC, X64_GEN), os.path.join(CSRC, X64_F16_INC)], check=True,
-                   stdout=None if verbose else subprocess.DEVNULL, env=dict(os.environ, LA_X64_DTYPE="f16"))
-    subprocess.run([sys.executable, os.path.join(CSRC, X64_GEN), os.path.join(CSRC, X64_D256_INC)], check=True,
-                   stdout=None if verbose else subprocess.DEVNULL, env=dict(os.environ, LA_X64_D="256", LA_X64_OPT=os.environ.get("LA_X64_D256_OPT", "")))
-    subprocess.run([sys.executable, os.path.join(CSRC, X64_GEN), os.path.join(CSRC, X64_D256_F16_INC)], check=True,
-                   stdout=None if verbose else subprocess.DEVNULL,
-                   env=dict(os.environ, LA_X64_D="256", LA_X64_DTYPE="f16", LA_X64_OPT=os.environ.get("LA_X64_D256_OPT", "")))
+    quiet = None if verbose else subprocess.DEVNULL
+    for head_dim, dtype, inc in X64_BODIES:       # one generated body per (head dim, 16-bit element type)
+        env = dict(os.environ, LA_X64_D=str(head_dim), LA_X64_DTYPE=dtype)
+        if head_dim != 128:                        # LA_X64_OPT tunes the head_dim-128 body (tools/asm_variants.py); the others have their own knob
+            env["LA_X64_OPT"] = os.environ.get(f"LA_X64_D{head_dim}_OPT", "")
+        subprocess.run([sys.executable, os.path.join(CSRC, X64_GEN), os.path.join(CSRC, inc)], check=True, stdout=quiet, env=env)
     subprocess.run([sys.executable, os.path.join(CSRC, X64F8_GEN), os.path.join(CSRC, X64F8_INC)], check=True,
                    stdout=None if verbose else subprocess.DEVNULL)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",

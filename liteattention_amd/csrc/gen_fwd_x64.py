@@ -50,19 +50,26 @@ CVT_OP = {"bf16": "v_cvt_pk_bf16_f32", "f16": "v_cvt_pk_f16_f32"}[DTYPE]        
 # Head dim of the body: 128 (two 32-row q-blocks per wave, q-tile 256) or 256 (LA_X64_D=256: ONE q-block per wave, q-tile 128 - O^T
 # alone is 128 registers per q-block there). Both have 32 + 32 MFMAs per step; the 256 form does half the softmax per step and
 # reads twice the K/V fragment bytes per FLOP. See the register-map comments below for what moves.
+# Head dims 96 and 192 (LA_X64_D=96 / 192) are the 128 / 256 forms with three quarters of the MFMAs: 12 / 24 K fragments and V^T
+# fragments per tile instead of 16 / 32, the LDS image keeps the 256 / 512-byte row pitch (both XOR swizzles are defined on it; the
+# quarter of each LDS row behind the data is filled with duplicates by the DMA lanes that have no column of their own).
 D = int(os.environ.get("LA_X64_D", "128"))
-assert D in (128, 256)
-NQB = 2 if D == 128 else 1                # 32-row q-blocks per wave
+assert D in (96, 128, 192, 256)
+DL = 128 if D <= 128 else 256             # layout head dim: LDS row pitch, q-blocks per wave, DMA pieces
+NQB = 2 if DL == 128 else 1               # 32-row q-blocks per wave
 KS = D // 16                              # k-steps of S^T = K Q^T
 DB = D // 32                              # 32-wide d-blocks of O^T
-ROW = 2 * D                               # bytes per K / V row
+ROW = 2 * DL                              # bytes per K / V row in LDS
 NKF, NVF = 2 * KS, 4 * DB                 # K fragments (A operands of QK) / V^T fragments (A operands of PV) per tile
+NG = NKF * NQB                            # MFMAs (= gaps for the other pipes) per phase: 32, or 24 for head dims 96 / 192
+assert NG == NVF * NQB
 PW = 16 * ROW // 1024                     # 1-KiB DMA pieces per wave per tile (a wave stages 16 of the 64 rows)
 XPAIRS = int(opt_val("x", "5"))          # pair-groups (of 16; one group = the same pair of both q-blocks) done in phase 2
 CAP1 = int(opt_val("cap1", "0"))          # fillers per MFMA gap the distributor may place (0 = balance evenly)
 CAP2 = int(opt_val("cap2", "0"))
-DMA_GAPS = [int(x) for x in opt_val("dmagaps", "1,2,4,6,8,10,11,13,15,17" if D == 128 else
+DMA_GAPS = [int(x) for x in opt_val("dmagaps", {128: "1,2,4,6,8,10,11,13,15,17", 96: "0,1,3,4,6,7,8,9,11,12"}[D] if DL == 128 else
                                     "1,2,3,4,5,7,8,9,10,11,13,14,15,16,17,19,20,21,22,23").replace(".", ",").split(",")]   # m0K,K0..3,m0V,V0..3 (phase 1)
+assert max(DMA_GAPS) < NG
 
 # ---------------------------------------------------------------- AGPR map
 def O_(qb, db):
@@ -89,8 +96,8 @@ KADDR = list(range(160, 168))
 VADDR = list(range(168, 172))
 # per-lane DMA source offsets, one per piece: head_dim 256 has 8 pieces per tensor; the second four sit in the registers the
 # second q-block's running state has at head_dim 128 (MTRUE[1], MREF[1], NMS[1], L0[1], L1[1], MLOC[1], MLOC2[1], ALPHA[1])
-LK = list(range(172, 176)) + ([181, 183, 185, 188] if D == 256 else [])
-LV = list(range(176, 180)) + ([189, 191, 193, 195] if D == 256 else [])
+LK = list(range(172, 176)) + ([181, 183, 185, 188] if DL == 256 else [])
+LV = list(range(176, 180)) + ([189, 191, 193, 195] if DL == 256 else [])
 # (L0[qb], L1[qb]) and (NMS[0], NMS[1]) are even-aligned 64-bit pairs: operands of the packed-fp32 VALU ops
 MTRUE, MREF, NMS, L0, L1, MLOC, MLOC2, ALPHA = ([180, 181], [182, 183], [184, 185], [186, 188], [187, 189], [190, 191],
                                                 [192, 193], [194, 195])
@@ -449,17 +456,17 @@ def n_fill(items):
 
 
 def distribute(queue, post, start, cap):
-    """Append the ops of `queue` (order kept) to post[start..31], topping every gap up to `cap` fillers."""
+    """Append the ops of `queue` (order kept) to post[start..NG-1], topping every gap up to `cap` fillers."""
     q = list(queue)
     if cap <= 0:
-        total = sum(n_fill(post[t]) for t in range(start, 32)) + n_fill(q)
-        cap = -(-total // (32 - start))
-    for t in range(start, 32):
+        total = sum(n_fill(post[t]) for t in range(start, NG)) + n_fill(q)
+        cap = -(-total // (NG - start))
+    for t in range(start, NG):
         while q and n_fill(post[t]) < cap:
             post[t].append(q.pop(0))
             while q and isinstance(q[0], str) and q[0].endswith(":"):      # a label sticks to the op before it
                 post[t].append(q.pop(0))
-    post[31] += q
+    post[NG - 1] += q
 
 
 deferred = []     # out-of-line blocks emitted after the loop: callables
@@ -478,28 +485,28 @@ def step(variant):
     ord2 = [(f % DB) * 4 + (f // DB) for f in range(NVF)]    # V^T fragment order: kk outer, d-block inner
 
     # ---- phase 1: QK^T(i+1) || rest of softmax(i), DMA issue (V(i+1), K(i+3)), first V^T fragments
-    pre = [[] for _ in range(32)]
-    post = [[] for _ in range(32)]
+    pre = [[] for _ in range(NG)]
+    post = [[] for _ in range(NG)]
     mf = []
-    for t in range(32):
+    for t in range(NG):
         mf.append(mfma_qk(nxt, ord1[t // NQB], t % NQB) if "nomfma1" not in OPT else "    s_nop 0")
     for g, op in zip(DMA_GAPS, dma_ops(kbuf_stage, vbuf_stage, st=variant)):
         post[g].append(op)
     if "novread" not in OPT:
-        for f in range(8):
-            post[16 + 2 * f] += v_read(f, vbuf_cur, ord2[f])
+        for f in range(8):                                   # the first 8 V^T fragments, spread over the second half of the phase
+            post[NG // 2 + f * (NG // 2) // 8] += v_read(f, vbuf_cur, ord2[f])
     vq = softmax_stream(cur, list(range(XPAIRS, 16)))
     distribute(vq, post, 0, CAP1)
-    for t in range(32):
+    for t in range(NG):
         for it in pre[t] + [mf[t]] + post[t]:
             out.append(it)
 
     # ---- phase 2: PV(i) || K(i+2) fragments -> AGPRs, rest of the V^T fragments, next step's DMA bases,
     #               stats(i+1), first part of softmax(i+1)
-    pre = [[] for _ in range(32)]
-    post = [[] for _ in range(32)]
+    pre = [[] for _ in range(NG)]
+    post = [[] for _ in range(NG)]
     mf = []
-    for t in range(32):
+    for t in range(NG):
         f, qb = t // NQB, t % NQB
         if qb == 0 and "novread" not in OPT and "nowaitv" not in OPT:
             pre[t].append(("WAIT", ("v", ord2[f], 1)))
@@ -544,7 +551,7 @@ def step(variant):
     # the first two gaps may only hold ops that do not read S_nxt (MFMA -> VALU read hazard): the SALU / seq part
     distribute(vq[:n_head], post, 0, CAP2 if CAP2 > 0 else 6)
     distribute(vq[n_head:], post, 2, CAP2)
-    for t in range(32):
+    for t in range(NG):
         for it in pre[t] + [mf[t]] + post[t]:
             out.append(it)
 
@@ -578,7 +585,7 @@ def prologue():
     emit(f"s_mov_b32 {s(S_CC)}, {s(S_C)}")
     emit(f"s_mov_b32 {s(S_CC + 1)}, {s(S_C)}")
     emit(f"s_sub_u32 {s(S_NM1)}, {s(S_NTILES)}, 1")
-    emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, {12 if D == 128 else 13}")      # a wave stages 16 rows = 4 / 8 KiB of a tile
+    emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, {12 if DL == 128 else 13}")      # a wave stages 16 rows = 4 / 8 KiB of a tile
     emit(f"s_add_u32 {s(S_DMAW)}, {s(S_DMAW)}, {s(S_LDS)}")
     emit(f"s_mov_b32 {s(S_I)}, 0")
     emit(f"s_mov_b32 {s(S_RESC)}, 0")
@@ -589,7 +596,7 @@ def prologue():
     emit(f"v_lshlrev_b32 {v(HH4)}, 2, {v(T[0])}")
     emit(f"v_and_b32 {v(T[1])}, 31, {v(LANE)}")               # l31
     emit(f"v_and_b32 {v(T[2])}, 15, {v(LANE)}")               # a16 / cpos
-    emit(f"v_lshlrev_b32 {v(T[3])}, {8 if D == 128 else 9}, {v(T[1])}")            # l31 * ROW
+    emit(f"v_lshlrev_b32 {v(T[3])}, {8 if DL == 128 else 9}, {v(T[1])}")            # l31 * ROW
     emit(f"v_add_u32 {v(T[3])}, {s(S_LDS)}, {v(T[3])}")
     for ks in range(8):
         emit(f"v_add_u32 {v(T[4])}, {2 * ks}, {v(T[0])}")
@@ -597,7 +604,7 @@ def prologue():
         emit(f"v_lshl_add_u32 {v(KADDR[ks])}, {v(T[4])}, 4, {v(T[3])}")
     emit(f"v_lshrrev_b32 {v(T[4])}, 2, {v(T[2])}")            # kq = a16 >> 2
     emit(f"v_add_u32 {v(T[5])}, {v(HH4)}, {v(T[4])}")         # key0
-    emit(f"v_lshlrev_b32 {v(T[5])}, {8 if D == 128 else 9}, {v(T[5])}")
+    emit(f"v_lshlrev_b32 {v(T[5])}, {8 if DL == 128 else 9}, {v(T[5])}")
     emit(f"v_add_u32 {v(T[5])}, {s(S_LDS)}, {v(T[5])}")
     emit(f"v_add_u32 {v(T[5])}, {V_REGION}, {v(T[5])}")
     emit(f"v_lshrrev_b32 {v(T[6])}, 4, {v(LANE)}")            # g = lane >> 4 = rip
@@ -610,7 +617,7 @@ def prologue():
         emit(f"v_xor_b32 {v(T[7])}, {db}, {v(T[4])}")
         emit(f"v_lshl_add_u32 {v(VADDR[db])}, {v(T[7])}, 6, {v(T[5])}")
     emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 4")
-    if D == 128:
+    if DL == 128:
         # DMA image: a 1-KiB piece = 4 rows of 256 bytes; lane -> (row in piece rip = lane >> 4, chunk cpos = lane & 15)
         emit(f"v_add_u32 {v(RIPROW)}, {s(S_T0)}, {v(T[6])}")      # 16*wave + rip
         emit(f"v_xor_b32 {v(RAGK)}, {v(T[2])}, {v(T[6])}")
@@ -635,13 +642,22 @@ def prologue():
         emit(f"v_add_u32 {v(T[4])}, {RSTEP * j}, {v(RIPROW)}")
         emit(f"v_min_i32 {v(T[4])}, {v(T[4])}, {s(S_T1)}")
         emit(f"v_mul_lo_u32 {v(LK[j])}, {v(T[4])}, {s(S_KRS)}")
+        def in_row(reg):
+            """head dims 96 / 192: a source chunk past the row's 2 D bytes (the LDS image is 2 DL bytes wide) -> 64 bytes lower: a
+            duplicate of a valid chunk, written to an LDS position no fragment read ever touches"""
+            if D != DL:
+                emit(f"v_subrev_u32 {v(T[7])}, {2 * DL - 2 * D}, {v(reg)}")
+                emit(f"v_cmp_le_u32 vcc, {2 * D}, {v(reg)}")
+                emit(f"v_cndmask_b32 {v(reg)}, {v(reg)}, {v(T[7])}, vcc")
         emit(f"v_xor_b32 {v(T[5])}, {(RSTEP * j) << 4}, {v(RAGK)}")
+        in_row(T[5])
         emit(f"v_add_u32 {v(LK[j])}, {v(LK[j])}, {v(T[5])}")
         emit(f"v_mul_lo_u32 {v(LV[j])}, {v(T[4])}, {s(S_VRS)}")
         if D == 128:
             emit(f"v_add_u32 {v(LV[j])}, {v(LV[j])}, {v(RAGV)}")
         else:
             emit(f"v_xor_b32 {v(T[5])}, {((RSTEP * j) & 3) << 6}, {v(RAGV)}")
+            in_row(T[5])
             emit(f"v_add_u32 {v(LV[j])}, {v(LV[j])}, {v(T[5])}")
         if bias:
             emit(f"v_add_u32 {v(LK[j])}, {bias}, {v(LK[j])}")
@@ -670,10 +686,10 @@ def prologue():
         emit(f"v_cmp_gt_i32 vcc, {s(S_SEQLENQ)}, {v(QROW[qb])}")
         for r in range(4 * KS):
             emit(f"v_cndmask_b32 {v(4 * KS * qb + r)}, 0, {v(4 * KS * qb + r)}, vcc")
-    for r in range(64):
+    for r in range(4 * KS * NQB):
         emit(f"v_accvgpr_write_b32 a{128 + r}, {v(r)}")
     emit("; ---- state")
-    for r in range(128):
+    for r in range(16 * DB * NQB):
         emit(f"v_accvgpr_write_b32 a{r}, 0")
     for qb in range(NQB):
         emit(f"v_mov_b32 {v(MTRUE[qb])}, 0xff800000")
@@ -693,7 +709,7 @@ def prologue():
     emit(f"v_readfirstlane_b32 {s(TBS[0])}, {v(T[8])}")
     emit(f"v_readfirstlane_b32 {s(TBS[0] + 1)}, {v(T[9])}")
     ord1 = [(f & 1) * KS + (f >> 1) for f in range(NKF)]
-    for t in range(32):
+    for t in range(NG):
         out.append(mfma_qk(0, ord1[t // NQB], t % NQB))
     for j in range(NKF):
         emit(k_read(KV_TILE, j))

@@ -19,7 +19,9 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 // Kernel selection is a pure function of the arguments (no environment variables, no process-wide statics):
 //   bf16 / fp16 head_dim 128: the 256-row hand-scheduled kernel (x64) unless LA_FLAG_KERNEL_128ROW asks for the 128-row one (v2);
 //   head_dim 256: the hand-scheduled kernel in its 32-rows-per-wave form (q-tile 128) unless LA_FLAG_KERNEL_128ROW asks for the
-//   hipcc-scheduled v2 instantiation (same tiles); head_dim 64: v2; fp8 head_dim 128: x64-fp8. The skip lists are indexed by the selected kernel's tile, so
+//   hipcc-scheduled v2 instantiation (same tiles); head_dim 96 / 192: the 128 / 256 hand-scheduled forms with three quarters of
+//   the fragments (no v2 instantiation: LA_ERR_HEAD_DIM under LA_FLAG_KERNEL_128ROW, hosts pad to 128 / 256 then);
+//   head_dim 64: v2; fp8 head_dim 128: x64-fp8. The skip lists are indexed by the selected kernel's tile, so
 //   la_get_tile_sizes_ex and la_fwd must agree on it: both call uses_128row().
 constexpr uint32_t kKnownFlags = LA_FLAG_V_PREPARED | LA_FLAG_STATIC_SCHED | LA_FLAG_KERNEL_128ROW | LA_FLAG_EXACT_RESCALE;
 bool uses_128row(int head_dim, int element_size, uint32_t flags) {
@@ -60,6 +62,7 @@ int la_get_tile_sizes_ex(int head_dim, int element_size, uint32_t flags, int* bl
     if (t.block_m == 0) return (element_size == 2 || element_size == 1) ? LA_ERR_HEAD_DIM : LA_ERR_DTYPE;
     if ((flags & ~kKnownFlags) != 0) return LA_ERR_UNSUPPORTED;
     if ((flags & LA_FLAG_KERNEL_128ROW) && element_size == 1) return LA_ERR_UNSUPPORTED;   // the 128-row fp8 kernel is not in this build
+    if ((flags & LA_FLAG_KERNEL_128ROW) && (head_dim == 96 || head_dim == 192)) return LA_ERR_HEAD_DIM;   // the hipcc-scheduled template has 64 / 128 / 256
     if (uses_128row(head_dim, element_size, flags)) t.block_m = 128;                       // A/B kernel: 32 rows per wave
     if (block_m) *block_m = t.block_m;
     if (block_n) *block_n = t.block_n;
@@ -180,7 +183,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     p.k_descale_batch_stride = a->k_descale_batch_stride; p.k_descale_head_stride = a->k_descale_head_stride;
     p.v_descale_batch_stride = a->v_descale_batch_stride; p.v_descale_head_stride = a->v_descale_head_stride;
 
-    if (!fp8 && la::fwd_lds_bytes_v2(a->head_dim, p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
+    if (!fp8 && la::fwd_lds_bytes_v2(a->head_dim <= 128 ? a->head_dim : 256, p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
     if (static_cast<int64_t>(p.batch) * p.num_heads * p.q_tiles > 0x7fffffffLL) return LA_ERR_SHAPE;
 
     if (fp8) {
@@ -199,7 +202,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     }
     // head_dim 128: the 256-row x64 kernel unless LA_FLAG_KERNEL_128ROW; head_dim 64 / 256: the 128-row v2 template.
     const bool skipable = a->read_list != nullptr;                                      // is_skipable, flash_api.cpp:931
-    const bool x64 = (a->head_dim == 128 || a->head_dim == 256) && !(a->flags & LA_FLAG_KERNEL_128ROW);
+    const bool x64 = a->head_dim != 64 && !(a->flags & LA_FLAG_KERNEL_128ROW);       // 96 / 128 / 192 / 256
     hipError_t err;
     // optional workspace (la_fwd_workspace_bytes): with it, launches that walk lists use persistent workgroups and the
     // ticket queues; without it, the static one-workgroup-per-item map (same results either way)

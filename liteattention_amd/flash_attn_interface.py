@@ -70,18 +70,18 @@ _FWD_SCHEMA = (
 
 
 def kernel_head_dim(head_dim: int, element_size: int) -> int:
-    """The instantiated head_dim that serves ``head_dim``: itself for 64 / 128 (bf16) and 128 (fp8), else the next
-    instantiated size up — the host zero-pads q, k, v to it (``mha_fwd``), which is exact: zero columns add 0 to
-    every score and give zero output columns, which are sliced away. The reference instantiates 64/96/128/192/256
-    (hopper/setup.py:57-61) and picks the next size up the same way (flash_api.cpp round_up_headdim). bf16: 64, 128, 256
-    are built (192 runs on the 256 kernel); fp8: 128; beyond that the library's typed error is raised."""
+    """The instantiated head_dim that serves ``head_dim``: the next size up for which the library has a kernel — the host
+    zero-pads q, k, v to it (``mha_fwd``), which is exact: zero columns add 0 to every score and give zero output columns,
+    which are sliced away. The reference instantiates 64/96/128/192/256 (hopper/setup.py:57-61) and picks the next size up the
+    same way (flash_api.cpp round_up_headdim). bf16 / fp16: 64, 96, 128, 192, 256 are built (with LA_FWD_KERNEL=v2, the
+    hipcc-scheduled A/B kernels: 64, 128, 256); fp8: 128; beyond that the library's typed error is raised. The library is
+    asked (``la_get_tile_sizes_ex``), there is no second table here."""
     if head_dim <= 0 or head_dim % (16 if element_size == 1 else 8) != 0:
         return head_dim                                      # la_get_tile_sizes / mha_fwd report the error
-    if element_size == 2 and head_dim <= 64:
-        return 64
-    if head_dim <= 128:
-        return 128
-    return 256 if (element_size == 2 and head_dim <= 256) else head_dim
+    for d in (64, 96, 128, 192, 256):
+        if d >= head_dim and _cabi.is_instantiated(d, element_size):
+            return d
+    return head_dim
 
 
 def get_tile_sizes(head_dim: int, element_size: int) -> Tuple[int, int]:

@@ -52,6 +52,7 @@ def test_struct_layout_matches_header(tmp_path):
 
 def test_tile_sizes_and_status_strings():
     assert _cabi.get_tile_sizes(128, 2) == (256, 64) and _cabi.get_tile_sizes(64, 2) == (128, 64)
+    assert _cabi.get_tile_sizes(96, 2) == (256, 64) and _cabi.get_tile_sizes(192, 2) == (128, 64) and _cabi.get_tile_sizes(256, 2) == (128, 64)
     assert _cabi.get_tile_sizes(128, 1) == (256, 64)
     lib = _cabi.load()
     m, n = ctypes.c_int(), ctypes.c_int()
@@ -93,8 +94,12 @@ def test_argument_validation_returns_codes_without_launching():
     a.flags = 0
     a.head_dim = a.head_dim_v = 100
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_HEAD_DIM        # % 8 (flash_api.cpp:854)
+    a.head_dim = a.head_dim_v = 80
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_HEAD_DIM        # not instantiated (64 / 96 / 128 / 192 / 256 are)
     a.head_dim = a.head_dim_v = 96
-    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_HEAD_DIM        # not instantiated
+    a.flags = _cabi.LA_FLAG_KERNEL_128ROW
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_HEAD_DIM        # the hipcc-scheduled A/B template has 64 / 128 / 256 only
+    a.flags = 0
     a.head_dim = a.head_dim_v = 128
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_TILE_MISMATCH
     a.block_m, a.block_n = 256, 64

@@ -3,7 +3,7 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import liteattention_amd as L
-for D, S, H in ((256, 16384, 40), (192, 16384, 40)):
+for D, S, H in ((256, 16384, 40), (192, 16384, 40), (96, 16384, 40)):
     g = torch.Generator(device="cuda").manual_seed(0)
     q, k, v = [torch.randn(1, S, H, D, device="cuda", generator=g).bfloat16() for _ in range(3)]
     for _ in range(2): L.flash_attn_func(q, k, v)
