@@ -64,6 +64,14 @@ NKF, NVF = 2 * KS, 4 * DB                 # K fragments (A operands of QK) / V^T
 NG = NKF * NQB                            # MFMAs (= gaps for the other pipes) per phase: 32, or 24 for head dims 96 / 192
 assert NG == NVF * NQB
 PW = 16 * ROW // 1024                     # 1-KiB DMA pieces per wave per tile (a wave stages 16 of the 64 rows)
+# Where the K fragments of tile i+2 are read from LDS. Two q-blocks per wave: during phase 2 of step i (the LDS pipe has room there).
+# One q-block per wave (head dims 192 / 256): a phase moves the same 32 MFMAs over half the rows, so LDS bytes per MFMA double and
+# phase 2 (24 V^T + 32 K fragments = 56 KiB per wave, 85 % of the CU's LDS read rate) stalls the MFMAs; there every K fragment
+# register is refilled in PHASE 1, right behind the QK MFMA of tile i+1 that consumed it (K(i+2) has been in LDS since the barrier
+# of step i-1): 38 / 26 KiB per phase instead of 8 / 56. Measured (dense S=16384 H=40, same box): head_dim 256 1201 -> 1218 TFLOP/s
+# (+1.4 %), head_dim 192 1111 -> 1107 (24 + 24 KiB there: nothing to balance) - small, because these forms sit at the power limit
+# too (1.8-1.9 GHz). Default: 256 only; `kearly` / `klate2` force it on / off for A/B.
+K_EARLY = NQB == 1 and (D == 256 or "kearly" in OPT) and "klate2" not in OPT
 XPAIRS = int(opt_val("x", "5"))          # pair-groups (of 16; one group = the same pair of both q-blocks) done in phase 2
 CAP1 = int(opt_val("cap1", "0"))          # fillers per MFMA gap the distributor may place (0 = balance evenly)
 CAP2 = int(opt_val("cap2", "0"))
@@ -492,6 +500,10 @@ def step(variant):
         mf.append(mfma_qk(nxt, ord1[t // NQB], t % NQB) if "nomfma1" not in OPT else "    s_nop 0")
     for g, op in zip(DMA_GAPS, dma_ops(kbuf_stage, vbuf_stage, st=variant)):
         post[g].append(op)
+    if K_EARLY and "nokread" not in OPT:
+        for t in range(NG):
+            if t % NQB == NQB - 1:                           # the last MFMA that reads fragment ord1[t // NQB] has issued
+                post[t].append(k_read(kbuf_read, ord1[t // NQB]))
     if "novread" not in OPT:
         for f in range(8):                                   # the first 8 V^T fragments, spread over the second half of the phase
             post[NG // 2 + f * (NG // 2) // 8] += v_read(f, vbuf_cur, ord2[f])
@@ -513,7 +525,7 @@ def step(variant):
         mf.append(mfma_pv(cur, f % 8, ord2[f], qb) if "nomfma2" not in OPT else "    s_nop 0")
         if qb == NQB - 1 and f + 8 < NVF and "novread" not in OPT:
             post[t] += v_read(f % 8, vbuf_cur, ord2[f + 8])
-        if "nokread" not in OPT and (t < NKF if "klate" not in OPT else (t & 1) == 0):
+        if "nokread" not in OPT and not K_EARLY and (t < NKF if "klate" not in OPT else (t & 1) == 0):
             post[t].append(k_read(kbuf_read, ord1[t if "klate" not in OPT else f]))
     rare, back = new_label("rare"), new_label("rare_back")
     fl, flback = new_label("flush"), new_label("flush_back")

@@ -3,7 +3,7 @@
     python tools/asm_variants.py x_base=x64: x_nodma=x64:nodma f8_base=x64f8: ...
       name=x64:<opts>    gen_fwd_x64.py with LA_X64_OPT=<opts>
       name=x64f8:<opts>  gen_fwd_x64_fp8.py with LA_X64F8_OPT=<opts>
-      name=x64d256:<opts> gen_fwd_x64.py with LA_X64_D=256 LA_X64_OPT=<opts>
+      name=x64d<D>:<opts> gen_fwd_x64.py with LA_X64_D=<D> (96, 192, 256) LA_X64_OPT=<opts>
     (GPU box)  LITEATTENTION_AMD_LIB=$PWD/build_variants/<name>.so python tools/abl_bench.py
 Ablation variants compute wrong results; they only price a component.
 """
@@ -23,9 +23,10 @@ def build_one(spec):
         opt, gen, env_key, macro = opt[6:], "gen_fwd_x64_fp8.py", "LA_X64F8_OPT", "LA_X64F8_BODY_INC"
     elif opt.startswith("x64:"):
         opt, gen, env_key, macro = opt[4:], "gen_fwd_x64.py", "LA_X64_OPT", "LA_X64_BODY_INC"
-    elif opt.startswith("x64d256:"):      # the head_dim-256 form of the bf16 generator (bench with tools/d256_bench.py)
-        opt, gen, env_key, macro = opt[8:], "gen_fwd_x64.py", "LA_X64_OPT", "LA_X64_D256_BODY_INC"
-        extra_env["LA_X64_D"] = "256"
+    elif opt.startswith(("x64d96:", "x64d192:", "x64d256:")):      # the other head dims of the bf16 generator (bench with tools/d256_bench.py <D>)
+        dim = opt[4:opt.index(":")]
+        opt, gen, env_key, macro = opt[opt.index(":") + 1:], "gen_fwd_x64.py", "LA_X64_OPT", f"LA_X64_D{dim}_BODY_INC"
+        extra_env["LA_X64_D"] = dim
     else:
         raise SystemExit(f"{spec}: options must start with x64: (bf16), x64d256: (bf16 head_dim 256) or x64f8: (fp8)")
     subprocess.run([sys.executable, os.path.join(CSRC, gen), inc], check=True, env=dict(os.environ, **{env_key: opt}, **extra_env),

@@ -36,13 +36,16 @@ for cfg in "imposed 0.0" "imposed 0.42" "imposed 0.77" "real -4.22" "real -2.46"
   pmc ${n}_write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- $P
   pmc ${n}_busy GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- $P
 done
-# 5. the other instantiations: bench lines + kernel stats + MFMA utilisation
-for t in d64 d256; do
+# 5. the other instantiations: bench lines + kernel stats + MFMA utilisation (d64: tools/d64_bench.py; 96 / 192 / 256: tools/d256_bench.py <D>)
+for t in d64 d96 d192 d256; do
   want other || continue
-  python $R/tools/${t}_bench.py > $OUT/${t}_bench.txt 2>&1
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${t}_kt -o kt -- python $R/tools/${t}_bench.py > $OUT/${t}_kt.log 2>&1
-  pmc ${t}_mfma SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -- python $R/tools/${t}_bench.py
+  if [ $t = d64 ]; then C="python $R/tools/d64_bench.py"; else C="python $R/tools/d256_bench.py ${t#d}"; fi
+  $C > $OUT/${t}_bench.txt 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${t}_kt -o kt -- $C > $OUT/${t}_kt.log 2>&1
+  pmc ${t}_mfma SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -- $C
 done
+# the hipcc-scheduled A/B kernels on the same box (head dims 192 / 96 zero-padded onto 256 / 128 by the host)
+want other && LA_FWD_KERNEL=v2 python $R/tools/d256_bench.py > $OUT/v2_bench.txt 2>&1
 ls $OUT | head -80
 grep -h PROBE $OUT/traffic_*_fetch.log 2>/dev/null
 [ -f $OUT/bench_line.json ] && tail -c 300 $OUT/bench_line.json

@@ -172,10 +172,15 @@ if rows:
     json.dump({"kernel_source_sha16": sha, "rows": rows}, open(os.path.join(PROF, f"{tag}_traffic_vs_sparsity.json"), "w"), indent=1)
 
 # ---- other instantiations
-md = [f"# Other instantiations `{tag}` (bf16 head_dim 64, 256, 192-on-256), kernel sources {sha}", ""]
-for t in ("d64", "d256"):
+md = [f"# Other instantiations `{tag}` (bf16 head_dim 64, 96, 192, 256), kernel sources {sha}", ""]
+if os.path.exists(os.path.join(src, "v2_bench.txt")):
+    md += ["Same box, `LA_FWD_KERNEL=v2 python tools/d256_bench.py` (the hipcc-scheduled 128-row kernels; 192 / 96 zero-padded onto 256 / 128):", "", "```"] + \
+          [l for l in open(os.path.join(src, "v2_bench.txt")).read().strip().splitlines() if "amdgpu.ids" not in l] + ["```", ""]
+for t in ("d64", "d96", "d192", "d256"):
+    if not os.path.exists(os.path.join(src, f"{t}_bench.txt")):
+        continue
     txt = open(os.path.join(src, f"{t}_bench.txt")).read().strip().splitlines() if os.path.exists(os.path.join(src, f"{t}_bench.txt")) else []
-    md += [f"## {t}", "", "bench (`python tools/%s_bench.py`, un-profiled):" % t, "", "```"] + [l for l in txt if "amdgpu.ids" not in l] + ["```", ""]
+    md += [f"## {t}", "", "bench (`python tools/%s`, un-profiled):" % ("d64_bench.py" if t == "d64" else "d256_bench.py " + t[1:]), "", "```"] + [l for l in txt if "amdgpu.ids" not in l] + ["```", ""]
     st = kernel_stats(f"{t}_kt")
     md += ["| kernel | calls | avg ms | % |", "|---|---|---|---|"] + [f"| `{short(r['name'])}` | {r['calls']} | {r['avg_ms']:.3f} | {r['pct']:.2f} |" for r in st[:4]]
     pmc, meta, n = counters(f"{t}_mfma")
