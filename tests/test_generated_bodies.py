@@ -1,0 +1,71 @@
+"""CPU: static checks on the generated gfx950 bodies (liteattention_amd/csrc/gen_fwd_x64*.py). The bodies run inside a C++ shell
+whose inline-asm statement declares what they clobber (v0-v222, s35-s95, every AGPR, m0, vcc, scc): a register outside that set
+written by a body would silently corrupt compiler-owned state. Also pins the MFMA counts per step and that the head_dim-128 bodies of
+the two 16-bit types differ in nothing but the MFMA / convert opcodes."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "liteattention_amd", "csrc")
+CASES = [("gen_fwd_x64.py", {"LA_X64_D": str(d), "LA_X64_DTYPE": t}) for d in (96, 128, 192, 256) for t in ("bf16", "f16")] + \
+        [("gen_fwd_x64_fp8.py", {})]
+
+
+def _generate(tmp_path, gen, env):
+    out = tmp_path / "body.inc"
+    e = dict(os.environ, **env)
+    e.pop("LA_X64_OPT", None)
+    e.pop("LA_X64F8_OPT", None)
+    subprocess.run([sys.executable, os.path.join(CSRC, gen), str(out)], check=True, stdout=subprocess.DEVNULL, env=e)
+    return out.read_text()
+
+
+def _registers(text):
+    """(max VGPR, max AGPR, set of SGPRs) named anywhere in the body."""
+    vmax = amax = -1
+    sgprs = set()
+    for kind, lo, hi, single in re.findall(r"\b([vas])(?:\[(\d+):(\d+)\]|(\d+))\b", text):
+        first, last = (int(single), int(single)) if single else (int(lo), int(hi))
+        if kind == "v":
+            vmax = max(vmax, last)
+        elif kind == "a":
+            amax = max(amax, last)
+        else:
+            sgprs.update(range(first, last + 1))
+    return vmax, amax, sgprs
+
+
+@pytest.mark.parametrize("gen,env", CASES, ids=[f"{g[:-3]}-{'-'.join(e.values())}" for g, e in CASES])
+def test_body_stays_inside_the_declared_clobbers(tmp_path, gen, env):
+    text = _generate(tmp_path, gen, env)
+    body = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith((";", "//")))
+    vmax, amax, sgprs = _registers(body)
+    assert 0 <= vmax <= 222, vmax                      # LA_X64_CLOBBERS: v0 .. v222
+    assert amax <= 255
+    assert sgprs and min(sgprs) >= 35 and max(sgprs) <= 95, (min(sgprs), max(sgprs))      # s32-s34 are ABI-reserved, s0-s31 the shell's
+    assert "%0" in body and "%1" in body               # the two inputs: wave index, LDS address of the parameter block
+    assert "s_setpc" not in body and "s_endpgm" not in body
+    # every label is local to the asm statement (%= suffix): two instantiations in one translation unit must not collide
+    for lab in re.findall(r"^\s*([.\w%=]+):\s*$", body, flags=re.M):
+        assert lab.endswith("%="), lab
+
+
+@pytest.mark.parametrize("D,per_phase", [(96, 24), (128, 32), (192, 24), (256, 32)])
+def test_mfma_count_per_step(tmp_path, D, per_phase):
+    """prologue QK of tile 0 (one phase) + two unrolled steps of (QK + PV): 5 phases of MFMAs."""
+    text = _generate(tmp_path, "gen_fwd_x64.py", {"LA_X64_D": str(D)})
+    assert text.count("v_mfma_f32_32x32x16_bf16") == 5 * per_phase
+    assert "v_mfma_f32_32x32x16_f16" not in text
+
+
+def test_fp16_body_differs_only_in_the_type_dependent_opcodes(tmp_path):
+    a = _generate(tmp_path, "gen_fwd_x64.py", {"LA_X64_D": "128", "LA_X64_DTYPE": "bf16"})
+    b = _generate(tmp_path, "gen_fwd_x64.py", {"LA_X64_D": "128", "LA_X64_DTYPE": "f16"})
+    norm = lambda t: t.replace("v_mfma_f32_32x32x16_bf16", "MFMA").replace("v_mfma_f32_32x32x16_f16", "MFMA") \
+                      .replace("v_cvt_pk_bf16_f32", "CVT").replace("v_cvt_pk_f16_f32", "CVT")                      # noqa: E731
+    la, lb = norm(a).splitlines(), norm(b).splitlines()
+    assert len(la) == len(lb)
+    assert [x for x, y in zip(la, lb) if x != y and not x.lstrip().startswith(("//", ";"))] == []
