@@ -57,10 +57,11 @@ typedef enum la_status {
 } la_status;
 
 /* la_fwd_args.flags */
-#define LA_FLAG_KERNEL_128ROW 4u /* A/B: run the 128-row (32 rows per wave, hipcc-scheduled) kernel where the default is the 256-row
-                                  * hand-scheduled one (bf16 head_dim 128). The skip lists then use 128-row q-tiles: take the tile
-                                  * sizes from la_get_tile_sizes_ex() with the same flags. fp8: needs a -DLA_WITH_AB_KERNELS build. */
-#define LA_FLAG_EXACT_RESCALE 8u /* A/B: the 256-row kernels rescale O on EVERY growth of a row maximum (tau = 0) instead of lazily
+#define LA_FLAG_KERNEL_128ROW 4u /* A/B: run the hipcc-scheduled 128-row template (32 rows per wave) where the default is the
+                                  * hand-scheduled kernel: bf16 / fp16 head_dim 128 (the skip lists then use 128-row q-tiles instead of
+                                  * 256-row ones: take the tile sizes from la_get_tile_sizes_ex() with the same flags) and head_dim 256
+                                  * (same tiles). head_dim 96 / 192 have no such instantiation: LA_ERR_HEAD_DIM. fp8: LA_ERR_UNSUPPORTED. */
+#define LA_FLAG_EXACT_RESCALE 8u /* A/B: the hand-scheduled kernels rescale O on EVERY growth of a row maximum (tau = 0) instead of lazily
                                   * (bf16: only after it grew by more than 2^8; results agree to rounding, lists are identical) */
 #define LA_FLAG_STATIC_SCHED 2u  /* keep one workgroup per item (static XCD map) even when a workspace is given. For
                                   * launches that must share the GPU with another kernel while they run — e.g. an RCCL

@@ -200,7 +200,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         if (e8 != hipSuccess) { g_last_hip_error = static_cast<int>(e8); return LA_ERR_LAUNCH; }
         return LA_OK;
     }
-    // head_dim 128: the 256-row x64 kernel unless LA_FLAG_KERNEL_128ROW; head_dim 64 / 256: the 128-row v2 template.
+    // head_dim 96 / 128 / 192 / 256: the hand-scheduled x64 kernel unless LA_FLAG_KERNEL_128ROW; head_dim 64: the 128-row v2 template.
     const bool skipable = a->read_list != nullptr;                                      // is_skipable, flash_api.cpp:931
     const bool x64 = a->head_dim != 64 && !(a->flags & LA_FLAG_KERNEL_128ROW);       // 96 / 128 / 192 / 256
     hipError_t err;
