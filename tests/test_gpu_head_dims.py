@@ -174,3 +174,36 @@ def test_longest_key_sequence(D):
     k2 = torch.zeros(1, 2000 * 64, 1, D, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match=_cabi.status_string(_cabi.LA_ERR_SEQLEN)[:20]):
         L.flash_attn_func(q, k2, k2)
+
+
+@pytest.mark.parametrize("D", DIMS)
+def test_race_screen_200_iterations(D):
+    """The reference's race screen (hopper/tests/test_flash_attn.py:1144-1175; the 1000-iteration form runs at head_dim 128 in
+    test_gpu_round2.py) on these bodies: real, fragmented, unequal lists, more items than CUs (persistent loop, ticket stealing), a
+    co-running memory hog on a second stream; every launch identical to the first in O, LSE and the write list."""
+    L = _L()
+    B, S, H, thr = 1, 8192, 8, -2.0
+    q, k, v = [x.cuda() for x in structured_qkv(B, S, H, D, seed=700, alpha=7.0, frames=16)]
+    att = L.LiteAttention(threshold=thr, max_batch_size=B)
+    for _ in range(3):
+        att(q, k, v)
+    base, phase = att._skip_list.clone(), att._phase
+    assert 0.02 < att.get_skip_fraction(batch=B) < 0.95
+
+    def run():
+        att._skip_list.copy_(base)
+        att._phase = phase
+        return att(q, k, v, return_softmax_lse=True)
+
+    hog_stream = torch.cuda.Stream()
+    hog_a = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    hog_b = torch.empty_like(hog_a)
+    out0, lse0 = run()
+    out0, lse0, lists0 = out0.clone(), lse0.clone(), att._skip_list.clone()
+    for it in range(200):
+        if it % 4 == 0:
+            with torch.cuda.stream(hog_stream):
+                hog_b.copy_(hog_a)
+        out, lse = run()
+        assert torch.equal(out, out0) and torch.equal(lse, lse0) and torch.equal(att._skip_list, lists0), it
+    torch.cuda.synchronize()

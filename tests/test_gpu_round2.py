@@ -420,7 +420,7 @@ def test_race_screen_1000_iterations(path):
 
 
 # ------------------------------------------------------------------------------------------ malformed lists
-@pytest.mark.parametrize("dtype,D", [("bf16", 128), ("fp8", 128), ("bf16", 64)])
+@pytest.mark.parametrize("dtype,D", [("bf16", 128), ("fp8", 128), ("bf16", 64), ("bf16", 96), ("bf16", 192), ("bf16", 256)])
 def test_garbage_read_lists_are_memory_safe(dtype, D):
     """The read list is caller-owned memory: whatever it holds (negative or huge tile numbers, ascending or overlapping ranges,
     a length word beyond the row, zeros), the kernel must stay inside q / k / v / the write list - tile numbers are clamped to
