@@ -116,6 +116,35 @@ def cpu_baseline(S, D, bm, bn, rows, target_seconds=15.0):
     return res
 
 
+def other_head_dims(L, dev, dims=(64, 96, 192, 256), S=16384, H=40, reps=5):
+    """The reference's other default head sizes (hopper/setup.py:57-61), dense bf16 at S=16384 H=40: useful TFLOP/s by HIP events on
+    the launch stream, and a sampled-row check of the timed output against fp32 torch. 64: the hipcc-scheduled 128-row template;
+    96 / 192 / 256: the hand-scheduled kernel's other bodies."""
+    import torch
+    from liteattention_amd.selfcheck import sampled_row_check
+    out = {"what": f"dense bf16 B=1 S={S} H={H}, {reps} launches per head dim", "runs": []}
+    g = torch.Generator(device=dev).manual_seed(2)
+    for D in dims:
+        q, k, v = [torch.randn(1, S, H, D, device=dev, generator=g).bfloat16() for _ in range(3)]
+        for _ in range(2):
+            o, lse = L.flash_attn_func(q, k, v, return_softmax_lse=True)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record()
+            o, lse = L.flash_attn_func(q, k, v, return_softmax_lse=True)
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in ev)[reps // 2]
+        bm, bn = L.get_tile_sizes(D, 2)
+        ver = sampled_row_check(q, k, v, o, lse, None, bm, bn, heads=(0, H - 1), n_rows=64)
+        tf = 4.0 * H * S * S * D / (ms * 1e-3) / 1e12
+        out["runs"].append({"head_dim": D, "tiles": [bm, bn], "ms": round(ms, 3), "tflops": round(tf, 1),
+                            "frac_of_mfma_peak": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                            "verified": {"rows": ver["rows"], "max_err": ver["max_err"], "max_err_lse": ver["max_err_lse"], "ok": ver["ok"]}})
+        del q, k, v, o, lse
+    return out
+
+
 def denoise50(L, dev, thresholds=(("21%", -5.157), ("42%", -4.220), ("57%", -3.399), ("77%", -2.462))):
     """Per threshold: 50 calls of LiteAttention.__call__ on the slowly varying workload; kernel time per step by HIP events.
     Reports the sparsity of the list the LAST step read, its time against the dense kernel on the same tensors, the 50-step total,
@@ -165,6 +194,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp8", action="store_true", help="skip the fp8 (configs[4]) sub-record of the 1-GPU bf16 line")
     ap.add_argument("--no-verify", action="store_true", help="skip the sampled-row check after the timed loop")
+    ap.add_argument("--no-head-dims", action="store_true", help="skip the head_dim 64 / 96 / 192 / 256 sub-record of the 1-GPU bf16 line")
     ap.add_argument("--no-denoise", action="store_true", help="skip the 50-step denoising run (BASELINE.json configs[2]) of the 1-GPU bf16 line")
     ap.add_argument("--overlap-windows", type=int, default=3,
                     help="N > 1: q-tile windows per step whose all-gathers overlap the next window's compute (1 = off)")
@@ -394,6 +424,13 @@ def main():
                              "roofline": f8["roofline"], "verified": f8.get("verified")}
         except Exception as e:  # noqa: BLE001
             result["fp8"] = {"value": None, "error": repr(e)}
+
+    # ---- the reference's other default head sizes beside the headline 128 (about a second)
+    if world == 1 and args.dtype == "bf16" and not args.no_head_dims:
+        try:
+            result["other_head_dims"] = other_head_dims(L, dev)
+        except Exception as e:  # noqa: BLE001
+            result["other_head_dims"] = {"error": repr(e)}
 
     # ---- BASELINE.json configs[2]: 50 synthetic denoising steps with REAL (fragmented, per-head) skip lists at fixed thresholds
     # (found by bisection in round 1 for 21 / 42 / 57 / 77 % last-step sparsity with 256-row q-tiles; tools/denoise_bench.py)
