@@ -1,6 +1,8 @@
 #!/usr/bin/env python
-"""Generates la_fwd_x64_body.inc: hand-scheduled gfx950 main loop of the bf16 / head_dim-128 QK-Skip forward with
-ONE wave per SIMD and 64 query rows per wave (q-tile 256 x k-tile 64, one 4-wave workgroup per CU).
+"""Generates la_fwd_x64[_d<D>][_f16]_body.inc: hand-scheduled gfx950 main loop of the bf16 / fp16 QK-Skip forward with
+ONE wave per SIMD (one 4-wave workgroup per CU). The text below describes the head_dim-128 form: 64 query rows per wave, q-tile
+256 x k-tile 64. LA_X64_D selects the other forms (96: the same with 12 of 16 fragments; 256 / 192: one 32-row q-block per wave,
+q-tile 128 - see the comments at D / DL / NQB below), LA_X64_DTYPE the 16-bit element type.
 
 Why this shape (measured): with two 32-row waves per SIMD the MFMA pipe idles 37 % of the
 cycles and the chip clocks at 1.69 GHz, because every wave re-reads the whole K/V tile from LDS for only 32 rows and
