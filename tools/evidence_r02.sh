@@ -46,6 +46,8 @@ for t in d64 d96 d192 d256; do
 done
 # the hipcc-scheduled A/B kernels on the same box (head dims 192 / 96 zero-padded onto 256 / 128 by the host)
 want other && LA_FWD_KERNEL=v2 python $R/tools/d256_bench.py > $OUT/v2_bench.txt 2>&1
+# 6. socket power and clocks under the kernels (rocm-smi)
+want power && (cd $R && bash tools/power_probe.sh $OUT/power_probe.txt > /dev/null 2>&1)
 ls $OUT | head -80
 grep -h PROBE $OUT/traffic_*_fetch.log 2>/dev/null
 [ -f $OUT/bench_line.json ] && tail -c 300 $OUT/bench_line.json

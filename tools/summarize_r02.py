@@ -189,4 +189,6 @@ for t in ("d64", "d96", "d192", "d256"):
     md += ["", f"PMC (all forward dispatches of the tool averaged): {json.dumps({k: round(v, 4) if isinstance(v, float) else v for k, v in d.items()})}",
            f"kernel resources: {meta}", ""]
 open(os.path.join(PROF, f"{tag}_other_head_dims.md"), "w").write("\n".join(md) + "\n")
+if os.path.exists(os.path.join(src, "power_probe.txt")):
+    shutil.copy(os.path.join(src, "power_probe.txt"), os.path.join(PROF, f"{tag}_power_probe.txt"))
 print(open(os.path.join(PROF, f"{tag}_rocprof_summary.md")).read()[:3000])
