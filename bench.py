@@ -116,6 +116,39 @@ def cpu_baseline(S, D, bm, bn, rows, target_seconds=15.0):
     return res
 
 
+def power_sample(launch, n_launches, device_index=0):
+    """Socket power and shader clock (rocm-smi) read WHILE `n_launches` queued calls of `launch` keep the GPU busy; outside any timed
+    region. The kernels of this path hold the package at its power cap with the clock throttled: this puts
+    the two numbers that say so next to the roofline fraction. Returns None if rocm-smi is not there."""
+    import json as _json
+    import shutil
+    import subprocess
+    import torch
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    for _ in range(n_launches):
+        launch()
+    time.sleep(0.35)                         # let the power reading settle on the loop
+    samples = []
+    for _ in range(2):
+        try:
+            raw = subprocess.run([smi, "-d", str(device_index), "--showpower", "--showclocks", "--showmaxpower", "--json"],
+                                 capture_output=True, text=True, timeout=10).stdout
+            card = next(iter(_json.loads(raw[raw.index("{"):]).values()))
+            samples.append({"socket_w": float(card["Current Socket Graphics Package Power (W)"]),
+                            "sclk_mhz": float(card["sclk clock speed:"].strip("()").lower().replace("mhz", "")),
+                            "cap_w": float(card["Max Graphics Package Power (W)"])})
+        except Exception:  # noqa: BLE001
+            pass
+    torch.cuda.synchronize()
+    if not samples:
+        return None
+    return {"socket_w": round(sum(x["socket_w"] for x in samples) / len(samples), 1),
+            "sclk_mhz": round(sum(x["sclk_mhz"] for x in samples) / len(samples), 1), "cap_w": samples[0]["cap_w"],
+            "how": f"rocm-smi, 2 samples while {n_launches} queued launches of the timed configuration run (outside the timed region)"}
+
+
 def other_head_dims(L, dev, dims=(64, 96, 192, 256), S=16384, H=40, reps=5):
     """The reference's other default head sizes (hopper/setup.py:57-61), dense bf16 at S=16384 H=40: useful TFLOP/s by HIP events on
     the launch stream, and a sampled-row check of the timed output against fp32 torch. 64: the hipcc-scheduled 128-row template;
@@ -194,6 +227,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp8", action="store_true", help="skip the fp8 (configs[4]) sub-record of the 1-GPU bf16 line")
     ap.add_argument("--no-verify", action="store_true", help="skip the sampled-row check after the timed loop")
+    ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock sample")
     ap.add_argument("--no-head-dims", action="store_true", help="skip the head_dim 64 / 96 / 192 / 256 sub-record of the 1-GPU bf16 line")
     ap.add_argument("--no-denoise", action="store_true", help="skip the 50-step denoising run (BASELINE.json configs[2]) of the 1-GPU bf16 line")
     ap.add_argument("--overlap-windows", type=int, default=3,
@@ -370,6 +404,17 @@ def main():
                 ver["ok"] = bool(ver.get("ok") and ver["ok_all_ranks"])
             res["verified"] = ver
 
+        # ---- package power / clock under the timed configuration (1 GPU only; about a second)
+        if use_dist is None and not args.no_power:
+            try:
+                set_sparsity(HEADLINE_SPARSITY)
+                n_q = max(8, int(1.2 / max(step_s, 1e-4)))
+                pw = power_sample(lambda: att(q, k, v), n_q, dev.index or 0)
+                if pw is not None:
+                    res["power"] = pw
+            except Exception:  # noqa: BLE001
+                pass
+
         # ---- 1-GPU sparsity sweep (the reference's sparsity-vs-runtime curve, README.md:81-87)
         if sweep:
             sw = []
@@ -410,7 +455,7 @@ def main():
     }
     if main_res.get("overlap_note"):
         result["config"]["overlap_note"] = main_res["overlap_note"]
-    for key in ("verified", "multi_gpu", "sweep"):
+    for key in ("verified", "multi_gpu", "power", "sweep"):
         if key in main_res:
             result[key] = main_res[key]
 
@@ -421,7 +466,7 @@ def main():
             f8.pop("_bm_bn_tiles")
             result["fp8"] = {"value": f8["value"], "unit": result["unit"], "ms_per_step": f8["ms_per_step"], "dtype": "fp8 (e4m3 in, fp32 accumulate, bf16 out)",
                              "steps": max(5, args.steps // 2), "sparsity": f8["sparsity"], "tiles": f8["tiles"],
-                             "roofline": f8["roofline"], "verified": f8.get("verified")}
+                             "roofline": f8["roofline"], "verified": f8.get("verified"), "power": f8.get("power")}
         except Exception as e:  # noqa: BLE001
             result["fp8"] = {"value": None, "error": repr(e)}
 

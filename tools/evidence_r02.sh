@@ -17,11 +17,11 @@ want() { [ "${EV_SECTIONS:-all}" = all ] || [[ " $EV_SECTIONS " == *" $1 "* ]]; 
 want bench && python $R/bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 want bench && python $R/bench.py --dtype fp16 --no-denoise --no-cpu-baseline > $OUT/bench_line_fp16.json 2>> $OUT/bench_line.err
 # 2. kernel trace + stats of the same command (shorter loop)
-want kt && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $R/bench.py --no-sweep --no-cpu-baseline --no-denoise --no-head-dims --steps 5 --warmup 2 > $OUT/kt.log 2>&1
+want kt && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $R/bench.py --no-sweep --no-cpu-baseline --no-denoise --no-head-dims --no-power --steps 5 --warmup 2 > $OUT/kt.log 2>&1
 # 3. PMC passes, bf16 headline and fp8
 for dt in bf16 fp8; do
   want pmc || continue
-  B="python $R/bench.py --no-sweep --no-cpu-baseline --no-fp8 --no-verify --no-denoise --no-head-dims --steps 3 --warmup 1 --dtype $dt"
+  B="python $R/bench.py --no-sweep --no-cpu-baseline --no-fp8 --no-verify --no-denoise --no-head-dims --no-power --steps 3 --warmup 1 --dtype $dt"
   pmc ${dt}_mfma SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_INSTS_SALU -- $B
   pmc ${dt}_wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS -- $B
   pmc ${dt}_fetch FETCH_SIZE -- $B

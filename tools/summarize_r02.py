@@ -116,8 +116,8 @@ for dt in ("bf16", "fp8"):
     line = kt_line if dt == "bf16" else (kt_line or {}).get("fp8")
     name = f"{tag}_rocprof_summary" if dt == "bf16" else f"{tag}_fp8_rocprof_summary"
     md = [f"# rocprofv3 summary `{tag}` ({dt}), kernel sources {sha}", "",
-          "Commands (tools/evidence_r02.sh): `rocprofv3 --kernel-trace --stats -- python bench.py --no-sweep --no-cpu-baseline --no-denoise --no-head-dims --steps 5 --warmup 2` "
-          f"for the kernel statistics; PMC in separate `rocprofv3 --pmc ... -- python bench.py --no-sweep --no-cpu-baseline --no-fp8 --no-verify --no-denoise --no-head-dims --steps 3 --warmup 1 --dtype {dt}` passes.", ""]
+          "Commands (tools/evidence_r02.sh): `rocprofv3 --kernel-trace --stats -- python bench.py --no-sweep --no-cpu-baseline --no-denoise --no-head-dims --no-power --steps 5 --warmup 2` "
+          f"for the kernel statistics; PMC in separate `rocprofv3 --pmc ... -- python bench.py --no-sweep --no-cpu-baseline --no-fp8 --no-verify --no-denoise --no-head-dims --no-power --steps 3 --warmup 1 --dtype {dt}` passes.", ""]
     if line:
         md += [f"bench record under the profiler: value={line.get('value')} TFLOP/s, ms_per_step={line.get('ms_per_step')}, "
                f"kernel_ms(HIP events)={line['roofline']['kernel_ms']}, roofline.frac={line['roofline']['frac']}; "
