@@ -377,7 +377,21 @@ def _register_op():
     def _fwd_impl(*args, **kwargs):
         return mha_fwd(*args, **kwargs)
 
+    def _fwd_meta(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=None, *args, **kwargs):
+        """Shapes and dtypes only (fake-tensor tracing / torch.compile treat the op as opaque): out has the input type, bf16 for
+        e4m3 inputs (flash_api.cpp:859); softmax_lse is fp32 (B, H, Sq), or (H, total_q) for packed batches (:887-892)."""
+        o_dtype = torch.bfloat16 if q.dtype == torch.float8_e4m3fn else q.dtype
+        if out is None:
+            out = torch.empty((*q.shape[:-1], v.shape[-1]), dtype=o_dtype, device=q.device)
+        if cu_seqlens_q is not None:
+            lse = torch.empty((q.shape[1], q.shape[0]), dtype=torch.float32, device=q.device)
+        else:
+            lse = torch.empty((q.shape[0], q.shape[2], q.shape[1]), dtype=torch.float32, device=q.device)
+        empty = torch.empty(0, dtype=torch.float32, device=q.device)
+        return out, lse, empty, torch.empty(0, dtype=torch.float32, device=q.device)
+
     lib.impl("fwd", _fwd_impl, "CUDA")
+    lib.impl("fwd", _fwd_meta, "Meta")
     _op_lib = lib
 
 

@@ -111,3 +111,23 @@ def test_build_rejects_scratch_in_the_x64_kernels():
     bad = ok.replace("ScratchSize [bytes/lane]: 0", "ScratchSize [bytes/lane]: 48")
     with pytest.raises(RuntimeError, match="must not spill"):
         b._check_no_scratch(bad, ())
+
+
+def test_op_has_a_meta_kernel_for_fake_tensor_tracing():
+    """torch.ops.lite_attention.fwd on meta tensors: shapes / dtypes of the reference op (flash_api.cpp:859, 887-892) without a launch,
+    so that torch.compile / export can trace a pipeline through the opaque op."""
+    import torch
+    import liteattention_amd  # noqa: F401  (registers the op)
+    q = torch.empty(2, 100, 6, 128, dtype=torch.bfloat16, device="meta")
+    k = torch.empty(2, 130, 2, 128, dtype=torch.bfloat16, device="meta")
+    out, lse, a, b = torch.ops.lite_attention.fwd(q, k, k)
+    assert out.shape == q.shape and out.dtype == torch.bfloat16 and out.device.type == "meta"
+    assert lse.shape == (2, 6, 100) and lse.dtype == torch.float32 and a.numel() == 0 and b.numel() == 0
+    q8 = torch.empty(1, 64, 2, 128, dtype=torch.float8_e4m3fn, device="meta")
+    assert torch.ops.lite_attention.fwd(q8, q8, q8)[0].dtype == torch.bfloat16
+    qh = torch.empty(1, 64, 2, 96, dtype=torch.float16, device="meta")
+    assert torch.ops.lite_attention.fwd(qh, qh, qh)[0].dtype == torch.float16
+    qp = torch.empty(300, 4, 128, dtype=torch.bfloat16, device="meta")
+    cu = torch.empty(4, dtype=torch.int32, device="meta")
+    o, l, _, _ = torch.ops.lite_attention.fwd(qp, qp, qp, None, None, None, None, cu, cu, None, None, None, 120, 120)
+    assert o.shape == (300, 4, 128) and l.shape == (4, 300)

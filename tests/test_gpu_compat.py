@@ -86,3 +86,18 @@ def test_threshold_calibration_hits_target_sparsity():
     assert thr < 0
     assert abs(trace[-2] - 0.25) <= 0.06, trace
     assert trace == sorted(trace)                             # skip fraction is monotone over steps
+
+
+def test_dynamo_traces_through_the_op_with_its_meta_kernel():
+    """torch.compile(fullgraph=True) over a function that calls flash_attn_func: the registered Meta kernel gives dynamo the output
+    shapes, the op stays opaque. (AOT-autograd backends reject the op for the output alias annotation `Tensor(out!)` in its schema -
+    the reference's own schema, flash_api.cpp:1723-1762, kept verbatim.)"""
+    import liteattention_amd as L
+    q, k, v = [torch.randn(1, 300, 2, 128, device="cuda").bfloat16() for _ in range(3)]
+
+    def fn(q, k, v):
+        return L.flash_attn_func(q * 1.0, k, v).float() * 2.0
+
+    ref = fn(q, k, v)
+    out = torch.compile(fn, backend="eager", fullgraph=True)(q, k, v)
+    assert torch.equal(out, ref)
