@@ -117,7 +117,7 @@ def test_stock_import_names_resolve_to_the_gfx950_kernel(shims):
         assert (lse_b[:, sl].cpu() - torch.logsumexp(s, -1)).abs().max().item() <= 1e-3
 
 
-@pytest.mark.parametrize("D,H,Hk", [(128, 4, 4), (64, 4, 2), (96, 2, 2), (256, 2, 1)])
+@pytest.mark.parametrize("D,H,Hk", [(128, 4, 4), (64, 4, 2), (96, 2, 2), (192, 4, 2), (256, 2, 1), (80, 2, 2)])
 def test_varlen_is_one_launch_for_every_bf16_instantiation(D, H, Hk):
     """Packed batches on every bf16 kernel (head_dim 64 / 128 / 256, 96 zero-padded onto 128), MHA and GQA/MQA, ragged lengths
     around the tile sizes; nothing but the listed rows is written (NaN-prefilled out stays NaN past total_q... there is no
@@ -138,7 +138,9 @@ def test_varlen_is_one_launch_for_every_bf16_instantiation(D, H, Hk):
         sl_q, sl_k = slice(cq[b], cq[b + 1]), slice(ck[b], ck[b + 1])
         o_r, lse_r, _ = orc.qkskip_fwd(q[sl_q][None], k[sl_k][None], v[sl_k][None], block_m=bm, block_n=bn,
                                        softmax_scale=D ** -0.5)
-        assert (o[sl_q].float().cpu() - o_r[0]).abs().max().item() <= _tol(o_r), (D, b)
+        # 0.75 ulp of the largest output (tests/test_gpu_head_dims.py::test_dense_matches_oracle has the accounting: half an ulp for
+        # the bf16 store + P rounded relative to the lazily updated reference max, not averaged away over a 65-key sequence)
+        assert (o[sl_q].float().cpu() - o_r[0]).abs().max().item() <= 1.5 * 2.0 ** -8 * o_r.abs().max().item() + 1e-3, (D, b)
         assert (lse[:, sl_q].cpu() - lse_r[0]).abs().max().item() <= 1e-3, (D, b)
     # the L.flash_attn_varlen_func wrapper: same launch, host lists accepted, max_seqlen derived from them
     o2 = L.flash_attn_varlen_func(q.cuda(), k.cuda(), v.cuda(), cq, ck)
