@@ -63,6 +63,11 @@ typedef enum la_status {
                                   * (same tiles). head_dim 96 / 192 have no such instantiation: LA_ERR_HEAD_DIM. fp8: LA_ERR_UNSUPPORTED. */
 #define LA_FLAG_EXACT_RESCALE 8u /* A/B: the hand-scheduled kernels rescale O on EVERY growth of a row maximum (tau = 0) instead of lazily
                                   * (bf16: only after it grew by more than 2^8; results agree to rounding, lists are identical) */
+#define LA_FLAG_EXACT_ROWSUM 16u /* fp8: row sums l = sum of the UN-rounded fp32 P on the vector unit (the reference's form, softmax.h:275-296:
+                                  * LSE exact to fp32) instead of the default l~ = sum of the e4m3-rounded P taken from the matrix pipe
+                                  * (4-5 % faster; O = (sum P~ V) / (sum P~) is self-consistent, the LSE then carries the rounding of
+                                  * P~: |LSE - exact| <= ln(1 + 2^-4), about 1e-2 on rows of a few keys, 1e-4 on long rows).
+                                  * Ignored for bf16 / fp16 (always exact). */
 #define LA_FLAG_STATIC_SCHED 2u  /* keep one workgroup per item (static XCD map) even when a workspace is given. For
                                   * launches that must share the GPU with another kernel while they run — e.g. an RCCL
                                   * collective on another stream: persistent workgroups would hold every CU until the

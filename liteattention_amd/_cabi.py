@@ -61,12 +61,14 @@ LA_FLAG_V_PREPARED = 1
 LA_FLAG_STATIC_SCHED = 2
 LA_FLAG_KERNEL_128ROW = 4
 LA_FLAG_EXACT_RESCALE = 8
+LA_FLAG_EXACT_ROWSUM = 16
 
 
 def default_flags() -> int:
     """A/B switches of the HOST layer (the C library reads no environment): they only choose the default ``la_fwd_args.flags``.
     LA_FWD_KERNEL=v2 -> the 128-row bf16 head_dim-128 kernel (lists then use 128-row q-tiles); LA_SCHED=static -> one
-    workgroup per item instead of the ticket queues; LA_RESCALE_TAU=0 -> O rescaled on every growth of a row maximum."""
+    workgroup per item instead of the ticket queues; LA_RESCALE_TAU=0 -> O rescaled on every growth of a row maximum; LA_FP8_ROWSUM=exact -> fp8 row sums of the un-rounded
+    P on the vector unit (LA_FLAG_EXACT_ROWSUM: fp32-exact LSE, 4-5 % slower)."""
     f = 0
     if os.environ.get("LA_FWD_KERNEL", "").startswith("v2"):
         f |= LA_FLAG_KERNEL_128ROW
@@ -76,6 +78,8 @@ def default_flags() -> int:
         if float(os.environ["LA_RESCALE_TAU"]) != 0.0:
             raise ValueError("LA_RESCALE_TAU: only 0 (exact rescale, LA_FLAG_EXACT_RESCALE) or the default 8 are available")
         f |= LA_FLAG_EXACT_RESCALE
+    if os.environ.get("LA_FP8_ROWSUM", "").startswith("exact"):
+        f |= LA_FLAG_EXACT_ROWSUM
     return f
 
 
@@ -143,6 +147,9 @@ def is_instantiated(head_dim: int, element_size: int, flags: int = None) -> bool
     return load().la_get_tile_sizes_ex(int(head_dim), int(element_size), f, ctypes.byref(m), ctypes.byref(n)) == LA_OK
 
 
+_TILE_SIZES = {}      # (head_dim, element_size, kernel-selection flag) -> (block_m, block_n): constant for a loaded library
+
+
 def get_tile_sizes(head_dim: int, element_size: int, flags: int = None) -> Tuple[int, int]:
     """(kBlockM, kBlockN) of the kernel la_fwd runs for this head_dim / element size (and kernel-selection flags; default:
     ``default_flags()``, what ``mha_fwd`` passes). fp8 has no 128-row kernel: the flag is dropped for 1-byte elements."""
@@ -150,7 +157,12 @@ def get_tile_sizes(head_dim: int, element_size: int, flags: int = None) -> Tuple
     f = (default_flags() if flags is None else flags) & LA_FLAG_KERNEL_128ROW
     if element_size == 1:
         f = 0
+    key = (int(head_dim), int(element_size), f)
+    hit = _TILE_SIZES.get(key)
+    if hit is not None:
+        return hit
     rc = load().la_get_tile_sizes_ex(int(head_dim), int(element_size), f, ctypes.byref(m), ctypes.byref(n))
     if rc != LA_OK:
         raise RuntimeError(f"la_get_tile_sizes(head_dim={head_dim}, element_size={element_size}): {status_string(rc)}")
+    _TILE_SIZES[key] = (m.value, n.value)
     return m.value, n.value

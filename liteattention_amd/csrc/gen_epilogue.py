@@ -37,12 +37,17 @@ def store_epilogue(g, o_reg):
     emit(f"v_lshlrev_b32 {v(HH16)}, 2, {v(HH4)}")
     for qb in range(n_qb):
         # l = sum over the two half-waves; inv = oscale / l (0 for l == 0 or NaN); lse = m_ref c ln2 + ln l + lse_add
-        emit(f"v_add_f32 {v(T[0])}, {v(L0[qb])}, {v(L1[qb])}")
-        emit(f"v_mov_b32 {v(T[1])}, {v(T[0])}")
-        emit("s_nop 1")
-        emit(f"v_permlane32_swap_b32 {v(T[0])}, {v(T[1])}")
-        emit("s_nop 1")
-        emit(f"v_add_f32 {v(T[0])}, {v(T[0])}, {v(T[1])}")
+        if g.get("LSUM_AGPR"):
+            # row sums accumulated by the matrix pipe (fp8: ones x P~^T): every lane already holds the complete sum of its row
+            emit(f"v_accvgpr_read_b32 {v(T[0])}, a{g['LSUM_AGPR'][qb]}")
+            emit("s_nop 1")
+        else:
+            emit(f"v_add_f32 {v(T[0])}, {v(L0[qb])}, {v(L1[qb])}")
+            emit(f"v_mov_b32 {v(T[1])}, {v(T[0])}")
+            emit("s_nop 1")
+            emit(f"v_permlane32_swap_b32 {v(T[0])}, {v(T[1])}")
+            emit("s_nop 1")
+            emit(f"v_add_f32 {v(T[0])}, {v(T[0])}, {v(T[1])}")
         emit(f"v_rcp_f32 {v(T[2])}, {v(T[0])}")
         emit(f"v_log_f32 {v(T[3])}, {v(T[0])}")
         emit("s_nop 0")

@@ -55,10 +55,16 @@ CVT_OP = {"bf16": "v_cvt_pk_bf16_f32", "f16": "v_cvt_pk_f16_f32"}[DTYPE]        
 # Head dims 96 and 192 (LA_X64_D=96 / 192) are the 128 / 256 forms with three quarters of the MFMAs: 12 / 24 K fragments and V^T
 # fragments per tile instead of 16 / 32, the LDS image keeps the 256 / 512-byte row pitch (both XOR swizzles are defined on it; the
 # quarter of each LDS row behind the data is filled with duplicates by the DMA lanes that have no column of their own).
+# Head dim 64 (LA_X64_D=64, round 3) is the 128 form with half the MFMAs (8 K fragments, 8 V^T fragments per tile: 16 + 16 MFMAs per
+# step) under the SAME softmax: bound by the vector unit like the fp8 kernel. It has its own LDS image: rows of 128 bytes (tiles of
+# 8 KiB, 2 DMA pieces per wave and tensor), K chunks swizzled by (row >> 1) & 7 and V 64-byte segments by (row >> 1) & 1 - the
+# conflict-free forms for a 128-byte pitch (16 consecutive rows of one chunk column / 4 rows x 64 bytes of a transpose read cover
+# all 64 banks once).
 D = int(os.environ.get("LA_X64_D", "128"))
-assert D in (96, 128, 192, 256)
-DL = 128 if D <= 128 else 256             # layout head dim: LDS row pitch, q-blocks per wave, DMA pieces
-NQB = 2 if DL == 128 else 1               # 32-row q-blocks per wave
+assert D in (64, 96, 128, 192, 256)
+DL = 64 if D == 64 else (128 if D <= 128 else 256)   # layout head dim: LDS row pitch, q-blocks per wave, DMA pieces
+NQB = 2 if DL <= 128 else 1               # 32-row q-blocks per wave
+ROW_SHIFT = {64: 7, 128: 8, 256: 9}[DL]   # log2 of the LDS row pitch in bytes
 KS = D // 16                              # k-steps of S^T = K Q^T
 DB = D // 32                              # 32-wide d-blocks of O^T
 ROW = 2 * DL                              # bytes per K / V row in LDS
@@ -74,10 +80,10 @@ PW = 16 * ROW // 1024                     # 1-KiB DMA pieces per wave per tile (
 # (+1.4 %), head_dim 192 1111 -> 1107 (24 + 24 KiB there: nothing to balance) - small, because these forms sit at the power limit
 # too (1.8-1.9 GHz). Default: 256 only; `kearly` / `klate2` force it on / off for A/B.
 K_EARLY = NQB == 1 and (D == 256 or "kearly" in OPT) and "klate2" not in OPT
-XPAIRS = int(opt_val("x", "5"))          # pair-groups (of 16; one group = the same pair of both q-blocks) done in phase 2
+XPAIRS = int(opt_val("x", "8" if D == 64 else "5"))   # pair-groups (of 16; one group = the same pair of both q-blocks) done in phase 2
 CAP1 = int(opt_val("cap1", "0"))          # fillers per MFMA gap the distributor may place (0 = balance evenly)
 CAP2 = int(opt_val("cap2", "0"))
-DMA_GAPS = [int(x) for x in opt_val("dmagaps", {128: "1,2,4,6,8,10,11,13,15,17", 96: "0,1,3,4,6,7,8,9,11,12"}[D] if DL == 128 else
+DMA_GAPS = [int(x) for x in opt_val("dmagaps", {128: "1,2,4,6,8,10,11,13,15,17", 96: "0,1,3,4,6,7,8,9,11,12", 64: "1,2,4,8,9,11"}[D] if DL <= 128 else
                                     "1,2,3,4,5,7,8,9,10,11,13,14,15,16,17,19,20,21,22,23").replace(".", ",").split(",")]   # m0K,K0..3,m0V,V0..3 (phase 1)
 assert max(DMA_GAPS) < NG
 
@@ -440,14 +446,15 @@ def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True, st=0):
     o = []
     # head_dim 256: 8 pieces per tensor in two groups of 4 (the instruction offset is a 13-bit signed field: 0..3072 only), M0 moved
     # by 4 KiB for the second group; the lane offsets of piece j carry +(3072 - 1024 (j & 3))
-    for grp in range(PW // 4):
+    per = min(4, PW)                       # pieces per M0 group (head_dim 64: 2 pieces per tensor in all)
+    for grp in range(PW // per):
         if do_k:
             o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {kbuf_imm + 4096 * grp}")
-            o += [f"    global_load_lds_dwordx4 {v(LK[4 * grp + j])}, {sr(TBS[st])} offset:{1024 * j}{DMA_POLICY}" for j in range(4)]
-    for grp in range(PW // 4):
+            o += [f"    global_load_lds_dwordx4 {v(LK[4 * grp + j])}, {sr(TBS[st])} offset:{1024 * j}{DMA_POLICY}" for j in range(per)]
+    for grp in range(PW // per):
         if do_v:
             o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {V_REGION + vbuf_imm + 4096 * grp}")
-            o += [f"    global_load_lds_dwordx4 {v(LV[4 * grp + j])}, {sr(VBS[st])} offset:{1024 * j}{DMA_POLICY}" for j in range(4)]
+            o += [f"    global_load_lds_dwordx4 {v(LV[4 * grp + j])}, {sr(VBS[st])} offset:{1024 * j}{DMA_POLICY}" for j in range(per)]
     return o
 
 
@@ -599,7 +606,7 @@ def prologue():
     emit(f"s_mov_b32 {s(S_CC)}, {s(S_C)}")
     emit(f"s_mov_b32 {s(S_CC + 1)}, {s(S_C)}")
     emit(f"s_sub_u32 {s(S_NM1)}, {s(S_NTILES)}, 1")
-    emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, {12 if DL == 128 else 13}")      # a wave stages 16 rows = 4 / 8 KiB of a tile
+    emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, {ROW_SHIFT + 4}")      # a wave stages 16 rows = 2 / 4 / 8 KiB of a tile
     emit(f"s_add_u32 {s(S_DMAW)}, {s(S_DMAW)}, {s(S_LDS)}")
     emit(f"s_mov_b32 {s(S_I)}, 0")
     emit(f"s_mov_b32 {s(S_RESC)}, 0")
@@ -610,15 +617,18 @@ def prologue():
     emit(f"v_lshlrev_b32 {v(HH4)}, 2, {v(T[0])}")
     emit(f"v_and_b32 {v(T[1])}, 31, {v(LANE)}")               # l31
     emit(f"v_and_b32 {v(T[2])}, 15, {v(LANE)}")               # a16 / cpos
-    emit(f"v_lshlrev_b32 {v(T[3])}, {8 if DL == 128 else 9}, {v(T[1])}")            # l31 * ROW
+    emit(f"v_lshlrev_b32 {v(T[3])}, {ROW_SHIFT}, {v(T[1])}")            # l31 * ROW
     emit(f"v_add_u32 {v(T[3])}, {s(S_LDS)}, {v(T[3])}")
-    for ks in range(8):
+    if DL == 64:                                               # 128-byte rows: the K chunk swizzle is (row >> 1) & 7
+        emit(f"v_lshrrev_b32 {v(T[8])}, 1, {v(T[1])}")
+        emit(f"v_and_b32 {v(T[8])}, 7, {v(T[8])}")
+    for ks in range(4 if DL == 64 else 8):
         emit(f"v_add_u32 {v(T[4])}, {2 * ks}, {v(T[0])}")
-        emit(f"v_xor_b32 {v(T[4])}, {v(T[4])}, {v(T[2])}")
+        emit(f"v_xor_b32 {v(T[4])}, {v(T[4])}, {v(T[8] if DL == 64 else T[2])}")
         emit(f"v_lshl_add_u32 {v(KADDR[ks])}, {v(T[4])}, 4, {v(T[3])}")
     emit(f"v_lshrrev_b32 {v(T[4])}, 2, {v(T[2])}")            # kq = a16 >> 2
     emit(f"v_add_u32 {v(T[5])}, {v(HH4)}, {v(T[4])}")         # key0
-    emit(f"v_lshlrev_b32 {v(T[5])}, {8 if DL == 128 else 9}, {v(T[5])}")
+    emit(f"v_lshlrev_b32 {v(T[5])}, {ROW_SHIFT}, {v(T[5])}")
     emit(f"v_add_u32 {v(T[5])}, {s(S_LDS)}, {v(T[5])}")
     emit(f"v_add_u32 {v(T[5])}, {V_REGION}, {v(T[5])}")
     emit(f"v_lshrrev_b32 {v(T[6])}, 4, {v(LANE)}")            # g = lane >> 4 = rip
@@ -627,11 +637,26 @@ def prologue():
     emit(f"v_and_b32 {v(T[8])}, 3, {v(T[2])}")                # a3
     emit(f"v_lshl_or_b32 {v(T[7])}, {v(T[8])}, 3, {v(T[7])}")
     emit(f"v_add_u32 {v(T[5])}, {v(T[5])}, {v(T[7])}")
-    for db in range(4):
+    if DL == 64:                                               # 128-byte rows: two 64-byte segments, swizzled by (row >> 1) & 1 = kq >> 1
+        emit(f"v_lshrrev_b32 {v(T[4])}, 1, {v(T[4])}")
+    for db in range(2 if DL == 64 else 4):
         emit(f"v_xor_b32 {v(T[7])}, {db}, {v(T[4])}")
         emit(f"v_lshl_add_u32 {v(VADDR[db])}, {v(T[7])}, 6, {v(T[5])}")
     emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 4")
-    if DL == 128:
+    if DL == 64:
+        # DMA image: a 1-KiB piece = 8 rows of 128 bytes; lane -> (rip = lane >> 3, cpos = lane & 7). Row = 16 w + 8 j + rip: the K
+        # swizzle XORs the chunk with (row >> 1) & 7 = (4 j + (rip >> 1)) & 7, the V swizzle with ((row >> 1) & 1) << 2 = ((rip >> 1) & 1) << 2
+        emit(f"v_lshrrev_b32 {v(T[6])}, 3, {v(LANE)}")            # rip
+        emit(f"v_and_b32 {v(T[7])}, 7, {v(LANE)}")                # cpos
+        emit(f"v_add_u32 {v(RIPROW)}, {s(S_T0)}, {v(T[6])}")      # 16*wave + rip
+        emit(f"v_lshrrev_b32 {v(T[8])}, 1, {v(T[6])}")            # rip >> 1
+        emit(f"v_xor_b32 {v(RAGK)}, {v(T[7])}, {v(T[8])}")
+        emit(f"v_lshlrev_b32 {v(RAGK)}, 4, {v(RAGK)}")            # (cpos ^ (rip >> 1)) << 4
+        emit(f"v_and_b32 {v(T[8])}, 1, {v(T[8])}")
+        emit(f"v_lshlrev_b32 {v(T[8])}, 2, {v(T[8])}")
+        emit(f"v_xor_b32 {v(RAGV)}, {v(T[7])}, {v(T[8])}")
+        emit(f"v_lshlrev_b32 {v(RAGV)}, 4, {v(RAGV)}")            # (cpos ^ (((rip >> 1) & 1) << 2)) << 4
+    elif DL == 128:
         # DMA image: a 1-KiB piece = 4 rows of 256 bytes; lane -> (row in piece rip = lane >> 4, chunk cpos = lane & 15)
         emit(f"v_add_u32 {v(RIPROW)}, {s(S_T0)}, {v(T[6])}")      # 16*wave + rip
         emit(f"v_xor_b32 {v(RAGK)}, {v(T[2])}, {v(T[6])}")
@@ -663,11 +688,11 @@ def prologue():
                 emit(f"v_subrev_u32 {v(T[7])}, {2 * DL - 2 * D}, {v(reg)}")
                 emit(f"v_cmp_le_u32 vcc, {2 * D}, {v(reg)}")
                 emit(f"v_cndmask_b32 {v(reg)}, {v(reg)}, {v(T[7])}, vcc")
-        emit(f"v_xor_b32 {v(T[5])}, {(RSTEP * j) << 4}, {v(RAGK)}")
+        emit(f"v_xor_b32 {v(T[5])}, {((RSTEP * j) >> (1 if DL == 64 else 0)) << 4}, {v(RAGK)}")
         in_row(T[5])
         emit(f"v_add_u32 {v(LK[j])}, {v(LK[j])}, {v(T[5])}")
         emit(f"v_mul_lo_u32 {v(LV[j])}, {v(T[4])}, {s(S_VRS)}")
-        if D == 128:
+        if D == 128 or D == 64:
             emit(f"v_add_u32 {v(LV[j])}, {v(LV[j])}, {v(RAGV)}")
         else:
             emit(f"v_xor_b32 {v(T[5])}, {((RSTEP * j) & 3) << 6}, {v(RAGV)}")

@@ -45,7 +45,17 @@ XPAIRS = int(opt_val("x", "4"))          # pair-groups (of 16) done in phase 2. 
                                           # (measured x = 2 / 4: 2078-2101 TFLOP/s at 42 %, x = 3 / 5 / 6: 2048-2065)
 PK = "pk" in OPT                          # A/B: packed fp32 FMA / add in the softmax (v_pk_fma_f32, v_pk_add_f32). MEASURED ANTI-LEVER here too:
                                           # 64 fewer instructions per step, bit-identical results, 1891 vs 2068 TFLOP/s at 42 % (round 2, tools/ab.py --fp8)
-NG = 8                                    # MFMAs (gaps) per phase
+NG = 8                                    # QK MFMAs (gaps) of phase 1
+# Row sums. "lvalu" (round 2): l = sum of the UN-rounded fp32 P, 64 v_add_f32 per step (the reference's form, softmax.h:275-296).
+# Default (round 3): l~ = sum of the e4m3-ROUNDED P, taken from the matrix pipe: one more 32 x 32 x 64 MFMA per q-block and step
+# with an all-ones A operand (every row of the result is the column sum of P^T), accumulated in a[192:223] and rescaled with O.
+# Why: this kernel is bound by VALU issue (383 issue slots per step against 256 quad-cycles of MFMA; a lone wave issues a slot
+# every ~4.8 cycles: tools/valu_microbench.py), the packed / dot2 forms that would halve the adds are VOP3P and serialise with
+# the MFMA in flight (same tool), and the matrix pipe idles 55 % of the step. O = (sum P~ V) / (sum P~) is also the better
+# numerics under the lazy rescale: the weights sum to 1 exactly, so the e4m3 rounding of a row's dominant P (which is not 2^k
+# once m_ref lags m_true) cancels instead of scaling the whole row by up to 2^-4. The LSE inherits the rounding of P~.
+LMFMA = "lvalu" not in OPT
+NG2 = 10 if LMFMA else 8                  # MFMAs (gaps) of phase 2: PV + the two row-sum MFMAs
 TAU = 2.0                                 # lazy-rescale slack in log2 units (must match the shell: param[22] = TAU / c)
 P_OFFSET = 8.0 - TAU
 DMA_GAPS = [int(x) for x in opt_val("dmagaps", "0,1,1,2,3,3").replace(".", ",").split(",")]   # m0K,K0,K1,m0V,V0,V1 (phase 1 gaps; an M0 write is never adjacent to its first use)
@@ -64,6 +74,10 @@ def KA(j):          # j = 2*kb + sx
     return 160 + 8 * j
 
 
+def LSUM(qb):       # row sums of P~ (LMFMA): 16 accumulator registers per q-block, all rows equal
+    return 192 + 16 * qb
+
+
 # ---------------------------------------------------------------- VGPR map
 def S_(sset, qb, kb):
     return 64 * sset + 32 * qb + 16 * kb
@@ -75,6 +89,7 @@ VADDR = [164, 165]                        # [t]
 LK = [166, 167]
 LV = 168
 VSC = 169                                 # 0x7f7f7f7f: four E8M0 exponents of 127 (= 2^0)
+ONES = 170                                # v[170:177] = 0x38383838: the all-ones e4m3 A operand of the row-sum MFMA
 MTRUE, MREF, NMS, L0, L1, MLOC, MLOC2, ALPHA = ([180, 181], [182, 183], [184, 185], [186, 188], [187, 189], [190, 191],
                                                 [192, 193], [194, 195])
 T = list(range(196, 212))
@@ -175,6 +190,8 @@ def mfma_qk(sset, kb, sx, qb):
 
 
 def mfma_pv(sset, db, qb):
+    if db == 4:      # row sums: ones (32 x 64) times P^T
+        return f"    {MFMA} {ar(LSUM(qb), 16)}, {vr(ONES, 8)}, {vr(S_(sset, qb, 0), 8)}, {ar(LSUM(qb), 16)}, {SCALES}"
     return f"    {MFMA} {ar(O_(qb, db), 16)}, {vr(VF[db], 8)}, {vr(S_(sset, qb, 0), 8)}, {ar(O_(qb, db), 16)}, {SCALES}"
 
 
@@ -198,7 +215,7 @@ def softmax_parts(sset, p):
             A.append([f"    v_pk_add_f32 {vr(L0[qb], 2)}, {vr(L0[qb], 2)}, {vr(r0, 2)}"])
         else:
             F.append([f"    v_fma_f32 {v(ta)}, {v(r0)}, {s(S_C)}, {v(NMS[qb])}", f"    v_fma_f32 {v(tb)}, {v(r1)}, {s(S_C)}, {v(NMS[qb])}"])
-            A.append([f"    v_add_f32 {v(L0[qb])}, {v(L0[qb])}, {v(r0)}", f"    v_add_f32 {v(L1[qb])}, {v(L1[qb])}, {v(r1)}"])
+            A.append([] if LMFMA else [f"    v_add_f32 {v(L0[qb])}, {v(L0[qb])}, {v(r0)}", f"    v_add_f32 {v(L1[qb])}, {v(L1[qb])}, {v(r1)}"])
         E.append([f"    v_exp_f32 {v(r0)}, {v(ta)}", f"    v_exp_f32 {v(r1)}, {v(tb)}"])
         C.append([f"    v_cvt_pk_fp8_f32 {v(dst)}, {v(r0)}, {v(r1)}{hi}"])
     return F, E, A, C
@@ -309,8 +326,9 @@ def rare_rescale_block(rare_label, back_label):
         set_nms(qb)
         emit(f"v_add_f32 {v(MTHR[qb])}, {s(S_TAU)}, {v(MREF[qb])}")
     for qb in (0, 1):
-        emit(f"v_mul_f32 {v(L0[qb])}, {v(L0[qb])}, {v(ALPHA[qb])}")
-        emit(f"v_mul_f32 {v(L1[qb])}, {v(L1[qb])}, {v(ALPHA[qb])}")
+        if not LMFMA:                        # (LMFMA: the row sums live in accumulators and are rescaled with O)
+            emit(f"v_mul_f32 {v(L0[qb])}, {v(L0[qb])}, {v(ALPHA[qb])}")
+            emit(f"v_mul_f32 {v(L1[qb])}, {v(L1[qb])}, {v(ALPHA[qb])}")
     emit(f"s_mov_b32 {s(S_RESC)}, 1")
     emit(f"s_branch {back_label}")
 
@@ -356,6 +374,13 @@ def rescale_o_block(lbl, back):
                 emit(f"v_mul_f32 {v(T[k])}, {v(T[k])}, {v(ALPHA[qb])}")
             for k in range(8):
                 emit(f"v_accvgpr_write_b32 a{64 * qb + base + k}, {v(T[k])}")
+    if LMFMA:                                # the row sums: only register 0 of each block is ever read
+        for qb in (0, 1):
+            emit(f"v_accvgpr_read_b32 {v(T[qb])}, a{LSUM(qb)}")
+        for qb in (0, 1):
+            emit(f"v_mul_f32 {v(T[qb])}, {v(T[qb])}, {v(ALPHA[qb])}")
+        for qb in (0, 1):
+            emit(f"v_accvgpr_write_b32 a{LSUM(qb)}, {v(T[qb])}")
     emit(f"s_mov_b32 {s(S_RESC)}, 0")
     emit("s_nop 7")
     emit(f"s_branch {back}")
@@ -391,20 +416,21 @@ def n_fill(items):
 
 def distribute(queue, post, start, cap=0):
     q = list(queue)
+    ng = len(post)
     if cap <= 0:
-        total = sum(n_fill(post[t]) for t in range(start, NG)) + n_fill(q)
-        cap = -(-total // (NG - start))
-    for t in range(start, NG):
+        total = sum(n_fill(post[t]) for t in range(start, ng)) + n_fill(q)
+        cap = -(-total // (ng - start))
+    for t in range(start, ng):
         while q and n_fill(post[t]) < cap:
             post[t].append(q.pop(0))
             while q and isinstance(q[0], str) and q[0].endswith(":"):
                 post[t].append(q.pop(0))
-    post[NG - 1] += q
+    post[ng - 1] += q
 
 
 deferred = []
 QK_ORDER = [(sx, kb, qb) for sx in (0, 1) for kb in (0, 1) for qb in (0, 1)]      # dependent pairs are 4 MFMAs apart
-PV_ORDER = [(db, qb) for db in range(4) for qb in (0, 1)]
+PV_ORDER = [(db, qb) for db in range(4) for qb in (0, 1)] + ([(4, 0), (4, 1)] if LMFMA else [])   # db 4 = the row-sum MFMA
 K_FRAGS = [(j, t) for j in (0, 2, 1, 3) for t in (0, 1)]                            # sx = 0 fragments first
 
 
@@ -429,11 +455,11 @@ def step(variant):
 
     # ---- phase 2
     emit("s_nop 1")                          # the last e4m3 converts (VALU writes) -> first PV MFMA (reads them as B)
-    pre = [[] for _ in range(NG)]
-    post = [[] for _ in range(NG)]
+    pre = [[] for _ in range(NG2)]
+    post = [[] for _ in range(NG2)]
     mf = []
     for t, (db, qb) in enumerate(PV_ORDER):
-        if qb == 0:
+        if qb == 0 and db < 4:
             pre[t].append(("WAIT", ("v", db, 1)))
         mf.append(mfma_pv(cur, db, qb))
         if "klate" in OPT:
@@ -471,7 +497,7 @@ def step(variant):
     # gap 0 holds only ops that do not read S_nxt (its last MFMA was issued just before this phase)
     post[0] += vq[:n_head]
     distribute(vq[n_head:], post, 1)
-    for t in range(NG):
+    for t in range(NG2):
         out.extend(pre[t])
         out.append(mf[t])
         out.extend(post[t])
@@ -510,6 +536,9 @@ def prologue():
     emit(f"s_mov_b32 {s(S_RESC)}, 0")
     emit(f"v_mov_b32 {v(NEGINF)}, 0xff800000")
     emit(f"v_mov_b32 {v(VSC)}, 0x7f7f7f7f")
+    if LMFMA:
+        for r in range(8):
+            emit(f"v_mov_b32 {v(ONES + r)}, 0x38383838")      # e4m3 1.0 in every byte
 
     emit("; ---- per-lane constants")
     emit(f"v_lshrrev_b32 {v(T[0])}, 5, {v(LANE)}")            # hh
@@ -580,7 +609,7 @@ def prologue():
     for r in range(32):
         emit(f"v_accvgpr_write_b32 a{128 + r}, {v(r)}")
     emit("; ---- state")
-    for r in range(128):
+    for r in list(range(128)) + (list(range(LSUM(0), LSUM(1) + 16)) if LMFMA else []):
         emit(f"v_accvgpr_write_b32 a{r}, 0")
     for qb in (0, 1):
         emit(f"v_mov_b32 {v(MTRUE[qb])}, 0xff800000")
@@ -661,6 +690,8 @@ def epilogue():
     emit("s_nop 15")
     emit("s_nop 15")
     emit("s_nop 15")
+    if LMFMA:
+        globals()["LSUM_AGPR"] = [LSUM(0), LSUM(1)]            # l~ of the lane's row: register 0 of the row-sum accumulators
     store_epilogue(globals(), O_)                              # gen_epilogue.py: v_descale / l, bf16 O and LSE from the registers
     emit("s_waitcnt lgkmcnt(0)")
 

@@ -21,11 +21,13 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 //   head_dim 256: the hand-scheduled kernel in its 32-rows-per-wave form (q-tile 128) unless LA_FLAG_KERNEL_128ROW asks for the
 //   hipcc-scheduled v2 instantiation (same tiles); head_dim 96 / 192: the 128 / 256 hand-scheduled forms with three quarters of
 //   the fragments (no v2 instantiation: LA_ERR_HEAD_DIM under LA_FLAG_KERNEL_128ROW, hosts pad to 128 / 256 then);
-//   head_dim 64: v2; fp8 head_dim 128: x64-fp8. The skip lists are indexed by the selected kernel's tile, so
+//   head_dim 64: the hand-scheduled kernel with 8 + 8 fragments per tile (q-tile 256) unless LA_FLAG_KERNEL_128ROW asks for v2 (q-tile 128);
+//   fp8 head_dim 128: x64-fp8. The skip lists are indexed by the selected kernel's tile, so
 //   la_get_tile_sizes_ex and la_fwd must agree on it: both call uses_128row().
-constexpr uint32_t kKnownFlags = LA_FLAG_V_PREPARED | LA_FLAG_STATIC_SCHED | LA_FLAG_KERNEL_128ROW | LA_FLAG_EXACT_RESCALE;
-bool uses_128row(int head_dim, int element_size, uint32_t flags) {
-    return element_size == 2 && head_dim == 128 && (flags & LA_FLAG_KERNEL_128ROW) != 0;
+constexpr uint32_t kKnownFlags = LA_FLAG_V_PREPARED | LA_FLAG_STATIC_SCHED | LA_FLAG_KERNEL_128ROW | LA_FLAG_EXACT_RESCALE |
+                                LA_FLAG_EXACT_ROWSUM;
+bool uses_128row(int head_dim, int element_size, uint32_t flags) {      // the flag changes the q-tile (256 -> 128 rows) at head dims 64 and 128
+    return element_size == 2 && (head_dim == 128 || head_dim == 64) && (flags & LA_FLAG_KERNEL_128ROW) != 0;
 }
 constexpr uint64_t kSchedWorkspaceBytes = 1024;   // 8 ticket counters of 64 bytes (+ slack)
 constexpr float kRescaleTauBf16 = 8.0f;           // lazy-rescale slack of the x64 kernel, log2 units
@@ -43,7 +45,7 @@ const char* la_status_string(int status) {
         case LA_ERR_NULL_ARG: return "required pointer is NULL";
         case LA_ERR_STRUCT_SIZE: return "la_fwd_args.struct_size mismatch (ABI version skew)";
         case LA_ERR_DTYPE: return "FlashAttention only supports fp16, bf16, and fp8_e4m3 type; this build instantiates all three";
-        case LA_ERR_HEAD_DIM: return "head_size not instantiated in this build (bf16: 64, 128, 256; fp8: 128)";
+        case LA_ERR_HEAD_DIM: return "head_size not instantiated in this build (bf16 / fp16: 64, 96, 128, 192, 256 - under LA_FLAG_KERNEL_128ROW only 64, 128, 256; fp8: 128)";
         case LA_ERR_SHAPE: return "invalid shape (batch, seqlen_q, heads and head_dim must be positive; number of heads in key/value must divide number of heads in query)";
         case LA_ERR_STRIDE: return "Input tensor must have contiguous last dimension and 16-byte aligned rows";
         case LA_ERR_TILE_MISMATCH: return "block_m/block_n do not match la_get_tile_sizes(): skip lists would be mis-indexed";
@@ -195,14 +197,14 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
                                        a->batch, a->seqlen_k, a->num_heads_k, p.k_tiles, stream);
         if (e8 == hipSuccess) {
             p.v = static_cast<const uint16_t*>(a->workspace);
-            e8 = la::launch_fwd_fp8_d128_x64(p, a->read_list != nullptr, stream);
+            e8 = la::launch_fwd_fp8_d128_x64(p, a->read_list != nullptr, (a->flags & LA_FLAG_EXACT_ROWSUM) != 0, stream);
         }
         if (e8 != hipSuccess) { g_last_hip_error = static_cast<int>(e8); return LA_ERR_LAUNCH; }
         return LA_OK;
     }
-    // head_dim 96 / 128 / 192 / 256: the hand-scheduled x64 kernel unless LA_FLAG_KERNEL_128ROW; head_dim 64: the 128-row v2 template.
+    // every instantiated head_dim: the hand-scheduled x64 kernel unless LA_FLAG_KERNEL_128ROW (the hipcc-scheduled template: 64 / 128 / 256)
     const bool skipable = a->read_list != nullptr;                                      // is_skipable, flash_api.cpp:931
-    const bool x64 = a->head_dim != 64 && !(a->flags & LA_FLAG_KERNEL_128ROW);       // 96 / 128 / 192 / 256
+    const bool x64 = !(a->flags & LA_FLAG_KERNEL_128ROW);
     hipError_t err;
     // optional workspace (la_fwd_workspace_bytes): with it, launches that walk lists use persistent workgroups and the
     // ticket queues; without it, the static one-workgroup-per-item map (same results either way)

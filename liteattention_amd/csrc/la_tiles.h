@@ -9,7 +9,7 @@
 // of LDS. bf16 head_dim 128 (the headline path): ONE wave per SIMD owning the whole 512-entry register file and 64
 // query rows (two 32x32 MFMA column blocks), a workgroup is 4 waves -> kBlockM = 256; 256 x 64 = 16 Ki scores per
 // skip decision (reference Hopper tile: 128 x 176 = 22 Ki). fp8 head_dim 128 uses the same structure (kBlockM = 256). bf16
-// head_dim 64 and 256 / 192 keep 32 rows per wave, kBlockM = 128; 96 is the 128 kernel with fewer fragments (kBlockM = 256). LA_FLAG_KERNEL_128ROW (la_fwd_args.flags) selects the 128-row A/B
+// head_dim 256 / 192 keep 32 rows per wave, kBlockM = 128; 96 and 64 are the 128 kernel with fewer fragments (kBlockM = 256). LA_FLAG_KERNEL_128ROW (la_fwd_args.flags) selects the 128-row A/B
 // kernel for bf16 head_dim 128, and la_get_tile_sizes_ex then reports 128 (la_api.hip).
 #pragma once
 
@@ -24,7 +24,8 @@ struct TileShape {
 constexpr TileShape tile_shape(int head_dim, int element_size) {
     if (element_size == 2) {
         if (head_dim == 128 || head_dim == 96) return {256, 64};    // 96: the 128 kernel with 12 of the 16 fragments per tile
-        if (head_dim == 64) return {128, 64};   // K/V tile 8 KiB each: same key granularity, half the LDS
+        if (head_dim == 64) return {256, 64};   // round 3: the hand-scheduled form too (8 of the 16 fragments, LDS rows of 128 bytes);
+                                                // LA_FLAG_KERNEL_128ROW: the hipcc-scheduled 128-row template (round 2's kernel)
         if (head_dim == 256 || head_dim == 192) return {128, 64};   // K/V tile 32 KiB each, one workgroup per CU, one wave per SIMD
                                                                     // with 32 rows (O^T of 32 rows x 256 is 128 registers); 192: 24 of 32 fragments
     }

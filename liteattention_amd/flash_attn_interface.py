@@ -69,7 +69,10 @@ _FWD_SCHEMA = (
 )
 
 
-def kernel_head_dim(head_dim: int, element_size: int) -> int:
+_KERNEL_HEAD_DIM = {}      # (head_dim, element_size, kernel-selection flags) -> instantiated head_dim (the library's table never changes)
+
+
+def kernel_head_dim(head_dim: int, element_size: int, flags: Optional[int] = None) -> int:
     """The instantiated head_dim that serves ``head_dim``: the next size up for which the library has a kernel — the host
     zero-pads q, k, v to it (``mha_fwd``), which is exact: zero columns add 0 to every score and give zero output columns,
     which are sliced away. The reference instantiates 64/96/128/192/256 (hopper/setup.py:57-61) and picks the next size up the
@@ -78,15 +81,18 @@ def kernel_head_dim(head_dim: int, element_size: int) -> int:
     asked (``la_get_tile_sizes_ex``), there is no second table here."""
     if head_dim <= 0 or head_dim % (16 if element_size == 1 else 8) != 0:
         return head_dim                                      # la_get_tile_sizes / mha_fwd report the error
-    for d in (64, 96, 128, 192, 256):
-        if d >= head_dim and _cabi.is_instantiated(d, element_size):
-            return d
-    return head_dim
+    flags = (_cabi.default_flags() if flags is None else flags) & _cabi.LA_FLAG_KERNEL_128ROW
+    key = (head_dim, element_size, flags)
+    if key not in _KERNEL_HEAD_DIM:
+        _KERNEL_HEAD_DIM[key] = next((d for d in (64, 96, 128, 192, 256)
+                                      if d >= head_dim and _cabi.is_instantiated(d, element_size, flags)), head_dim)
+    return _KERNEL_HEAD_DIM[key]
 
 
 def get_tile_sizes(head_dim: int, element_size: int) -> Tuple[int, int]:
     """(kBlockM, kBlockN) of the gfx950 kernel that serves this head_dim — the single source for skip-list geometry."""
-    return _cabi.get_tile_sizes(kernel_head_dim(head_dim, element_size), element_size)
+    flags = _cabi.default_flags()
+    return _cabi.get_tile_sizes(kernel_head_dim(head_dim, element_size, flags), element_size, flags)
 
 
 def _check_list(t: Optional[torch.Tensor], name: str, q: torch.Tensor) -> Optional[int]:
@@ -111,7 +117,7 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
             is_causal=False, window_size_left=-1, window_size_right=-1, attention_chunk=0, softcap=0.0,
             is_rotary_interleaved=False, scheduler_metadata=None, num_splits=0, pack_gqa=None, sm_margin=0,
             attn_read_list=None, attn_must_do_list=None, attn_write_list=None, thr=-3.0,
-            _must_do_is_1d: bool = False, _q_windows=None, _window_hook=None, _static_sched: bool = False):
+            _must_do_is_1d: bool = False, _q_windows=None, _window_hook=None, _static_sched: bool = False, _flags: int = 0):
     """Host half of the op (flash_api.cpp:667-1249) for the non-causal, fixed-length subset (MHA / GQA / MQA) that
     ``LiteAttention.__call__`` reaches. Returns ``(out, softmax_lse, out_accum, softmax_lse_accum)``.
 
@@ -121,7 +127,10 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     [row_begin, row_end) of ``out`` are complete once that launch is; used to all-gather early rows while later
     windows compute). ``_static_sched`` sets LA_FLAG_STATIC_SCHED (per-item workgroups instead of persistent ones: a
     collective running beside the launch gets CUs as items retire); "after_first" sets it on every window but the first
-    (no collective is in flight beside window 0)."""
+    (no collective is in flight beside window 0). ``_flags``: extra ``LA_FLAG_*`` bits ORed into ``la_fwd_args.flags`` (tests / A/B:
+    LA_FLAG_EXACT_RESCALE, LA_FLAG_EXACT_ROWSUM); kernel-selection bits that change the tile geometry are not accepted here."""
+    if _flags & ~(_cabi.LA_FLAG_EXACT_RESCALE | _cabi.LA_FLAG_EXACT_ROWSUM):
+        raise ValueError("_flags accepts LA_FLAG_EXACT_RESCALE and LA_FLAG_EXACT_ROWSUM only")
     if not q.is_cuda:
         raise RuntimeError("lite_attention::fwd has no CPU implementation (HIP device tensors required)")
     if q.dtype not in (torch.bfloat16, torch.float16, torch.float8_e4m3fn):
@@ -177,7 +186,8 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     if softmax_scale is None:
         softmax_scale = D ** -0.5
 
-    D_kernel = kernel_head_dim(D, q.element_size())
+    host_flags = _cabi.default_flags()                       # the environment is read ONCE per call
+    D_kernel = kernel_head_dim(D, q.element_size(), host_flags)
     if D_kernel != D:
         # head_dim between the instantiated sizes: zero-pad the last dim (one extra pass over q, k, v; exact, see
         # kernel_head_dim), run the D_kernel kernel with the ORIGINAL softmax scale, slice the output
@@ -185,18 +195,21 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
             if is_fp8:
                 return torch.nn.functional.pad(t.view(torch.uint8), (0, D_kernel - D)).view(t.dtype)
             return torch.nn.functional.pad(t, (0, D_kernel - D))
+        out_dtype = torch.bfloat16 if is_fp8 else q.dtype
+        if out is not None and (out.dtype != out_dtype or tuple(out.shape) != (B, Sq, H, D) or out.stride(-1) != 1):
+            raise RuntimeError("For FP16/BF16 input, output must have the same dtype as inputs (BF16 for FP8 input), shape "
+                               "(batch, seqlen_q, nheads, headdim_v) and a contiguous last dimension")
         qp, kp, vp = pad_last(q), pad_last(k), pad_last(v)
         res = mha_fwd(qp, kp, vp, q_descale=q_descale, k_descale=k_descale, v_descale=v_descale,
                       softmax_scale=softmax_scale, attn_read_list=attn_read_list, attn_must_do_list=attn_must_do_list,
                       attn_write_list=attn_write_list, thr=thr, _must_do_is_1d=_must_do_is_1d, _q_windows=_q_windows,
-                      _static_sched=_static_sched,
+                      _static_sched=_static_sched, _flags=_flags,
                       _window_hook=None if _window_hook is None else
                       (lambda i, o, r0, r1: _window_hook(i, o[..., :D], r0, r1)))
-        o = res[0][..., :D]
-        if out is not None:
-            out.copy_(o)
-            o = out
-        return (o, *res[1:])
+        if out is None:
+            out = torch.empty((B, Sq, H, D), dtype=out_dtype, device=q.device)      # contiguous, as the reference returns it
+        out.copy_(res[0][..., :D])
+        return (out, *res[1:])
 
     out_dtype = torch.bfloat16 if is_fp8 else q.dtype                                            # :859
     if out is None:
@@ -217,7 +230,7 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     else:
         must_ptr = _check_list(attn_must_do_list, "attn_must_do_list", q)
 
-    block_m, block_n = get_tile_sizes(D, q.element_size())
+    block_m, block_n = _cabi.get_tile_sizes(D, q.element_size(), host_flags)
     q_tiles, k_tiles = -(-Sq // block_m), -(-Sk // block_n)
     for name, t in (("attn_read_list", attn_read_list), ("attn_write_list", attn_write_list),
                     ("attn_must_do_list", None if _must_do_is_1d else attn_must_do_list)):
@@ -251,15 +264,14 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     # caller-owned scratch (the C side allocates nothing): fp8 = the pre-transposed V tiles; bf16 with lists = the ticket
     # counter of the dynamic work distribution. Freed after the launch by the caching allocator's stream-ordered reuse.
     workspace = None
-    a.flags = (_cabi.default_flags() & ~(_cabi.LA_FLAG_KERNEL_128ROW if is_fp8 else 0)) | \
-              (_cabi.LA_FLAG_STATIC_SCHED if _static_sched is True else 0)
+    base_flags = (host_flags & ~(_cabi.LA_FLAG_KERNEL_128ROW if is_fp8 else 0)) | _flags
+    a.flags = base_flags | (_cabi.LA_FLAG_STATIC_SCHED if _static_sched is True else 0)
     need = _cabi.load().la_fwd_workspace_bytes(ctypes.byref(a))
     if need < 0:
         raise RuntimeError(f"lite_attention::fwd: {_cabi.status_string(int(need))}")
     if need > 0:
         workspace = torch.empty(int(need), dtype=torch.uint8, device=q.device)
         a.workspace, a.workspace_bytes = workspace.data_ptr(), int(need)
-    base_flags = _cabi.default_flags() & ~(_cabi.LA_FLAG_KERNEL_128ROW if is_fp8 else 0)
     windows = [(0, 0)] if _q_windows is None else [(int(b0), int(c0)) for b0, c0 in _q_windows]
     if _q_windows is not None and any(c0 <= 0 or b0 < 0 or b0 + c0 > q_tiles for b0, c0 in windows):
         raise RuntimeError(f"q-tile windows must lie inside [0, {q_tiles}) with positive counts; got {windows}")
@@ -321,14 +333,15 @@ def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
     B = cu_seqlens_q.numel() - 1
     D_kernel = kernel_head_dim(D, 2)
     if D_kernel != D:
+        if out is not None and (out.dtype != q.dtype or tuple(out.shape) != (Tq, H, D) or out.stride(-1) != 1):
+            raise RuntimeError("out must have the input dtype, shape (total_q, nheads, headdim) and a contiguous last dimension")
         pad = lambda t: torch.nn.functional.pad(t, (0, D_kernel - D))                                          # noqa: E731
         res = _mha_fwd_varlen(pad(q), pad(k), pad(v), None, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, None,
                               None, None, softmax_scale, None, None)
-        o = res[0][..., :D]
-        if out is not None:
-            out.copy_(o)
-            o = out
-        return (o, *res[1:])
+        if out is None:
+            out = torch.empty((Tq, H, D), dtype=q.dtype, device=q.device)           # contiguous (total_q, H, D), as the reference's
+        out.copy_(res[0][..., :D])
+        return (out, *res[1:])
     if out is None:
         out = torch.empty((Tq, H, D), dtype=q.dtype, device=q.device)
     elif out.dtype != q.dtype or tuple(out.shape) != (Tq, H, D) or out.stride(-1) != 1:

@@ -34,7 +34,8 @@ class LiteAttention:
     """QK-Skip attention with internally managed read/write skip lists.
 
     Args mirror the reference (lite_attention.py:36): ``enable_skipping=True``, ``threshold=-10.0``
-    (log2 domain, must be negative unless env LITE_ATTENTION_DEBUG is set), ``max_batch_size=4``.
+    (log2 domain, must be negative unless env LITE_ATTENTION_DEBUG is set), ``max_batch_size=4`` (an upper bound: the lists are
+    allocated for the batch actually seen and grow up to it, ``_skip_list[2, batch_seen, H, Qt, Kt+1]``).
     One instance per attention layer; not thread-safe (README.md:162-172)."""
 
     def __init__(self, enable_skipping: bool = True, threshold: float = -10.0, max_batch_size: int = 4):
@@ -85,19 +86,28 @@ class LiteAttention:
         return row.repeat(*list_shape[:3], 1).contiguous()
 
     # ---- list management ----------------------------------------------------------------------
-    def _init_skip_list(self, query: Tensor, value: Tensor, must_skip_list: list = None) -> Tensor:
-        return self.init_skip_list(self.max_batch_size, query.shape[1], query.shape[2], query.shape[3], False,
-                                   query.dtype, query.device, must_skip_list, seq_len_k=value.shape[1])
+    def _init_skip_list(self, query: Tensor, value: Tensor, must_skip_list: list = None, batch: Optional[int] = None) -> Tensor:
+        """Both ping-pong buffers for ``batch`` sequences (default: the batch of ``query``). The reference always allocates
+        ``max_batch_size`` (lite_attention.py:155-162, SURVEY Appendix B-7: 326 MB per layer at the Wan2.1 shape with the
+        default 4, 13 GB over 40 layers); here the lists cover the batch actually seen and grow on demand up to
+        ``max_batch_size`` (``_get_read_write_lists``), so a default-constructed object costs what ``max_batch_size=1`` would."""
+        return self.init_skip_list(query.shape[0] if batch is None else batch, query.shape[1], query.shape[2], query.shape[3],
+                                   False, query.dtype, query.device, must_skip_list, seq_len_k=value.shape[1])
 
     def _get_read_write_lists(self, query: Tensor, value: Tensor, must_skip_list: list = None
                               ) -> Tuple[Optional[Tensor], Optional[Tensor]]:
         """(read, write) views for this call; (re)builds the lists when any of seq lengths / heads /
-        head_dim / dtype / device changed (:179-200) and flips the ping-pong phase (:203-210)."""
+        head_dim / dtype / device - or the tile geometry of the kernel that will run - changed (:179-200) and flips the
+        ping-pong phase (:203-210). A batch larger than any seen so far (<= max_batch_size) grows the lists: the state of the
+        sequences already tracked is kept, the new ones start from "all tiles listed"."""
         if not self.enable_skipping:
             return None, None
         # checked on EVERY call (the reference only checks at (re)init, :158, and would index past the lists)
         assert query.shape[0] <= self.max_batch_size, "batch size must be less than or equal to max_batch_size (modify max_batch_size in LiteAttention constructor)"
-        key = (query.shape[1], value.shape[1], query.shape[2], query.shape[3], query.dtype, query.device)
+        # the tile sizes belong to the key: LA_FWD_KERNEL=v2 changes the q-tile of head_dim 128 from 256 to 128 rows, and lists
+        # built for one geometry are mis-shaped for the other (ADVICE r2)
+        key = (query.shape[1], value.shape[1], query.shape[2], query.shape[3], query.dtype, query.device,
+               get_tile_sizes(query.shape[3], query.dtype.itemsize))
         if self._skip_list is None or key != self._shape_key:
             self._skip_list = self._init_skip_list(query, value, must_skip_list)
             self._shape_key = key
@@ -105,17 +115,25 @@ class LiteAttention:
             self._must_do_rows = {}
             if _verbose():
                 print("[Warning]: reinitialized skip list during the forward pass")
+        elif query.shape[0] > self._skip_list.shape[1]:
+            grown = self._init_skip_list(query, value, must_skip_list)
+            grown[:, : self._skip_list.shape[1]] = self._skip_list
+            self._skip_list = grown
         rd = self._phase
         self._phase = 1 - rd
         return self._skip_list[rd], self._skip_list[1 - rd]
 
+    _MUST_DO_ROWS_MAX = 8          # distinct must_do_list values whose device rows are kept (least recently used go first)
+
     def _must_do_device_row(self, must_do_list, query: Tensor, width: int) -> Tensor:
         key = (0, 0) if must_do_list is None else tuple(must_do_list)   # [0,0] = empty must-do (:267)
-        row = self._must_do_rows.get(key)
+        row = self._must_do_rows.pop(key, None)
         if row is None:
             _, bn = get_tile_sizes(query.shape[-1], query.dtype.itemsize)
             row = _sl.must_do_row(key, bn, width, query.device)
-            self._must_do_rows[key] = row
+            while len(self._must_do_rows) >= self._MUST_DO_ROWS_MAX:
+                self._must_do_rows.pop(next(iter(self._must_do_rows)))
+        self._must_do_rows[key] = row                                    # (re)inserted last = most recently used
         return row
 
     # ---- the attention call -------------------------------------------------------------------
@@ -207,6 +225,7 @@ class LiteAttention:
             "max_batch_size": self.max_batch_size,
             "shape_key": None if key is None else (*key[:4], str(key[4]).replace("torch.", "")),
             "device": None if key is None else str(key[5]),
+            "tile_sizes": None if key is None else tuple(key[6]),
         }
 
     def load_state_dict(self, state: dict, device=None):
@@ -226,10 +245,18 @@ class LiteAttention:
         dev = torch.device(device)
         if dev.type == "cuda" and dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())      # query.device always carries an index
+        sq, sk, h, d, dt = state["shape_key"]
+        dtype = getattr(torch, dt)
+        tiles = get_tile_sizes(d, dtype.itemsize)
+        saved = state.get("tile_sizes")                       # absent in round-2 checkpoints: the list shape decides
+        if saved is not None and tuple(saved) != tuple(tiles):
+            raise ValueError(f"this state was saved for kernel tiles {tuple(saved)}, the kernel selected now uses {tuple(tiles)} "
+                             "(LA_FWD_KERNEL differs?): the lists cannot be reused")
+        if tuple(state["skip_list"].shape[3:]) != (_sl.cdiv(sq, tiles[0]), _sl.cdiv(sk, tiles[1]) + 1):
+            raise ValueError("the saved lists do not match the tile geometry of the kernel selected now")
         self._skip_list = state["skip_list"].to(dev).contiguous()
         self._phase = state["phase"]
-        sq, sk, h, d, dt = state["shape_key"]
-        self._shape_key = (sq, sk, h, d, getattr(torch, dt), dev)
+        self._shape_key = (sq, sk, h, d, dtype, dev, tuple(tiles))
 
 
 class SeqParallelLiteAttention:

@@ -140,6 +140,100 @@ def sampled_row_check(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: to
     return res
 
 
+# ----------------------------------------------------------------------------------------- skip vote + list writer, restated
+def lists_to_bitmap(lists: torch.Tensor) -> torch.Tensor:
+    """bool[..., k_tiles]: the tiles every row of ``lists`` ([..., k_tiles + 1] int32, any device) walks. Range 0 is walked even
+    when L == 0 (mainloop_fwd_sm90_tma_gmma_ws.hpp:93-101); ranges are (start, end) with start >= end, both inclusive."""
+    kt = lists.shape[-1] - 1
+    flat = lists.reshape(-1, kt + 1).to(torch.int64)
+    body = flat[:, 1:]
+    if kt % 2:
+        body = torch.nn.functional.pad(body, (0, 1))
+    pairs = body.unflatten(-1, (-1, 2))
+    live = (torch.arange(pairs.shape[1], device=lists.device)[None] < (flat[:, :1].clamp_min(2) // 2))
+    starts, ends = pairs[..., 0].clamp(0, kt - 1), pairs[..., 1].clamp(0, kt - 1)
+    live = live & (pairs[..., 0] >= pairs[..., 1])
+    diff = torch.zeros(flat.shape[0], kt + 1, dtype=torch.int32, device=lists.device)
+    one = live.to(torch.int32)
+    diff.scatter_add_(1, ends, one)
+    diff.scatter_add_(1, starts + 1, -one)
+    return (diff.cumsum(1)[:, :kt] > 0).reshape(*lists.shape[:-1], kt)
+
+
+def walk_of_row(row: Sequence[int]) -> List[int]:
+    """Tiles in the order the kernel's reader visits them for one list row (mainloop...:1804-1827)."""
+    n = max(int(row[0]), 2)
+    seq: List[int] = []
+    for i in range(1, n, 2):
+        seq.extend(range(int(row[i]), int(row[i + 1]) - 1, -1))
+    return seq
+
+
+def written_row(read_row: Sequence[int], flags: Sequence[bool]) -> List[int]:
+    """``SkipListWriter`` without a must-do list, restated (mainloop...:142-192): ``flags[i]`` is the skip vote of the i-th visited
+    tile (the first visited tile is recorded as not skipped whatever it voted, :1804-1805). Returns ``[L, entries...]``."""
+    out = [0]
+    skipping = True
+    n_ranges = max(int(read_row[0]), 2) // 2
+    pos = 0
+    for r in range(n_ranges):
+        start, end = int(read_row[1 + 2 * r]), int(read_row[2 + 2 * r])
+        skip = False
+        for n in range(start, end - 1, -1):
+            skip = bool(flags[pos]) and pos > 0
+            pos += 1
+            if skip != skipping:                      # record_transition (:163-168)
+                out.append(n)
+                skipping = skip
+        skipping = True                               # record_range_end (:173-181)
+        if not skip:
+            out.append(end)
+    out[0] = len(out) - 1
+    return out
+
+
+@torch.no_grad()
+def vote_writer_check(q: torch.Tensor, k: torch.Tensor, read_list: torch.Tensor, write_list: torch.Tensor, thr: float,
+                      block_m: int, block_n: int, items: Iterable, batch: int = 0, softmax_scale: Optional[float] = None,
+                      margin_tol: float = 1e-3) -> Dict:
+    """For every sampled ``(head, q-tile)`` of ``items``: fp32 scores of the whole q-tile (rows past seqlen_q are zero rows and
+    vote, as the reference's TMA zero fill does) against all keys, the walk of the row's READ list, the skip vote of every
+    walked tile — ``AND over the q-tile's rows of [(m_loc - m_prev) c <= thr]`` with the running max BEFORE the tile, c =
+    softmax_scale log2 e (softmax.h:190-194) — and the write row the writer state machine produces from the votes, compared
+    with the row the kernel wrote. A row that differs is "borderline" when one of its tiles has a decision margin within
+    ``margin_tol`` of ``thr`` (fp32 summation order may flip it), otherwise "bad". q (B,S,H,D), k (B,Sk,Hk,D); lists
+    [B,H,Qt,Kt+1]. Returns {"items", "bad", "borderline", "max_ranges", "ok"}."""
+    B, S, H, D = q.shape
+    Sk, Hk = k.shape[1], k.shape[2]
+    kt = -(-Sk // block_n)
+    c = (D ** -0.5 if softmax_scale is None else softmax_scale) * 1.4426950408889634
+    res = {"items": 0, "bad": 0, "borderline": 0, "max_ranges": 0, "ok": True}
+    for h, m in items:
+        rows = q[batch, m * block_m: (m + 1) * block_m, h].float()
+        if rows.shape[0] < block_m:
+            rows = torch.nn.functional.pad(rows, (0, 0, 0, block_m - rows.shape[0]))
+        s = rows @ k[batch, :, h // (H // Hk)].float().T                                  # [block_m, Sk]
+        s = torch.nn.functional.pad(s, (0, kt * block_n - Sk), value=float("-inf"))       # seqlen-k mask of tile kt-1
+        tile_max = s.view(block_m, kt, block_n).amax(-1)                                  # [block_m, kt]
+        rd = read_list[batch, h, m].tolist()
+        walk = walk_of_row(rd)
+        wm = tile_max[:, torch.tensor(walk, device=q.device)]                             # row max per visited tile
+        run = torch.cummax(wm, dim=1).values
+        margin = ((wm[:, 1:] - run[:, :-1]) * c).amax(0)                                  # worst row of every visited tile but the first
+        flags = [False] + (margin <= thr).tolist()
+        want = written_row(rd, flags)
+        got = write_list[batch, h, m, : want[0] + 1].tolist()
+        res["items"] += 1
+        res["max_ranges"] = max(res["max_ranges"], max(int(rd[0]), 2) // 2)
+        if got != want:
+            if bool(((margin - thr).abs() < margin_tol).any().item()):
+                res["borderline"] += 1
+            else:
+                res["bad"] += 1
+    res["ok"] = res["bad"] == 0
+    return res
+
+
 # ----------------------------------------------------------------------------------------- 50-step denoising workload
 class DenoiseWorkload:
     """BASELINE.json configs[2]: synthetic, slowly varying, STRUCTURED q/k/v of a 50-step denoising loop at the Wan2.1 video shape

@@ -1,5 +1,6 @@
 """Shared test helpers: seeded inputs (same recipe as tests/golden/make_golden.py) and golden loading."""
 import json
+import math
 import os
 
 import numpy as np
@@ -46,6 +47,15 @@ def ref_tolerance(out_ref, pt_maxerr):
     return 2 * pt_maxerr + fwd_atol
 
 
+def fp8_lse_tol():
+    """Bound on |LSE - oracle| for the fp8 kernel. Default: the row sums are those of the e4m3-ROUNDED P (taken from the matrix
+    pipe, gen_fwd_x64_fp8.py LMFMA), every P~ is within 2^-4 of its P, so |ln(sum P~ / sum P)| <= ln(1 + 2^-4) = 0.0606 (reached
+    only by rows of one or two comparable keys; 1e-2 typical for a few keys; on long rows the noise averages out and a bias of
+    about -7e-4 remains - round-to-nearest of a log-uniform P loses (step / value)^2 / 12 of the sum). LA_FP8_ROWSUM=exact
+    (LA_FLAG_EXACT_ROWSUM): fp32 sums of the un-rounded P as in the reference (softmax.h:275-296): 1e-3, the bf16 bound."""
+    return 1e-3 if os.environ.get("LA_FP8_ROWSUM", "").startswith("exact") else math.log1p(2.0 ** -4) + 1e-3
+
+
 def host_golden():
     with open(os.path.join(GOLDEN, "host_golden.json")) as f:
         return json.load(f)
@@ -65,3 +75,32 @@ def structured_qkv(B, S, H, D, seed, alpha=10.0, frames=8, dtype=torch.bfloat16)
         out.append(x.to(dtype))
     out.append(torch.randn(B, S, H, D, generator=g).to(dtype))
     return out
+
+
+def fragmented_qkv(B, S, H, D, seed, step=0, steps=6, alpha=10.0, block_n=64, dtype=torch.bfloat16, Sk=None):
+    """Inputs whose QK-Skip lists FRAGMENT: key tiles (of `block_n` keys) are hot every 3rd or 4th tile (per-head pattern) and cold between, cold
+    tiles score `1 - g` below the hot ones (g per tile, fixed by `seed`), so a negative threshold flags most cold pairs and every
+    flagged pair splits the list (the first flagged tile of a run stays as the range end): about Kt / 3.5 ranges per
+    row, i.e. more than the 64 ranges one pass of the wave-parallel list expansion handles once Kt > 200. Some hot tiles are only
+    lukewarm and some cold ones nearly hot, and the per-step noise shrinks (`step` / `steps`), so lists keep changing over steps.
+    Returns bf16-representable (q, k, v) of shape (B, S|Sk, H, D) on the CPU."""
+    Sk = S if Sk is None else Sk
+    g = torch.Generator().manual_seed(seed)
+    kt = -(-Sk // block_n)
+    u = torch.randn(B, 1, H, D, generator=g)
+    u = u / u.norm(dim=-1, keepdim=True)
+    pos = torch.cumsum(torch.randint(3, 5, (B, H, kt), generator=g), dim=-1) - 3   # a hot tile every 3 or 4 tiles, per head
+    hot = torch.zeros(B, H, kt + 4, dtype=torch.bool).scatter_(2, pos.clamp(max=kt + 3), True)[..., :kt]
+    gain_hot = 0.62 + 0.38 * torch.rand(B, H, kt, generator=g)
+    gain_cold = 0.45 * torch.rand(B, H, kt, generator=g) ** 0.5
+    gain = torch.where(hot, gain_hot, gain_cold)
+    gain[..., kt - 1] = 1.0                                                       # the first walked tile sets the running max
+    gain_keys = gain.permute(0, 2, 1).repeat_interleave(block_n, dim=1)[:, :Sk]   # (B, Sk, H)
+    q0 = alpha * u + torch.randn(B, S, H, D, generator=g)
+    k0 = alpha * gain_keys[..., None] * u + torch.randn(B, Sk, H, D, generator=g)
+    v0 = torch.randn(B, Sk, H, D, generator=g)
+    s = 0.6 * (1.0 - step / max(1, steps))                                        # per-step perturbation, shrinking
+    gs = torch.Generator().manual_seed(seed * 1000 + 17 + step)
+    q = q0 + s * torch.randn(q0.shape, generator=gs)
+    k = k0 + s * torch.randn(k0.shape, generator=gs)
+    return q.to(dtype), k.to(dtype), v0.to(dtype)

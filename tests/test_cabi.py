@@ -51,7 +51,7 @@ def test_struct_layout_matches_header(tmp_path):
 
 
 def test_tile_sizes_and_status_strings():
-    assert _cabi.get_tile_sizes(128, 2) == (256, 64) and _cabi.get_tile_sizes(64, 2) == (128, 64)
+    assert _cabi.get_tile_sizes(128, 2) == (256, 64) and _cabi.get_tile_sizes(64, 2) == (256, 64)
     assert _cabi.get_tile_sizes(96, 2) == (256, 64) and _cabi.get_tile_sizes(192, 2) == (128, 64) and _cabi.get_tile_sizes(256, 2) == (128, 64)
     assert _cabi.get_tile_sizes(128, 1) == (256, 64)
     lib = _cabi.load()

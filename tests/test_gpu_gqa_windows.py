@@ -7,7 +7,7 @@ import math
 import pytest
 import torch
 
-from helpers import GQA_CASES, GQA_FP8_CASES, load_dense_case, ref_tolerance, structured_qkv
+from helpers import GQA_CASES, GQA_FP8_CASES, load_dense_case, ref_tolerance, structured_qkv, fp8_lse_tol
 from test_gpu_parity import _compare_lists, _oracle_tol
 
 pytestmark = pytest.mark.gpu
@@ -52,12 +52,12 @@ def test_gqa_fp8_matches_reference_outputs(name):
     out, lse = L.flash_attn_func(q, k, v, q_descale=qd, k_descale=kd, v_descale=vd, return_softmax_lse=True)
     err = (out.float().cpu() - c["out_ref"]).abs().max().item()
     assert err <= ref_tolerance(c["out_ref"], c["pt_maxerr"]), (err, ref_tolerance(c["out_ref"], c["pt_maxerr"]))
-    assert (lse.cpu() - c["lse_ref"]).abs().max().item() <= 1e-3
+    assert (lse.cpu() - c["lse_ref"]).abs().max().item() <= fp8_lse_tol()
     bm8, bn8 = L.get_tile_sizes(128, 1)
     o8, lse8, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=bm8, block_n=bn8, p_round="fp8",
                                  q_descale=c["q_descale"], k_descale=c["k_descale"], v_descale=c["v_descale"])
     assert (out.float().cpu() - o8).abs().max().item() <= 0.05 * o8.abs().max().item() + 2e-2
-    assert (lse.cpu() - lse8).abs().max().item() <= 1e-3
+    assert (lse.cpu() - lse8).abs().max().item() <= fp8_lse_tol()
 
 
 @pytest.mark.parametrize("D", [128, 64])
@@ -172,7 +172,7 @@ def test_other_head_dims_run_on_the_next_instantiated_kernel(D, dtype):
                                            margins=margins, p_round="fp8" if dtype == "fp8" else True)
         tol = (0.05 * o_ref.abs().max().item() + 2e-2) if dtype == "fp8" else _oracle_tol(o_ref)
         assert (out.float().cpu() - o_ref).abs().max().item() <= tol
-        assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
+        assert (lse.cpu() - lse_ref).abs().max().item() <= (fp8_lse_tol() if dtype == "fp8" else 1e-3)
         bad, _ = _compare_lists(orc, rd, wr, wr_orc, margins, -3.0, B)
         assert bad == 0
 
@@ -242,7 +242,10 @@ def test_longest_supported_key_sequence_and_the_typed_error_beyond_it(dtype):
     ref = torch.softmax(sc, -1) @ vf
     tol = 0.05 * ref.abs().max().item() + 2e-2 if dtype == "fp8" else 2.0 ** -7 * ref.abs().max().item() + 1e-3
     assert (out.float()[0, :, 0] - ref).abs().max().item() <= tol
-    assert (lse[0, 0] - torch.logsumexp(sc, -1)).abs().max().item() <= 1e-3
+    # fp8 default: row sums of the e4m3-rounded P. Over 288 k keys the rounding noise averages out but its BIAS does not: P is
+    # log-uniform inside an e4m3 rounding interval, so round-to-nearest loses (step / value)^2 / 12 ~ 7e-4 of the sum (measured
+    # 6e-4 .. 1e-3, every row low); LA_FLAG_EXACT_ROWSUM has neither (tests/test_gpu_fp8.py runs both modes)
+    assert (lse[0, 0] - torch.logsumexp(sc, -1)).abs().max().item() <= (2.5e-3 if dtype == "fp8" else 1e-3)
     assert att.get_skip_fraction() == 0.0
     too_long = torch.zeros(1, 40000 * 64, H, D, dtype=q.dtype, device="cuda")
     with pytest.raises(RuntimeError, match="too long"):
@@ -293,7 +296,7 @@ def test_reference_profile_script_head_dims():
         torch.cuda.synchronize()
         bm, bn = L.get_tile_sizes(head_dim, 2)
         Qt, Kt = math.ceil(10000 / bm), math.ceil(10000 / bn)
-        assert tuple(attn._skip_list.shape) == (2, 4, 4, Qt, Kt + 1) and output.shape == q.shape
+        assert tuple(attn._skip_list.shape) == (2, 1, 4, Qt, Kt + 1) and output.shape == q.shape      # the batch seen (reference: max_batch_size = 4)
         cur = attn.current_read_list()[:1]
         assert bool((cur[..., 0] >= 2).all()) and bool((cur[..., 1] == Kt - 1).all())
         assert attn.get_skip_fraction(batch=1) > 0.9

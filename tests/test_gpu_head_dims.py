@@ -1,4 +1,5 @@
-"""GPU: head dims 96, 192 and 256 on the hand-scheduled kernel. 256: 32 query rows per wave, q-tile 128 x k-tile 64 (generator run with
+"""GPU: head dims 64, 96, 192 and 256 on the hand-scheduled kernel. 64 (round 3): the head_dim-128 form (q-tile 256) with 8 of the 16 K /
+V^T fragments per tile on an LDS image of 128-byte rows (generator run with LA_X64_D=64). 256: 32 query rows per wave, q-tile 128 x k-tile 64 (generator run with
 LA_X64_D=256); 192: the same with 24 of the 32 K / V^T fragments per tile; 96: the head_dim-128 form (q-tile 256) with 12 of 16.
 The reference builds these head sizes by default (hopper/setup.py:57-61, instantiations/flash_fwd_hdim{96,192,256}_bf16_sm90.cu). Cases:
 dense ragged shapes and skip lists over several steps against the oracle, bf16 and fp16; the persistent multi-item loop with ticket
@@ -11,14 +12,14 @@ from helpers import structured_qkv
 from test_gpu_parity import _compare_lists
 
 pytestmark = pytest.mark.gpu
-DIMS = [96, 192, 256]
+DIMS = [64, 96, 192, 256]
 
 
 def _L():
     import liteattention_amd as L
-    assert L.get_tile_sizes(256, 2) == (128, 64) and L.get_tile_sizes(192, 2) == (128, 64) and L.get_tile_sizes(96, 2) == (256, 64)
+    assert L.get_tile_sizes(256, 2) == (128, 64) and L.get_tile_sizes(192, 2) == (128, 64) and L.get_tile_sizes(96, 2) == L.get_tile_sizes(64, 2) == (256, 64)
     from liteattention_amd.flash_attn_interface import kernel_head_dim
-    assert [kernel_head_dim(d, 2) for d in (72, 96, 160, 192, 256)] == [96, 96, 192, 192, 256]      # native, not zero-padded
+    assert [kernel_head_dim(d, 2) for d in (40, 64, 72, 96, 160, 192, 256)] == [64, 64, 96, 96, 192, 192, 256]      # native, not zero-padded
     return L
 
 

@@ -10,7 +10,10 @@ hopper/tests/test_flash_attn.py:152-177; property style of test_gpu_parity.py::t
   * dynamic (ticket queues, persistent workgroups) == static (one workgroup per item, XCD map) bit-exactly: O, LSE, lists;
   * >= 256 sampled query rows per checked head against an fp32 torch attention over exactly the listed keys:
         bf16: |O - ref| <= 2^-8 max|ref| + 1e-4      fp8: |O - ref| <= 0.05 max|ref| + 1e-3 (P is rounded to e4m3)
-        LSE:  |LSE - ref| <= 2e-4 for both (one missing 64-key tile of a 43 k-key row moves the LSE by 1.5e-3).
+        LSE:  |LSE - ref| <= 2e-4 (bf16, and fp8 with LA_FLAG_EXACT_ROWSUM: one missing 64-key tile of a 43 k-key row moves the LSE
+              by 1.5e-3, so a skipped, doubled or mis-masked tile cannot hide); fp8 default <= 2.5e-3: the row sums are those of
+              the e4m3-rounded P, whose rounding noise averages out over a long row but whose bias (about -7e-4: P is log-uniform
+              inside a rounding interval) does not. The walk is the same code in both fp8 modes.
 """
 import pytest
 import torch
@@ -27,10 +30,14 @@ def qkv():
     return [torch.randn(1, S, H, D, device="cuda", generator=g, dtype=torch.float32).to(torch.bfloat16) for _ in range(3)]
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp8", "fp8-exact-rowsum"])
 @pytest.mark.parametrize("sparsity", [0.42, 0.77, None])
-def test_headline_shape(qkv, dtype, sparsity):
+def test_headline_shape(qkv, dtype, sparsity, monkeypatch):
     import liteattention_amd as L
+    exact_rowsum = dtype == "fp8-exact-rowsum"                            # LA_FLAG_EXACT_ROWSUM: the reference's fp32 row sums
+    if exact_rowsum:
+        monkeypatch.setenv("LA_FP8_ROWSUM", "exact")
+        dtype = "fp8"
     from liteattention_amd import selfcheck as sc
     from liteattention_amd.flash_attn_interface import mha_fwd
     fp8 = dtype == "fp8"
@@ -72,7 +79,7 @@ def test_headline_shape(qkv, dtype, sparsity):
     assert torch.equal(out_s, out) and torch.equal(lse_s, lse)
     assert same_rows(wr_s, wr)
 
-    tol = dict(o_rtol=0.05, o_atol=1e-3) if fp8 else dict(o_rtol=2.0 ** -8, o_atol=1e-4)
+    tol = dict(o_rtol=0.05, o_atol=1e-3, lse_atol=2e-4 if exact_rowsum else 2.5e-3) if fp8 else dict(o_rtol=2.0 ** -8, o_atol=1e-4)
     res = sc.sampled_row_check(q, k, v, out, lse, read, bm, bn, heads=(0, 17, 39), n_rows=256, **tol)
     assert res["ok"], res
     assert res["rows"] >= 3 * 256

@@ -99,7 +99,7 @@ def test_g4_call_trace_matches_reference(rec):
     att.set_threshold(-2.0)
     att(q2, q2, q2)
     assert len(rec.calls) == len(g["trace"])
-    for call, ref in zip(rec.calls, g["trace"]):
+    for i, (call, ref) in enumerate(zip(rec.calls, g["trace"])):
         # which ping-pong buffer is read / written: recover the index from the storage offset
         per = call["read"].numel() * 4
         # the lists of one call are the two halves of ONE allocation
@@ -107,8 +107,10 @@ def test_g4_call_trace_matches_reference(rec):
         assert (call["read"].data_ptr() - lo) // per == ref["read"]
         assert (call["write"].data_ptr() - lo) // per == ref["write"]
         assert call["thr"] == ref["thr"] and call["scale"] == ref["scale"]
-        # same [maxB, H, ., .] geometry; the tile counts differ because the tiles differ (reference 128 x 176, here 256 x 64)
-        assert list(call["read"].shape[:2]) == ref["list_shape"][:2]
+        # [batch, H, ., .]: the reference allocates max_batch_size rows whatever the batch, this build the
+        # batch it has seen (1 for the first three calls, then 2), never more than the reference; the tile counts differ because
+        # the tiles differ (reference 128 x 176, here 256 x 64)
+        assert call["read"].shape[0] == (1 if i < 3 else 2) <= ref["list_shape"][0] and call["read"].shape[1] == ref["list_shape"][1]
         assert call["must_do"][:3].tolist() == ref["must_do_head"]       # default [0,0] -> [2,0,0]
     bm, bn = L.get_tile_sizes(128, 2)
     assert rec.calls[0]["read"].shape[2:] == (-(-1000 // bm), -(-1000 // bn) + 1)
@@ -120,7 +122,7 @@ def test_phase_and_reinit_rules(rec):
     q = torch.zeros(1, 300, 2, 128, dtype=torch.bfloat16)
     att(q, q, q)
     first = att._skip_list
-    assert att._phase == 1 and first.shape == (2, 2, 2, -(-300 // L.get_tile_sizes(128, 2)[0]), 6)
+    assert att._phase == 1 and first.shape == (2, 1, 2, -(-300 // L.get_tile_sizes(128, 2)[0]), 6)     # the batch SEEN, not max_batch_size
     att(q, q, q)
     assert att._phase == 0 and att._skip_list is first
     # changing heads, dtype or key length re-initialises (lite_attention.py:179-187 + Appendix B-2)
@@ -129,7 +131,13 @@ def test_phase_and_reinit_rules(rec):
     assert att._skip_list is not first and att._phase == 1 and att._skip_list.shape[2] == 3
     kshort = torch.zeros(1, 200, 3, 128, dtype=torch.bfloat16)
     att(q3, kshort, kshort)
-    assert att._skip_list.shape == (2, 2, 3, -(-300 // L.get_tile_sizes(128, 2)[0]), 5) and att._phase == 1     # Kt from key.shape[1]
+    assert att._skip_list.shape == (2, 1, 3, -(-300 // L.get_tile_sizes(128, 2)[0]), 5) and att._phase == 1     # Kt from key.shape[1]
+    # a larger batch (<= max_batch_size) GROWS the lists: the tracked sequence keeps its state, the new one starts full
+    att._skip_list[:, 0, :, :, 1] = 2                                    # mark sequence 0's rows
+    before, phase = att._skip_list.clone(), att._phase
+    att(q3.repeat(2, 1, 1, 1), kshort.repeat(2, 1, 1, 1), kshort.repeat(2, 1, 1, 1))
+    assert att._skip_list.shape[1] == 2 and att._phase == 1 - phase
+    assert torch.equal(att._skip_list[:, :1], before) and bool((att._skip_list[:, 1, :, :, :3] == torch.tensor([2, 3, 0])).all())
     with pytest.raises(AssertionError):
         att(torch.zeros(3, 300, 3, 128, dtype=torch.bfloat16), kshort.repeat(3, 1, 1, 1), kshort.repeat(3, 1, 1, 1))
 
@@ -274,7 +282,7 @@ def test_head_dim_is_served_by_the_next_instantiated_size(monkeypatch):
     assert [kernel_head_dim(d, 1) for d in (16, 64, 96, 128)] == [128] * 4
     assert kernel_head_dim(264, 2) == 264 and kernel_head_dim(192, 1) == 192 and kernel_head_dim(100, 2) == 100    # left to the library's typed error
     assert get_tile_sizes(96, 2) == (256, 64) and get_tile_sizes(80, 2) == (256, 64)
-    assert get_tile_sizes(192, 2) == get_tile_sizes(256, 2) == get_tile_sizes(64, 2) == (128, 64)
+    assert get_tile_sizes(192, 2) == get_tile_sizes(256, 2) == (128, 64) and get_tile_sizes(64, 2) == get_tile_sizes(40, 2) == (256, 64)
     monkeypatch.setenv("LA_FWD_KERNEL", "v2")
     assert [kernel_head_dim(d, 2) for d in (64, 96, 128, 192, 256)] == [64, 128, 128, 256, 256]
-    assert get_tile_sizes(96, 2) == (128, 64) and get_tile_sizes(128, 1) == (256, 64)
+    assert get_tile_sizes(96, 2) == get_tile_sizes(64, 2) == (128, 64) and get_tile_sizes(128, 1) == (256, 64)
