@@ -158,8 +158,13 @@ typedef struct la_fwd_args {
      * Both given: q is (total_q, H, D), k/v (total_k, Hk, D), o (total_q, H, D) — the *_batch_stride fields are ignored —
      * cu_seqlens_* are DEVICE int32[batch + 1] prefix sums (sequence b = rows [cu[b], cu[b+1])), seqlen_q / seqlen_k are the
      * MAXIMUM sequence lengths (they size the grid; longer sequences are truncated to them), and lse is (H, total_q):
-     * lse[h * total_q + row]. Sequences with no keys get o = 0, lse = +inf. Dense only: read_list must be NULL (the
-     * reference's varlen entry point has no skip lists either); bf16 only. One launch for the whole batch, no host sync. */
+     * lse[h * total_q + row]. Sequences with no keys get o = 0, lse = +inf. bf16 and fp16 (fp8: LA_ERR_UNSUPPORTED).
+     * One launch for the whole batch, no host sync.
+     * Skip lists with cu_seqlens (round 3; the reference's varlen entry point has none): read_list / write_list / a 4-D
+     * must_do_list are [>= batch, H, ceil(seqlen_q / block_m), ceil(seqlen_k / block_n) + 1] - the geometry of the MAXIMA - and
+     * row (b, h, m) describes q-tile m of sequence b over that sequence's own k-tiles (tile indices relative to the sequence).
+     * Rows of q-tiles past a sequence's end, and of sequences without keys, are neither read nor written. Served by the
+     * hand-scheduled kernels at head_dim <= 128: with LA_FLAG_KERNEL_128ROW or a larger head_dim it is LA_ERR_UNSUPPORTED. */
     const int32_t* cu_seqlens_q;
     const int32_t* cu_seqlens_k;
     int64_t        total_q;      /* rows of q / o (= cu_seqlens_q[batch]); the head stride of lse */

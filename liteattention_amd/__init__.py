@@ -20,12 +20,12 @@ if not _BUILDING:
                                        skip_list_stats)
     from .lite_attention import LiteAttention, SeqParallelLiteAttention  # noqa: E402
     from .compat import (blockmask_to_skip_lists, fa2_flash_attn_func, flash_attn_varlen_func,  # noqa: E402
-                         flash_blocksparse_attn_func)
+                         flash_blocksparse_attn_func, flash_blocksparse_attn_qkvpacked_func)
     from .calibration import calibrate_threshold  # noqa: E402
     from .parallel import (HeadShardedLiteAttention, RingSeqParallelLiteAttention,  # noqa: E402
                            UlyssesLiteAttention)
 
 __all__ = ["LiteAttention", "SeqParallelLiteAttention", "flash_attn_func", "flash_attn_combine",
            "get_tile_sizes", "skip_list_stats", "fa2_flash_attn_func", "flash_attn_varlen_func",
-           "flash_blocksparse_attn_func", "blockmask_to_skip_lists", "calibrate_threshold",
+           "flash_blocksparse_attn_func", "flash_blocksparse_attn_qkvpacked_func", "blockmask_to_skip_lists", "calibrate_threshold",
            "HeadShardedLiteAttention", "UlyssesLiteAttention", "RingSeqParallelLiteAttention", "__version__"]

@@ -19,7 +19,7 @@ from typing import List, Optional, Sequence
 
 import torch
 
-from .flash_attn_interface import flash_attn_func, get_tile_sizes
+from .flash_attn_interface import flash_attn_func, get_tile_sizes, mha_fwd
 
 
 def _to_list(x) -> List[int]:
@@ -200,27 +200,45 @@ def blockmask_to_rows(blockmask: torch.Tensor) -> List[List[int]]:
     return rows
 
 
+def blockmask_to_lists(blockmask: torch.Tensor, k_tiles_valid: Optional[torch.Tensor] = None, validate: bool = True) -> torch.Tensor:
+    """Vectorised ``blockmask_to_rows`` on whatever device holds the mask: bool ``[..., q_tiles, k_tiles]`` -> int32 list rows
+    ``[..., q_tiles, k_tiles + 1]`` (``[L, start0, end0, ...]``, descending ranges, both ends inclusive). No Python loop over rows
+    and no host round trip except the optional check that every row keeps a tile. ``k_tiles_valid`` (int tensor broadcastable to
+    the leading dims): tiles >= it are dropped first — a sequence shorter than the mask uses the mask's top-left corner."""
+    m = blockmask.to(torch.bool)
+    kt = m.shape[-1]
+    tile = torch.arange(kt - 1, -1, -1, device=m.device)                       # position j of the descending walk <-> tile kt-1-j
+    m = m.flip(-1)
+    if k_tiles_valid is not None:
+        m = m & (tile < k_tiles_valid.to(m.device)[..., None, None])
+    if validate and not bool(m.any(-1).all()):
+        raise ValueError("a q-tile keeps no k-tile: not representable as a skip list")
+    prev = torch.nn.functional.pad(m[..., :-1], (1, 0))
+    nxt = torch.nn.functional.pad(m[..., 1:], (0, 1))
+    start, end = m & ~prev, m & ~nxt                                           # first / last position of every kept run
+    ridx = start.cumsum(-1) - 1                                                # index of the run a position belongs to
+    width = kt + 2                                                             # one dump column for the positions that write nothing
+    lists = torch.zeros(*m.shape[:-1], width + 1, dtype=torch.int32, device=m.device)
+    tile_b = tile.to(torch.int32).expand(m.shape)
+    dump = torch.full_like(ridx, width)
+    lists.scatter_(-1, torch.where(start, 1 + 2 * ridx, dump), tile_b)
+    lists.scatter_(-1, torch.where(end, 2 + 2 * ridx, dump), tile_b)
+    lists[..., 0] = 2 * start.sum(-1)
+    return lists[..., : kt + 1].contiguous()
+
+
 def blockmask_to_skip_lists(blockmask: torch.Tensor, batch: int, heads: int, device) -> torch.Tensor:
     """blockmask [q_tiles, k_tiles] (shared by all batches/heads) or [batch, heads, q_tiles, k_tiles] ->
-    int32 skip lists ``[2, batch, heads, q_tiles, k_tiles + 1]`` (both ping-pong buffers identical)."""
+    int32 skip lists ``[2, batch, heads, q_tiles, k_tiles + 1]`` (both ping-pong buffers identical). Converted on ``device``
+    by tensor ops (``blockmask_to_lists``); a shared mask is converted once and broadcast."""
     if blockmask.dim() == 2:
-        blockmask = blockmask[None, None].expand(batch, heads, -1, -1)
-    B, H, Qt, Kt = blockmask.shape
-    if (B, H) != (batch, heads):
-        raise ValueError("blockmask batch/heads do not match")
-    lists = torch.zeros(B, H, Qt, Kt + 1, dtype=torch.int32)
-    cache = {}
-    for b in range(B):
-        for h in range(H):
-            key = blockmask[b, h].to(torch.bool).cpu().numpy().tobytes()
-            if key not in cache:
-                rows = blockmask_to_rows(blockmask[b, h])
-                t = torch.zeros(Qt, Kt + 1, dtype=torch.int32)
-                for m, r in enumerate(rows):
-                    t[m, : len(r)] = torch.tensor(r, dtype=torch.int32)
-                cache[key] = t
-            lists[b, h] = cache[key]
-    return torch.stack([lists, lists]).to(device).contiguous()
+        rows = blockmask_to_lists(blockmask.to(device))
+        lists = rows[None, None].expand(batch, heads, -1, -1)
+    else:
+        if tuple(blockmask.shape[:2]) != (batch, heads):
+            raise ValueError("blockmask batch/heads do not match")
+        lists = blockmask_to_lists(blockmask.to(device))
+    return torch.stack([lists, lists]).contiguous()
 
 
 def flash_blocksparse_attn_func(q, k, v, blockmask: torch.Tensor, softmax_scale=None, return_softmax_lse=False,
@@ -249,22 +267,8 @@ def convert_blockmask(blockmask: torch.Tensor, causal: bool = False) -> torch.Te
     return blockmask.to(torch.bool)
 
 
-def flash_blocksparse_attn_qkvpacked_func(qkv, cu_seqlens, blockmask, dropout_p, max_s, softmax_scale=None, causal=False,
-                                          return_attn_probs=False, convert_mask=True):
-    """The reference's signature (flash_blocksparse_attn_interface.py:185-200): qkv (total, 3, nheads, headdim) packed
-    sequences, cu_seqlens [B+1], blockmask [ceil(max_s/kBlockM), ceil(max_s/kBlockN)] over THIS kernel's tiles, shared by
-    every sequence and head (sequence b uses its top-left ceil(len_b/kBlockM) x ceil(len_b/kBlockN) corner). Returns
-    ``context`` (total, nheads, headdim) or ``(context, softmax_lse (nheads, total), None)``. One launch per sequence:
-    skip lists are per fixed-length problem (mainloop_fwd_sm90_tma_gmma_ws.hpp:63-69)."""
-    _reject(dropout_p=(dropout_p, 0.0), causal=(causal, False))
-    if qkv.dim() != 4 or qkv.shape[1] != 3:
-        raise RuntimeError("qkv must be (total_tokens, 3, nheads, headdim)")
-    cu = _to_list(cu_seqlens)
+def _blocksparse_packed_per_sequence(qkv, cu, mask, max_s, softmax_scale, return_attn_probs, bm, bn):
     H, D = qkv.shape[2], qkv.shape[3]
-    bm, bn = get_tile_sizes(D, qkv.element_size())
-    if tuple(blockmask.shape) != (-(-max_s // bm), -(-max_s // bn)):
-        raise ValueError(f"blockmask must be [{-(-max_s // bm)}, {-(-max_s // bn)}] for max_s={max_s} and tiles ({bm}, {bn})")
-    mask = convert_blockmask(blockmask, causal) if convert_mask else blockmask.to(torch.bool)
     out = torch.empty((qkv.shape[0], H, D), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((H, qkv.shape[0]), dtype=torch.float32, device=qkv.device) if return_attn_probs else None
     for b in range(len(cu) - 1):
@@ -281,4 +285,50 @@ def flash_blocksparse_attn_qkvpacked_func(qkv, cu_seqlens, blockmask, dropout_p,
             lse[:, t0:t1] = res[1][0]
         else:
             out[t0:t1] = res[0]
+    return (out, lse, None) if return_attn_probs else out
+
+
+def flash_blocksparse_attn_qkvpacked_func(qkv, cu_seqlens, blockmask, dropout_p, max_s, softmax_scale=None, causal=False,
+                                          return_attn_probs=False, convert_mask=True):
+    """The reference's signature (flash_blocksparse_attn_interface.py:185-200): qkv (total, 3, nheads, headdim) packed
+    sequences, cu_seqlens [B+1], blockmask [ceil(max_s/kBlockM), ceil(max_s/kBlockN)] over THIS kernel's tiles, shared by
+    every sequence and head (sequence b uses its top-left ceil(len_b/kBlockM) x ceil(len_b/kBlockN) corner). Returns
+    ``context`` (total, nheads, headdim) or ``(context, softmax_lse (nheads, total), None)``.
+
+    ONE launch for the whole packed batch (round 3; round 2 looped over the sequences after a ``.tolist()``): the mask is clipped
+    to every sequence's own k-tiles and turned into list rows on the device (``blockmask_to_lists``), and ``la_fwd`` takes the lists
+    together with ``cu_seqlens``. The only host round trip left is the check that no q-tile of a sequence lost all of its k-tiles
+    (the reference-style ValueError); device ``cu_seqlens`` are used as they are."""
+    _reject(dropout_p=(dropout_p, 0.0), causal=(causal, False))
+    if qkv.dim() != 4 or qkv.shape[1] != 3:
+        raise RuntimeError("qkv must be (total_tokens, 3, nheads, headdim)")
+    H, D = qkv.shape[2], qkv.shape[3]
+    bm, bn = get_tile_sizes(D, qkv.element_size())
+    qt, kt = -(-max_s // bm), -(-max_s // bn)
+    if tuple(blockmask.shape) != (qt, kt):
+        raise ValueError(f"blockmask must be [{qt}, {kt}] for max_s={max_s} and tiles ({bm}, {bn})")
+    mask = (convert_blockmask(blockmask, causal) if convert_mask else blockmask.to(torch.bool)).to(qkv.device)
+    from . import _cabi
+    if D > 128 or (_cabi.default_flags() & _cabi.LA_FLAG_KERNEL_128ROW):
+        # lists + cu_seqlens in one launch exist for the hand-scheduled kernels at head_dim <= 128 (la_api.hip); elsewhere: one
+        # launch per sequence after reading cu_seqlens on the host, as in round 2
+        return _blocksparse_packed_per_sequence(qkv, _to_list(cu_seqlens), mask, max_s, softmax_scale, return_attn_probs, bm, bn)
+    cu = cu_seqlens if torch.is_tensor(cu_seqlens) else torch.tensor(list(cu_seqlens), dtype=torch.int32)
+    cu = cu.to(device=qkv.device, dtype=torch.int32).contiguous()
+    B = cu.numel() - 1
+    lens = cu[1:] - cu[:-1]
+    if bool((lens > max_s).any()):
+        raise RuntimeError("a sequence is longer than max_s")
+    kt_b, qt_b = (lens + bn - 1) // bn, (lens + bm - 1) // bm
+    # rows of q-tiles past a sequence's end are never read: give them the full corner so that the "keeps a tile" check only
+    # speaks about real rows
+    live_row = torch.arange(qt, device=qkv.device)[None, :] < qt_b[:, None]                                   # [B, qt]
+    clipped = mask[None] | ~live_row[:, :, None]
+    rows = blockmask_to_lists(clipped, k_tiles_valid=torch.clamp(kt_b, min=1), validate=True)                 # [B, qt, kt + 1]
+    lists = rows[:, None].expand(B, H, qt, kt + 1).contiguous()
+    write = torch.empty_like(lists)
+    must_do = torch.tensor([2, 0, 0], dtype=torch.int32, device=qkv.device)
+    out, lse, *_ = mha_fwd(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens_q=cu, cu_seqlens_k=cu, max_seqlen_q=int(max_s),
+                           max_seqlen_k=int(max_s), softmax_scale=softmax_scale, attn_read_list=lists, attn_must_do_list=must_do,
+                           attn_write_list=write, thr=float("-inf"), _must_do_is_1d=True)
     return (out, lse, None) if return_attn_probs else out

@@ -50,7 +50,7 @@ const char* la_status_string(int status) {
         case LA_ERR_STRIDE: return "Input tensor must have contiguous last dimension and 16-byte aligned rows";
         case LA_ERR_TILE_MISMATCH: return "block_m/block_n do not match la_get_tile_sizes(): skip lists would be mis-indexed";
         case LA_ERR_LISTS: return "attn_read_list and attn_write_list must be given together";
-        case LA_ERR_UNSUPPORTED: return "feature outside the QK-Skip hot path (head_dim_v != head_dim, unknown flags, skip lists or fp8 with cu_seqlens)";
+        case LA_ERR_UNSUPPORTED: return "feature outside the QK-Skip hot path (head_dim_v != head_dim, unknown flags, fp8 with cu_seqlens, skip lists with cu_seqlens on the 128-row kernels)";
         case LA_ERR_LAUNCH: return "HIP kernel launch failed (see la_last_hip_error)";
         case LA_ERR_SEQLEN: return "seqlen_k too long: expanded skip list does not fit in LDS";
         case LA_ERR_WORKSPACE: return "fp8 needs a 16-byte aligned workspace of la_fwd_workspace_bytes() bytes";
@@ -126,7 +126,9 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     const bool varlen = a->cu_seqlens_q != nullptr || a->cu_seqlens_k != nullptr;
     if (varlen) {                                                                        // flash_api.cpp:736-760
         if (a->cu_seqlens_q == nullptr || a->cu_seqlens_k == nullptr) return LA_ERR_NULL_ARG;
-        if (a->read_list != nullptr || fp8) return LA_ERR_UNSUPPORTED;                    // dense bf16 only
+        if (fp8) return LA_ERR_UNSUPPORTED;                                               // needs a per-sequence V^T prepare pass
+        if (a->read_list != nullptr && ((a->flags & LA_FLAG_KERNEL_128ROW) || a->head_dim > 128))
+            return LA_ERR_UNSUPPORTED;                                                    // lists + cu_seqlens: the hand-scheduled kernels, head_dim <= 128
         if (a->total_q < 0 || a->q_tile_count != 0) return LA_ERR_SHAPE;
     }
     if (a->seqlen_k == 0) {

@@ -218,6 +218,12 @@ __device__ __forceinline__ void work_item(const FwdParams& p, int vid, int& bh, 
 // Counters: 8 x 64 bytes in the caller's workspace, zeroed on the launch stream. Every ticket of a queue goes to exactly
 // one caller (atomicAdd), and a workgroup leaves only after it has seen all eight queues empty: every item is taken.
 // ------------------------------------------------------------------------------------------------
+#ifndef LA_SCHED_G
+#define LA_SCHED_G 4          // heads whose chunks are interleaved in the ticket order (K/V live set = G heads); tools/sched_sweep.sh
+#endif
+#ifndef LA_SCHED_C
+#define LA_SCHED_C 32         // q-tiles per chunk of the one-workgroup-per-CU kernels (= workgroups co-resident on an XCD)
+#endif
 constexpr int kSchedQueues = 8;
 constexpr int kSchedCounterStride = 16;      // uints: one 64-byte line per counter
 
@@ -230,7 +236,7 @@ struct SchedGeom {
     __device__ int queue_tickets(int x) const { return x < nv ? ((nv - x + kSchedQueues - 1) / kSchedQueues) * C : 0; }
     // ticket t of queue x -> item (bh * cnt + q-tile offset), or -2 for a padding slot of a head's last chunk
     __device__ int item(int x, unsigned t) const {
-        constexpr int G = 4;
+        constexpr int G = LA_SCHED_G;
         const int J = x + kSchedQueues * static_cast<int>(t / C);      // virtual chunk
         const int grp = J / (G * nch);
         const int g = min(G, nbh - grp * G);                           // heads in this group (only the last can be short)
@@ -297,8 +303,11 @@ __device__ __forceinline__ int expand_read_list(const int* __restrict__ row, int
         const int r = base + lane;
         int start = 0, cnt = 0;
         if (r < n_ranges) {
-            start = min(max(row[1 + 2 * r], 0), k_tiles - 1);
-            const int end = min(max(row[2 + 2 * r], 0), k_tiles - 1);
+            // the row is k_tiles + 1 ints: a pair whose end would lie behind it (odd k_tiles with (k_tiles + 1) / 2 ranges; k_tiles = 1)
+            // reads as (0, 0) - the oracle's reader_load rule - except the first pair, whose start is always in the row
+            const bool in_row = 2 + 2 * r <= k_tiles;
+            start = (in_row || r == 0) ? min(max(row[1 + 2 * r], 0), k_tiles - 1) : 0;
+            const int end = in_row ? min(max(row[2 + 2 * r], 0), k_tiles - 1) : 0;
             cnt = max(start - end + 1, 0);
             if (r == 0) cnt = max(cnt, 1);        // the first tile of the first range is always walked (mainloop...:1614-1660)
         }

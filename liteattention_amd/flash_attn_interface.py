@@ -157,7 +157,7 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
         raise NotImplementedError("pack_gqa is compiled out (hopper/setup.py:53)")
     if cu_seqlens_q is not None or cu_seqlens_k is not None:
         return _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, q_descale, k_descale,
-                               v_descale, softmax_scale, attn_read_list, attn_write_list)
+                               v_descale, softmax_scale, attn_read_list, attn_write_list, attn_must_do_list, thr, _must_do_is_1d)
     if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
         raise RuntimeError("q, k, v must be 4D tensors (batch, seqlen, nheads, headdim)")
     if q.stride(-1) != 1 or k.stride(-1) != 1 or v.stride(-1) != 1:
@@ -297,14 +297,16 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
 
 
 def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, q_descale, k_descale, v_descale,
-                    softmax_scale, attn_read_list, attn_write_list):
+                    softmax_scale, attn_read_list, attn_write_list, attn_must_do_list=None, thr=-3.0, _must_do_is_1d=False):
     """Packed variable-length batches (flash_api.cpp:672-674, 736-760): q (total_q, H, D), k/v (total_k, Hk, D), cu_seqlens_*
-    int32 [B+1] on the device, max_seqlen_* size the grid. ONE launch, no host sync. Dense bf16 / fp16 only. lse is (H, total_q)."""
+    int32 [B+1] on the device, max_seqlen_* size the grid. ONE launch, no host sync. bf16 / fp16 only. lse is (H, total_q).
+    Skip lists (extension; the reference's varlen entry point has none, hopper/_internal/flash_attn_interface.py:638-682):
+    ``[>= B, H, ceil(max_seqlen_q / kBlockM), ceil(max_seqlen_k / kBlockN) + 1]``, row (b, h, m) describing q-tile m of sequence b
+    over THAT sequence's k-tiles - what the static block-sparse adapter needs to run a packed batch in one launch."""
     if cu_seqlens_q is None or cu_seqlens_k is None:
         raise RuntimeError("cu_seqlens_q and cu_seqlens_k must be given together")
-    if attn_read_list is not None or attn_write_list is not None:
-        raise NotImplementedError("skip lists with cu_seqlens: the reference's varlen entry point has none either "
-                                  "(hopper/_internal/flash_attn_interface.py:638-682)")
+    if (attn_read_list is None) != (attn_write_list is None):
+        raise RuntimeError("attn_read_list and attn_write_list must be given together")
     if q.dtype not in (torch.bfloat16, torch.float16) or q_descale is not None or k_descale is not None or v_descale is not None:
         raise NotImplementedError("varlen is built for bf16 and fp16 (fp8 needs a per-sequence V^T prepare pass)")
     if k.dtype != q.dtype or v.dtype != q.dtype:
@@ -337,7 +339,7 @@ def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
             raise RuntimeError("out must have the input dtype, shape (total_q, nheads, headdim) and a contiguous last dimension")
         pad = lambda t: torch.nn.functional.pad(t, (0, D_kernel - D))                                          # noqa: E731
         res = _mha_fwd_varlen(pad(q), pad(k), pad(v), None, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, None,
-                              None, None, softmax_scale, None, None)
+                              None, None, softmax_scale, attn_read_list, attn_write_list, attn_must_do_list, thr, _must_do_is_1d)
         if out is None:
             out = torch.empty((Tq, H, D), dtype=q.dtype, device=q.device)           # contiguous (total_q, H, D), as the reference's
         out.copy_(res[0][..., :D])
@@ -355,6 +357,25 @@ def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
     a = _cabi.LaFwdArgs()
     a.struct_size = ctypes.sizeof(_cabi.LaFwdArgs)
     a.dtype = _cabi.LA_DTYPE_FP16 if q.dtype == torch.float16 else _cabi.LA_DTYPE_BF16
+    workspace = None
+    if attn_read_list is not None:
+        q_tiles, k_tiles = -(-int(max_seqlen_q) // block_m), -(-max(int(max_seqlen_k), 0) // block_n)
+        for name, t in (("attn_read_list", attn_read_list), ("attn_write_list", attn_write_list),
+                        ("attn_must_do_list", None if _must_do_is_1d else attn_must_do_list)):
+            if t is None:
+                continue
+            _check_list(t, name, q)
+            if t.shape[0] < B or tuple(t.shape[1:]) != (H, q_tiles, k_tiles + 1):
+                raise RuntimeError(f"{name} must have shape [>=batch, heads, q_blocks, k_blocks + 1] = [>={B}, {H}, {q_tiles}, "
+                                   f"{k_tiles + 1}] for max_seqlen ({max_seqlen_q}, {max_seqlen_k}) and tile sizes ({block_m}, {block_n}); "
+                                   f"got {tuple(t.shape)}")
+        if _must_do_is_1d and attn_must_do_list is not None and (
+                attn_must_do_list.dtype != torch.int32 or attn_must_do_list.dim() != 1 or attn_must_do_list.numel() < 3):
+            raise RuntimeError("1-D attn_must_do_list must be a contiguous int32 vector [len, start, end, ...]")
+        a.read_list, a.write_list = attn_read_list.data_ptr(), attn_write_list.data_ptr()
+        a.must_do_list = None if attn_must_do_list is None else attn_must_do_list.data_ptr()
+        a.must_do_is_1d = 1 if _must_do_is_1d else 0
+        a.thr = float(thr)
     a.q, a.k, a.v, a.o, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), softmax_lse.data_ptr()
     a.q_row_stride, a.q_head_stride = q.stride(0), q.stride(1)
     a.k_row_stride, a.k_head_stride = k.stride(0), k.stride(1)
@@ -364,8 +385,15 @@ def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
     a.num_heads, a.num_heads_k, a.head_dim, a.head_dim_v = H, Hk, D, D
     a.softmax_scale = float(softmax_scale)
     a.block_m, a.block_n = block_m, block_n
-    a.flags = flags & (_cabi.LA_FLAG_KERNEL_128ROW | _cabi.LA_FLAG_EXACT_RESCALE)
+    a.flags = flags & (_cabi.LA_FLAG_KERNEL_128ROW | _cabi.LA_FLAG_EXACT_RESCALE | _cabi.LA_FLAG_STATIC_SCHED)
     a.cu_seqlens_q, a.cu_seqlens_k, a.total_q = cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), Tq
+    if attn_read_list is not None:                # ticket counters of the dynamic work distribution (as in the fixed-length path)
+        need = _cabi.load().la_fwd_workspace_bytes(ctypes.byref(a))
+        if need < 0:
+            raise RuntimeError(f"lite_attention::fwd (varlen): {_cabi.status_string(int(need))}")
+        if need > 0:
+            workspace = torch.empty(int(need), dtype=torch.uint8, device=q.device)
+            a.workspace, a.workspace_bytes = workspace.data_ptr(), int(need)
     with torch.cuda.device(q.device):
         rc = _cabi.load().la_fwd(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream))
     if rc != _cabi.LA_OK:

@@ -162,7 +162,7 @@ def test_kernel_selection_is_an_argument_not_process_state():
 
 
 def test_varlen_argument_validation():
-    """cu_seqlens (ABI 4): both or neither; dense bf16 only; no q-tile window. All rejected before any HIP call."""
+    """cu_seqlens (ABI 4): both or neither; skip lists only where built; no q-tile window. All rejected before any HIP call."""
     lib = _cabi.load()
     a = _cabi.LaFwdArgs()
     a.struct_size = ctypes.sizeof(_cabi.LaFwdArgs)
@@ -175,8 +175,19 @@ def test_varlen_argument_validation():
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_NULL_ARG            # cu_seqlens_k missing
     a.cu_seqlens_k = 0x5000
     a.total_q = 889
-    a.read_list, a.write_list = 0x2000, 0x3000
-    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_UNSUPPORTED         # no skip lists with varlen
+    a.read_list, a.write_list = 0x2000, 0x3000                                    # skip lists with varlen: head_dim <= 128 on the
+    a.flags = _cabi.LA_FLAG_KERNEL_128ROW                                         # hand-scheduled kernels only (round 3)
+    a.block_m = 128
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_UNSUPPORTED
+    a.flags, a.block_m = 0, 128
+    a.head_dim = a.head_dim_v = 256
+    a.q_row_stride = a.k_row_stride = a.v_row_stride = a.o_row_stride = 4 * 256
+    a.q_head_stride = a.k_head_stride = a.v_head_stride = a.o_head_stride = 256
+    assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_UNSUPPORTED
+    a.head_dim = a.head_dim_v = 128
+    a.block_m = 256
+    a.q_row_stride = a.k_row_stride = a.v_row_stride = a.o_row_stride = 4 * 128
+    a.q_head_stride = a.k_head_stride = a.v_head_stride = a.o_head_stride = 128
     a.read_list = a.write_list = None
     a.q_tile_count = 1
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_SHAPE               # no q-tile windows with varlen

@@ -45,11 +45,20 @@ else:
     v0 = torch.randn(S, H, D, device=dev, generator=g)
     base = (q0[None], k0[None], v0[None])
     att.threshold = a.real
+    cache = f"/tmp/la_real_lists_{a.real}_{a.steps}.pt"      # the lists do not depend on the library variant (votes are bit-exact): reuse
     for t in range(a.steps):
+        if os.path.exists(cache) and t < a.steps - 1:
+            continue
         s_ = 0.5 + (0.05 - 0.5) * t / max(1, a.steps - 1)
         gt = torch.Generator(device=dev).manual_seed(10 ** 6 + t)
         q, k, v = [((1 - s_ * s_) ** 0.5 * x + s_ * torch.randn(x.shape, device=dev, generator=gt)).to(torch.bfloat16) for x in base]
-        att(q, k, v)
+        if os.path.exists(cache):
+            att._get_read_write_lists(q, k)
+            att._skip_list[att._phase].copy_(torch.load(cache).to(dev))
+        else:
+            att(q, k, v)
+    if not os.path.exists(cache):
+        torch.save(att._skip_list[att._phase].cpu(), cache)
     att.threshold = float("-inf")                    # freeze the list reached after `steps` steps
     att._skip_list[1 - att._phase].copy_(att._skip_list[att._phase])
 sparsity = att.get_skip_fraction(batch=1)
