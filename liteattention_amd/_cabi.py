@@ -62,13 +62,15 @@ LA_FLAG_STATIC_SCHED = 2
 LA_FLAG_KERNEL_128ROW = 4
 LA_FLAG_EXACT_RESCALE = 8
 LA_FLAG_EXACT_ROWSUM = 16
+LA_FLAG_EXACT_EXP = 32
 
 
 def default_flags() -> int:
     """A/B switches of the HOST layer (the C library reads no environment): they only choose the default ``la_fwd_args.flags``.
     LA_FWD_KERNEL=v2 -> the 128-row bf16 head_dim-128 kernel (lists then use 128-row q-tiles); LA_SCHED=static -> one
     workgroup per item instead of the ticket queues; LA_RESCALE_TAU=0 -> O rescaled on every growth of a row maximum; LA_FP8_ROWSUM=exact -> fp8 row sums of the un-rounded
-    P on the vector unit (LA_FLAG_EXACT_ROWSUM: fp32-exact LSE, 4-5 % slower)."""
+    P on the vector unit (LA_FLAG_EXACT_ROWSUM: fp32-exact LSE); LA_FP8_EXP=exact -> fp8 P by v_exp_f32 + the hardware e4m3 rounding instead of
+    the log-linear byte encoding (LA_FLAG_EXACT_EXP; implied by LA_FP8_ROWSUM=exact)."""
     f = 0
     if os.environ.get("LA_FWD_KERNEL", "").startswith("v2"):
         f |= LA_FLAG_KERNEL_128ROW
@@ -80,6 +82,8 @@ def default_flags() -> int:
         f |= LA_FLAG_EXACT_RESCALE
     if os.environ.get("LA_FP8_ROWSUM", "").startswith("exact"):
         f |= LA_FLAG_EXACT_ROWSUM
+    if os.environ.get("LA_FP8_EXP", "").startswith("exact"):
+        f |= LA_FLAG_EXACT_EXP
     return f
 
 

@@ -25,7 +25,8 @@ X64_F16_INC = "la_fwd_x64_f16_body.inc"                        # the same genera
 X64_BODIES = [(128, "bf16", X64_INC), (128, "f16", X64_F16_INC)] + [
     (d, t, f"la_fwd_x64_d{d}_{'f16_' if t == 'f16' else ''}body.inc") for d in (64, 96, 192, 256) for t in ("bf16", "f16")]   # LA_X64_D / LA_X64_DTYPE
 X64F8_GEN, X64F8_INC = "gen_fwd_x64_fp8.py", "la_fwd_x64_fp8_body.inc"     # fp8: the same structure on the block-scaled MFMA
-X64F8_LVALU_INC = "la_fwd_x64_fp8_lvalu_body.inc"                           # LA_X64F8_OPT=lvalu: fp32 row sums on the VALU (LA_FLAG_EXACT_ROWSUM)
+X64F8_EXP_INC = "la_fwd_x64_fp8_exp_body.inc"                               # LA_X64F8_OPT=exp: P = v_exp_f32 rounded by the hardware convert (LA_FLAG_EXACT_EXP)
+X64F8_LVALU_INC = "la_fwd_x64_fp8_lvalu_body.inc"                           # LA_X64F8_OPT=lvalu: that, and fp32 row sums on the VALU (LA_FLAG_EXACT_ROWSUM)
 
 
 def _hipcc() -> str:
@@ -62,9 +63,10 @@ def _compile(lib_path: str, defines, verbose: bool) -> str:
             env["LA_X64_OPT"] = os.environ.get(f"LA_X64_D{head_dim}_OPT", "")
         subprocess.run([sys.executable, os.path.join(CSRC, X64_GEN), os.path.join(CSRC, inc)], check=True, stdout=quiet, env=env)
     subprocess.run([sys.executable, os.path.join(CSRC, X64F8_GEN), os.path.join(CSRC, X64F8_INC)], check=True, stdout=quiet)
-    f8_opt = ",".join(x for x in (os.environ.get("LA_X64F8_OPT", ""), "lvalu") if x)
-    subprocess.run([sys.executable, os.path.join(CSRC, X64F8_GEN), os.path.join(CSRC, X64F8_LVALU_INC)], check=True, stdout=quiet,
-                   env=dict(os.environ, LA_X64F8_OPT=f8_opt))
+    for variant, inc in (("exp", X64F8_EXP_INC), ("lvalu", X64F8_LVALU_INC)):       # LA_X64F8_<VARIANT>_OPT tunes that body alone
+        f8_opt = ",".join(x for x in (os.environ.get(f"LA_X64F8_{variant.upper()}_OPT", ""), variant) if x)
+        subprocess.run([sys.executable, os.path.join(CSRC, X64F8_GEN), os.path.join(CSRC, inc)], check=True, stdout=quiet,
+                       env=dict(os.environ, LA_X64F8_OPT=f8_opt))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-I", INCLUDE, "-I", CSRC]
     cmd += [f"-D{d}" for d in defines]

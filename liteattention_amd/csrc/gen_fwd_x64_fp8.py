@@ -40,7 +40,7 @@ def opt_val(key, default):
     return default
 
 
-XPAIRS = int(opt_val("x", "4"))          # pair-groups (of 16) done in phase 2. EVEN: two pair-groups share one packed-e4m3 destination register
+XPAIRS = int(opt_val("x", "8" if ("exp" not in OPT and "lvalu" not in OPT) else "4"))          # pair-groups (of 16) done in phase 2. EVEN: two pair-groups share one packed-e4m3 destination register
                                           # (lo / hi half by op_sel); an odd split leaves a half-written register across the phase boundary
                                           # (measured x = 2 / 4: 2078-2101 TFLOP/s at 42 %, x = 3 / 5 / 6: 2048-2065)
 PK = "pk" in OPT                          # A/B: packed fp32 FMA / add in the softmax (v_pk_fma_f32, v_pk_add_f32). MEASURED ANTI-LEVER here too:
@@ -55,9 +55,39 @@ NG = 8                                    # QK MFMAs (gaps) of phase 1
 # numerics under the lazy rescale: the weights sum to 1 exactly, so the e4m3 rounding of a row's dominant P (which is not 2^k
 # once m_ref lags m_true) cancels instead of scaling the whole row by up to 2^-4. The LSE inherits the rounding of P~.
 LMFMA = "lvalu" not in OPT
+# P itself. "exp" (rounds 1-2; LA_FLAG_EXACT_EXP): P = v_exp_f32(S c - m_ref c + OFF), rounded to e4m3 by v_cvt_pk_fp8_f32 - per score one
+# FMA, one transcendental (2 issue slots) and half a convert (which also costs 2 slots: tools/valu_microbench.py) = 4 slots.
+# Default (round 3) "lin": the e4m3 BYTE is computed directly, b = sat_u8(rne(8 y + 56 - 8 delta)), y = S c - m_ref c + OFF - one FMA
+# and one v_cvt_pk_u8_f32 (RNE, saturating, NaN / -inf -> 0: probed on the hardware), 2 slots per score, no transcendental.
+# An e4m3 byte b = 8 E + M decodes to 2^(E - 7) (1 + M / 8): reading b / 8 - 7 as a base-2 logarithm is the classic
+# linear-mantissa exponential (1 + f for 2^f, at most +6.1 %, cancelled on average by delta = 0.0575 = log2 of its mean ratio), and
+# the byte grid is then a LOG-uniform quantisation of P (step 2^(1/8)) instead of e4m3's round-to-nearest (relative step 1/8 ..
+# 1/16). Per element the error is within [-7.9 %, +6.5 %] against +-6.25 % for the hardware rounding; measured on the reference's
+# fp8 goldens the output error is 1.0-2.2 x that of the exact form and stays under the reference's own rule.
+# What it costs in range: bytes 1..7 (e4m3 subnormals) are reached for y in (-7, -6] only, so P below 2^-7 is dropped where the
+# hardware rounding keeps P down to 2^-10. Needs the row sums of the ENCODED P (LMFMA): no fp32 P exists in this form.
+LIN = LMFMA and "exp" not in OPT
+LIN_DELTA = 0.0575
 NG2 = 10 if LMFMA else 8                  # MFMAs (gaps) of phase 2: PV + the two row-sum MFMAs
-TAU = 2.0                                 # lazy-rescale slack in log2 units (must match the shell: param[22] = TAU / c)
-P_OFFSET = 8.0 - TAU
+# Lazy-rescale slack TAU (log2 units) and the offset of P. P <= 2^(P_OFFSET + TAU) must stay finite in e4m3 (max 448 = 2^8.8):
+# exp / lvalu: the reference's 2^8 ceiling (Max_offset = 8, softmax.h:85-87), TAU = 2. lin: ceiling 2^8.75 (byte 126; byte 127 is NaN)
+# and TAU = 1 - the byte grid ends at byte 1 = 2^-9 <-> y = -6.94, so a key is kept while its weight is above 2^-(P_OFFSET + 6.94)
+# of the row's reference maximum: 2^-14.7 here (hardware rounding at offset 6: 2^-16); every octave of TAU is an octave of tail.
+# The shell takes both numbers from the generated la_fwd_x64_fp8*_consts.h (param[22] = TAU / c, param[31] = ln 2^-P_OFFSET).
+# mx (default with lin): P is BLOCK-SCALED, the MX way, on the scale operand the matrix instruction has anyway. The E8M0 byte a lane
+# supplies with the B operand multiplies one 32-element block of its column: registers 0-3 of lanes n and n + 32 take lane n's byte,
+# registers 4-7 take lane n + 32's (probed: tools/debug/probe_mfma_scale2.hip) - here the two 32-key halves of the tile, for one
+# query row. Both get the same exponent, that of the row's largest P in THIS TILE: t = floor((m_loc - m_ref) c) from the row maximum
+# the skip vote needs anyway, P is encoded relative to 2^t (the tile's largest P lands in bytes 112..120 = [2^7, 2^8)) and the MFMA
+# multiplies by 2^t. What it buys: (1) the byte grid's 15 octaves hang below the TILE's maximum, not the row's - a diffuse tail far
+# below the row maximum keeps full relative precision (the plain byte grid drops keys below 2^-14.7 of the reference maximum, the
+# reference's e4m3 rounding below 2^-17; at S = 75 600 such tails carry real mass: DESIGN.md 3.4); (2) P cannot overflow whatever
+# the row maximum does, so the lazy rescale only guards the fp32 accumulators: TAU = 32, i.e. never on real data. Cost: 8 vector
+# instructions per step (exponent, scale byte and encoding offset for both q-blocks).
+MX = LIN and "nomx" not in OPT
+TAU = float(opt_val("tau", "32" if MX else ("1" if LIN else "2")))
+P_CEIL = 8.75 if LIN else 8.0
+P_OFFSET = 7.0 if MX else P_CEIL - TAU
 DMA_GAPS = [int(x) for x in opt_val("dmagaps", "0,1,1,2,3,3").replace(".", ",").split(",")]   # m0K,K0,K1,m0V,V0,V1 (phase 1 gaps; an M0 write is never adjacent to its first use)
 
 
@@ -97,6 +127,9 @@ NEGINF, HH4, LANE = 212, 213, 214
 QROW = [216, 217]
 MTHR = [220, 221]
 TABV = 222                                # LDS address of tab[i + 2], the tile-address table entry step i reads from
+# mx: per row -m_ref c + 127; per row and tile the offset of the byte encoding; the tile's E8M0 scale byte per S set
+NMR, NMSB, SCB = [178, 179], [186, 187], [[188, 189], [215, 218]]      # (L0 / L1 are unused with the matrix-pipe row sums)
+MXT = [T[10], T[11]]
 
 # ---------------------------------------------------------------- SGPR map (s32-s34 are ABI-reserved: unused)
 S_KBASE, S_VBASE, S_QBASE = 36, 38, 40
@@ -104,6 +137,7 @@ S_TB, S_VB, S_EXEC, S_T64, S_T64B = 42, 44, 46, 48, 50
 (S_KRS, S_VRS, S_LASTROW, S_NTILES, S_C, S_THR, S_TAILVALID, S_FIRSTLAST, S_TAB, S_DOFLAGS, S_WAVE, S_I, S_DOMASK,
  S_FREE0, S_FREE1, S_FREE2, S_LDS, S_T0, S_T1, S_T2, S_T3, S_NM1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_PARAM, S_DOWORD, S_NEGC,
  S_FREE3, S_DMAW, S_FREE4, S_TAU, S_RESC, S_FREE5) = range(52, 87)
+S_C8, S_NEGC8, S_M8 = S_FREE0, S_FREE1, S_FREE2   # lin: 8 c and -8 c; mx: -8.0
 S_FREE6, S_TB2, S_VB2, S_BIT = 87, 88, 90, 92     # second set of DMA bases (the loop is unrolled by two); the rotating vote bit
 TBS, VBS = [S_TB, S_TB2], [S_VB, S_VB2]
 
@@ -190,9 +224,29 @@ def mfma_qk(sset, kb, sx, qb):
 
 
 def mfma_pv(sset, db, qb):
+    sc = f"{v(VSC)}, {v(SCB[sset][qb])} op_sel_hi:[0,0,0]" if MX else SCALES      # mx: the lane's block scale on the B operand (P)
     if db == 4:      # row sums: ones (32 x 64) times P^T
-        return f"    {MFMA} {ar(LSUM(qb), 16)}, {vr(ONES, 8)}, {vr(S_(sset, qb, 0), 8)}, {ar(LSUM(qb), 16)}, {SCALES}"
-    return f"    {MFMA} {ar(O_(qb, db), 16)}, {vr(VF[db], 8)}, {vr(S_(sset, qb, 0), 8)}, {ar(O_(qb, db), 16)}, {SCALES}"
+        return f"    {MFMA} {ar(LSUM(qb), 16)}, {vr(ONES, 8)}, {vr(S_(sset, qb, 0), 8)}, {ar(LSUM(qb), 16)}, {sc}"
+    return f"    {MFMA} {ar(O_(qb, db), 16)}, {vr(VF[db], 8)}, {vr(S_(sset, qb, 0), 8)}, {ar(O_(qb, db), 16)}, {sc}"
+
+
+def mx_ops(sset, src):
+    """Exponent and encoding offset of the tile whose scores sit in S set `sset` (src = the rows' maxima over this tile, the same in
+    both half-waves): u = floor((m_loc - m_ref) c) + 127 -> E8M0 byte (the byte convert saturates: below 2^-127 the scale stops
+    following, harmless; a tile of -inf gives NaN offsets = byte 0 for every key), offset = NMS - 8 (u - 127) (NMS carries the + 1016)."""
+    o = []
+    for qb in (0, 1):
+        o.append(f"    v_fma_f32 {v(MXT[qb])}, {v(src[qb])}, {s(S_C)}, {v(NMR[qb])}")
+    for qb in (0, 1):
+        o.append(f"    v_floor_f32 {v(MXT[qb])}, {v(MXT[qb])}")
+    if "mxt0" in OPT:        # debug: every block exponent 0
+        for qb in (0, 1):
+            o.append(f"    v_mov_b32 {v(MXT[qb])}, 0x{float_bits(127.0):08x}")
+    for qb in (0, 1):
+        o.append(f"    v_cvt_pk_u8_f32 {v(SCB[sset][qb])}, {v(MXT[qb])}, 0, 0")
+    for qb in (0, 1):
+        o.append(f"    v_fma_f32 {v(NMSB[qb])}, {v(MXT[qb])}, {s(S_M8)}, {v(NMS[qb])}")
+    return o
 
 
 def softmax_parts(sset, p):
@@ -204,6 +258,16 @@ def softmax_parts(sset, p):
         r0 = S_(sset, qb, kb) + r
         r1 = r0 + 1
         dst = S_(sset, qb, 0) + 4 * kb + (r >> 2)         # 32 e4m3 bytes of a q-block = its first 8 registers
+        if LIN:
+            # in place: 8 y + 56 - 8 delta replaces the score, then one byte convert each into byte r & 3 of dst. dst is one of the
+            # q-block's first 8 registers, which hold the scores of pairs 0-3: pairs are processed in order, so the pair whose
+            # scores sit in dst (pair dst_index >> 1 <= p) has consumed them (its own first convert reads and writes dst at once)
+            nms = NMSB[qb] if MX else NMS[qb]
+            F.append([f"    v_fma_f32 {v(r0)}, {v(r0)}, {s(S_C8)}, {v(nms)}", f"    v_fma_f32 {v(r1)}, {v(r1)}, {s(S_C8)}, {v(nms)}"])
+            E.append([])
+            A.append([])
+            C.append([f"    v_cvt_pk_u8_f32 {v(dst)}, {v(r0)}, {r & 3}, {v(dst)}", f"    v_cvt_pk_u8_f32 {v(dst)}, {v(r1)}, {(r & 3) + 1}, {v(dst)}"])
+            continue
         hi = " op_sel:[0,0,1]" if (r >> 1) & 1 else ""
         ta, tb = T[8 + 2 * qb], T[9 + 2 * qb]
         if PK:
@@ -227,6 +291,13 @@ def softmax_stream(sset, groups):
     if not groups:
         return []
     parts = [softmax_parts(sset, p) for p in groups]
+    if LIN:          # FMAs of pair g + 1 between the FMAs and the converts of pair g: every convert is >= 4 instructions behind its FMA
+        o = parts[0][0][0] + parts[0][0][1]
+        for g in range(len(parts)):
+            if g + 1 < len(parts):
+                o += parts[g + 1][0][0] + parts[g + 1][0][1]
+            o += parts[g][3][0] + parts[g][3][1]
+        return o
     o = parts[0][0][0] + parts[0][0][1]
     n = len(parts)
     for g in range(n):
@@ -263,7 +334,7 @@ def row_max_ops(sset):
     return [x for pair in zip(*per) for x in pair]
 
 
-def stats_ops(rare_label, back_label, flush_label, flush_back, inval_label, inval_back):
+def stats_ops(rare_label, back_label, flush_label, flush_back, inval_label, inval_back, sset=0):
     """Half-wave max exchange, skip vote, true running max, lazy-rescale test: as gen_fwd_x64.py stats_ops (rotating vote bit in
     S_BIT, the step past the end of the walk recognised by i == n - 1, no position arithmetic)."""
     o = []
@@ -295,6 +366,8 @@ def stats_ops(rare_label, back_label, flush_label, flush_back, inval_label, inva
     a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")
     a(f"    s_cbranch_vccnz {rare_label}")
     o.append(back_label + ":")
+    if MX:
+        o += mx_ops(sset, MLOC)
     a(f"    s_lshl_b32 {s(S_BIT)}, {s(S_BIT)}, 1")                           # falls off the word (SCC = 0): flush it
     a(f"    s_cbranch_scc0 {flush_label}")
     o.append(flush_back + ":")
@@ -303,6 +376,13 @@ def stats_ops(rare_label, back_label, flush_label, flush_back, inval_label, inva
 
 def set_nms(qb):
     """-m_ref*c + P_OFFSET (the literal needs the VOP2 encoding: gfx9 VOP3 takes no literals)."""
+    if LIN:          # -8 m_ref c + (8 OFF + 56 - 8 delta): the byte of P = 2^OFF (a row's dominant key while m_ref = m_true) is exact
+        emit(f"v_mul_f32 {v(NMS[qb])}, {s(S_NEGC8)}, {v(MREF[qb])}")
+        emit(f"v_add_f32 {v(NMS[qb])}, 0x{float_bits(8.0 * P_OFFSET + 56.0 - 8.0 * LIN_DELTA + (1016.0 if MX else 0.0)):08x}, {v(NMS[qb])}")
+        if MX:       # -m_ref c + 127: the block exponent comes out biased like an E8M0 byte; NMS carries the matching + 8 * 127
+            emit(f"v_mul_f32 {v(NMR[qb])}, {s(S_NEGC)}, {v(MREF[qb])}")
+            emit(f"v_add_f32 {v(NMR[qb])}, 0x{float_bits(127.0):08x}, {v(NMR[qb])}")
+        return
     emit(f"v_mul_f32 {v(NMS[qb])}, {s(S_NEGC)}, {v(MREF[qb])}")
     emit(f"v_add_f32 {v(NMS[qb])}, 0x{float_bits(P_OFFSET):08x}, {v(NMS[qb])}")
 
@@ -489,7 +569,7 @@ def step(variant):
             mixed.append(nb.pop(0))
     vq += mixed
     inv, invback = new_label("inval"), new_label("inval_back")
-    vq += stats_ops(rare, back, fl, flback, inv, invback)
+    vq += stats_ops(rare, back, fl, flback, inv, invback, sset=nxt)
     deferred.append(lambda: inval_block(inv, invback))
     deferred.append(lambda: rare_rescale_block(rare, back))
     deferred.append(lambda: flush_block(fl, flback))
@@ -529,6 +609,12 @@ def prologue():
     for idx, sg in enumerate(plist):
         emit(f"v_readfirstlane_b32 {s(sg)}, {v(idx)}")
     emit("s_nop 4")
+    if LIN:
+        emit(f"v_mul_f32 {v(T[0])}, 8.0, {v(8)}")             # v8 / v21 still hold c / -c of the parameter block
+        emit(f"v_mul_f32 {v(T[1])}, 8.0, {v(21)}")
+        emit(f"v_readfirstlane_b32 {s(S_C8)}, {v(T[0])}")
+        emit(f"v_readfirstlane_b32 {s(S_NEGC8)}, {v(T[1])}")
+        emit(f"s_mov_b32 {s(S_M8)}, 0x{float_bits(-8.0):08x}")
     emit(f"s_sub_u32 {s(S_NM1)}, {s(S_NTILES)}, 1")
     emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, 11")          # 2 KiB of every 8 KiB tile per wave
     emit(f"s_add_u32 {s(S_DMAW)}, {s(S_DMAW)}, {s(S_LDS)}")
@@ -613,8 +699,9 @@ def prologue():
         emit(f"v_accvgpr_write_b32 a{r}, 0")
     for qb in (0, 1):
         emit(f"v_mov_b32 {v(MTRUE[qb])}, 0xff800000")
-        emit(f"v_mov_b32 {v(L0[qb])}, 0")
-        emit(f"v_mov_b32 {v(L1[qb])}, 0")
+        if not LMFMA:
+            emit(f"v_mov_b32 {v(L0[qb])}, 0")
+            emit(f"v_mov_b32 {v(L1[qb])}, 0")
         emit(f"v_mov_b32 {v(ALPHA[qb])}, 1.0")
 
     emit("; ---- tile addresses of positions 1..3 from the table; K(0) fragments -> AGPRs, S(0) = K(0) Q^T, then K(1) fragments")
@@ -673,6 +760,8 @@ def prologue():
     emit(f"s_mov_b32 {s(S_DOMASK)}, 1")                        # position 0 is never flagged; position 1 votes into bit 1
     emit(f"s_mov_b32 {s(S_BIT)}, 2")
     emit(f"s_mov_b32 {s(S_DOWORD)}, {s(S_DOFLAGS)}")
+    if MX:
+        out.extend(mx_ops(0, MTRUE))
     for op in softmax_stream(0, list(range(XPAIRS))):
         out.append(op)
     emit(("DRAIN",))
@@ -718,6 +807,10 @@ def main():
     lines = finalize(out)
     text = "\n".join(lines)
     path = sys.argv[1] if len(sys.argv) > 1 else "la_fwd_x64_fp8_body.inc"
+    mode = 2 if not LMFMA else (0 if LIN else 1)               # PMODE of the shell (la_fwd_kernel_x64_fp8.hip)
+    with open(path.replace("_body.inc", "_consts.h"), "w") as f:
+        f.write("// GENERATED by gen_fwd_x64_fp8.py together with the body of the same name — do not edit.\n")
+        f.write(f"#define LA_X64F8_TAU_{mode} {TAU!r}f\n#define LA_X64F8_OFFSET_{mode} {P_OFFSET!r}f\n")
     with open(path, "w") as f:
         f.write("// GENERATED by gen_fwd_x64_fp8.py — do not edit. Inline-asm body of la_fwd_fp8_d128_x64_kernel.\n")
         f.write('R"ASM(\n' + text + '\n)ASM"\n')

@@ -128,9 +128,9 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     windows compute). ``_static_sched`` sets LA_FLAG_STATIC_SCHED (per-item workgroups instead of persistent ones: a
     collective running beside the launch gets CUs as items retire); "after_first" sets it on every window but the first
     (no collective is in flight beside window 0). ``_flags``: extra ``LA_FLAG_*`` bits ORed into ``la_fwd_args.flags`` (tests / A/B:
-    LA_FLAG_EXACT_RESCALE, LA_FLAG_EXACT_ROWSUM); kernel-selection bits that change the tile geometry are not accepted here."""
-    if _flags & ~(_cabi.LA_FLAG_EXACT_RESCALE | _cabi.LA_FLAG_EXACT_ROWSUM):
-        raise ValueError("_flags accepts LA_FLAG_EXACT_RESCALE and LA_FLAG_EXACT_ROWSUM only")
+    LA_FLAG_EXACT_RESCALE, LA_FLAG_EXACT_ROWSUM, LA_FLAG_EXACT_EXP); kernel-selection bits that change the tile geometry are not accepted here."""
+    if _flags & ~(_cabi.LA_FLAG_EXACT_RESCALE | _cabi.LA_FLAG_EXACT_ROWSUM | _cabi.LA_FLAG_EXACT_EXP):
+        raise ValueError("_flags accepts LA_FLAG_EXACT_RESCALE, LA_FLAG_EXACT_ROWSUM and LA_FLAG_EXACT_EXP only")
     if not q.is_cuda:
         raise RuntimeError("lite_attention::fwd has no CPU implementation (HIP device tensors required)")
     if q.dtype not in (torch.bfloat16, torch.float16, torch.float8_e4m3fn):

@@ -139,8 +139,9 @@ def qkskip_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, block_m: in
             a.must_do_is_1d = 0
             a.must_do_list = _chk(must_do_list, "must_do_list")
     a.thr = thr
-    # "fp8": e4m3 P with the 2^8 offset (reference Max_offset); "f16": P rounded to fp16; True / False: bf16 / fp32 P
-    a.p_round = 2 if p_round == "fp8" else (3 if p_round == "f16" else int(p_round))
+    # "fp8": e4m3 P with the 2^8 offset (reference Max_offset); "f16": P rounded to fp16; True / False: bf16 / fp32 P;
+    # "fp8_lin": NOT a reference form - this build's default log-linear byte encoding of P (qkskip_oracle.c, p_round 4)
+    a.p_round = {"fp8": 2, "f16": 3, "fp8_lin": 4}.get(p_round, None) if isinstance(p_round, str) else int(p_round)
     keep = []
     for name, t in (("q_descale", q_descale), ("k_descale", k_descale), ("v_descale", v_descale)):
         if t is not None:
@@ -199,9 +200,10 @@ def attention_dense_ref_chunked(q, k, v, softmax_scale=None, chunk: int = 2048):
 
 
 def round_like_p(x: torch.Tensor, p_round) -> torch.Tensor:
-    """The C oracle's rounding of P applied to a float32 tensor (p_round as in qkskip_fwd: True/"bf16", "fp8", "f16")."""
+    """The C oracle's rounding of P applied to a float32 tensor (p_round as in qkskip_fwd: True/"bf16", "fp8", "f16";
+    "fp8_lin": x is taken as 8 y + 56 - 8 delta and mapped to the e4m3 value of the byte the kernel would store)."""
     y = x.detach().to(torch.float32).contiguous().clone()
-    mode = 2 if p_round == "fp8" else (3 if p_round == "f16" else int(bool(p_round)))
+    mode = {"fp8": 2, "f16": 3, "fp8_lin": 4}[p_round] if isinstance(p_round, str) else int(bool(p_round))
     lib = load_lib()
     lib.la_oracle_round.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]
     lib.la_oracle_round.restype = None

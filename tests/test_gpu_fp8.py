@@ -5,15 +5,16 @@ computed with P cast to e4m3 (hopper/tests/test_flash_attn.py:253,296): measured
 these cases (|O| <= ~2). Against the tiled oracle, which rounds P to e4m3 exactly like the kernel, the bound is
 0.05 * max|O| + 2e-2: v_exp_f32 and libm exp2f differ in the last fp32 bits, so a P that sits on an e4m3 rounding
 boundary can land one e4m3 step (6-12 % of that P) apart; with few keys one P carries O(1) of a row's weight.
-Still 3-5x tighter than the reference's own fp8 rule. LSE: `helpers.fp8_lse_tol()` - the default kernel sums the e4m3-rounded P
-(matrix pipe; round 3): <= ln(1 + 2^-4) + 1e-3 with a mean below 1e-2; LA_FLAG_EXACT_ROWSUM sums the un-rounded P: 1e-3 as for bf16.
-Every test of this module runs in both modes."""
+Still 3-5x tighter than the reference's own fp8 rule. The same bound holds for the default block-scaled log-linear byte encoding of P (round 3: per element
+within [-8.0 %, +6.5 %] of P against +-6.25 % for the hardware rounding, include/lite_attention_amd.h LA_FLAG_EXACT_EXP), checked against the oracle's
+restatement of that encoding (p_round="fp8_lin", itself pinned against the reference-generated outputs in tests/test_oracle.py). LSE: `helpers.fp8_lse_tol()`
+per form of P. Every test of this module runs in all three forms."""
 import math
 
 import pytest
 import torch
 
-from helpers import FP8_CASES, fp8_lse_tol, load_dense_case, ref_tolerance, structured_qkv
+from helpers import FP8_CASES, fp8_lse_tol, load_dense_case, ref_tolerance, structured_qkv, fp8_p_round
 
 pytestmark = pytest.mark.gpu
 F8 = torch.float8_e4m3fn
@@ -27,14 +28,17 @@ def _tiles():
 BM, BN = _tiles()
 
 
-@pytest.fixture(params=["rounded", "exact"], autouse=True)
-def rowsum_mode(request, monkeypatch):
-    """Both row-sum forms of the fp8 kernel: the default (sum of the e4m3-rounded P from the matrix pipe) and
-    LA_FP8_ROWSUM=exact -> LA_FLAG_EXACT_ROWSUM (fp32 sum of the un-rounded P on the vector unit)."""
+@pytest.fixture(params=["encoded", "exp", "exact"], autouse=True)
+def p_mode(request, monkeypatch):
+    """The three forms of P in the fp8 kernel: the default (log-linear byte encoding, row sums of the encoded P from the matrix pipe),
+    LA_FP8_EXP=exact -> LA_FLAG_EXACT_EXP (v_exp_f32 + hardware e4m3 rounding, row sums of the rounded P from the matrix pipe) and
+    LA_FP8_ROWSUM=exact -> LA_FLAG_EXACT_ROWSUM (that, with the fp32 sum of the un-rounded P on the vector unit: the reference's form)."""
+    monkeypatch.delenv("LA_FP8_ROWSUM", raising=False)
+    monkeypatch.delenv("LA_FP8_EXP", raising=False)
     if request.param == "exact":
         monkeypatch.setenv("LA_FP8_ROWSUM", "exact")
-    else:
-        monkeypatch.delenv("LA_FP8_ROWSUM", raising=False)
+    elif request.param == "exp":
+        monkeypatch.setenv("LA_FP8_EXP", "exact")
     return request.param
 
 
@@ -54,7 +58,7 @@ def test_fp8_dense_matches_reference_outputs(name):
     err = (out.float().cpu() - c["out_ref"]).abs().max().item()
     assert err <= ref_tolerance(c["out_ref"], c["pt_maxerr"]), (err, ref_tolerance(c["out_ref"], c["pt_maxerr"]))
     assert (lse.cpu() - c["lse_ref"]).abs().max().item() <= fp8_lse_tol()
-    o8, lse8, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=BM, block_n=BN, p_round="fp8",
+    o8, lse8, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=BM, block_n=BN, p_round=fp8_p_round(),
                                  q_descale=c["q_descale"], k_descale=c["k_descale"], v_descale=c["v_descale"])
     assert (out.float().cpu() - o8).abs().max().item() <= _tol(o8)
     assert (lse.cpu() - lse8).abs().max().item() <= fp8_lse_tol()
@@ -70,7 +74,7 @@ def test_fp8_ragged_shapes_no_descale(shape):
     k = torch.randn(B, Sk, H, 128, generator=g).to(F8)
     v = torch.randn(B, Sk, H, 128, generator=g).to(F8)
     out, lse = L.flash_attn_func(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
-    o8, lse8, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN, p_round="fp8")
+    o8, lse8, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN, p_round=fp8_p_round())
     assert (out.float().cpu() - o8).abs().max().item() <= _tol(o8)
     assert (lse.cpu() - lse8).abs().max().item() <= fp8_lse_tol()
 
@@ -95,7 +99,7 @@ def test_fp8_skip_lists_match_oracle_over_steps():
         rd, wr = att._skip_list[rd_idx].cpu(), att._skip_list[1 - rd_idx].cpu()
         wr_orc = torch.zeros_like(wr)
         o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN, read_list=rd, write_list=wr_orc,
-                                           must_do_list=md_row, thr=thr, margins=margins, p_round="fp8",
+                                           must_do_list=md_row, thr=thr, margins=margins, p_round=fp8_p_round(),
                                            q_descale=qd, k_descale=kd, v_descale=vd)
         assert (out.float().cpu() - o_ref).abs().max().item() <= _tol(o_ref)
         assert (lse.cpu() - lse_ref).abs().max().item() <= fp8_lse_tol()
@@ -135,7 +139,7 @@ def test_fp8_running_max_that_grows_late_in_the_walk(gain):
     q, k, v = [torch.randn(B, S, H, 128, generator=g) for _ in range(3)]
     k = k * torch.linspace(gain, 1.0, S).view(1, S, 1, 1)                  # early keys (walked last) up to `gain` x larger
     q, k, v = [x.to(F8) for x in (q, k, v)]
-    o8, lse8, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN, p_round="fp8")
+    o8, lse8, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN, p_round=fp8_p_round())
     out, lse = L.flash_attn_func(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
     assert bool(torch.isfinite(out.float()).all())
     assert (out.float().cpu() - o8).abs().max().item() <= _tol(o8)
@@ -149,7 +153,7 @@ def test_fp8_running_max_that_grows_late_in_the_walk(gain):
         rd, wr = att._skip_list[rd_idx].cpu(), att._skip_list[1 - rd_idx].cpu()
         wr_orc = torch.zeros_like(wr)
         o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN, read_list=rd, write_list=wr_orc, thr=-1.0,
-                                           margins=margins, p_round="fp8")
+                                           margins=margins, p_round=fp8_p_round())
         assert (out.float().cpu() - o_ref).abs().max().item() <= _tol(o_ref)
         assert (lse.cpu() - lse_ref).abs().max().item() <= fp8_lse_tol()
         bad, _ = _compare_lists(orc, rd, wr, wr_orc, margins, -1.0, B)

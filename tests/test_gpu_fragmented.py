@@ -26,7 +26,7 @@ import math
 import pytest
 import torch
 
-from helpers import fp8_lse_tol, fragmented_qkv
+from helpers import fp8_lse_tol, fragmented_qkv, fp8_p_round
 from test_gpu_parity import _compare_lists
 
 pytestmark = pytest.mark.gpu
@@ -39,7 +39,7 @@ def _setup(dtype, D):
     fp8 = dtype == "fp8"
     bm, bn = L.get_tile_sizes(D, 1 if fp8 else 2)
     if fp8:
-        cast, p_round = (lambda x: x.to(F8)), "fp8"
+        cast, p_round = (lambda x: x.to(F8)), fp8_p_round()
         tol = lambda o: 0.05 * o.abs().max().item() + 2e-2                            # noqa: E731
     elif dtype == "fp16":
         cast, p_round = (lambda x: x.half()), "f16"

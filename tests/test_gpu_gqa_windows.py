@@ -7,7 +7,7 @@ import math
 import pytest
 import torch
 
-from helpers import GQA_CASES, GQA_FP8_CASES, load_dense_case, ref_tolerance, structured_qkv, fp8_lse_tol
+from helpers import GQA_CASES, GQA_FP8_CASES, load_dense_case, ref_tolerance, structured_qkv, fp8_lse_tol, fp8_p_round
 from test_gpu_parity import _compare_lists, _oracle_tol
 
 pytestmark = pytest.mark.gpu
@@ -54,7 +54,7 @@ def test_gqa_fp8_matches_reference_outputs(name):
     assert err <= ref_tolerance(c["out_ref"], c["pt_maxerr"]), (err, ref_tolerance(c["out_ref"], c["pt_maxerr"]))
     assert (lse.cpu() - c["lse_ref"]).abs().max().item() <= fp8_lse_tol()
     bm8, bn8 = L.get_tile_sizes(128, 1)
-    o8, lse8, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=bm8, block_n=bn8, p_round="fp8",
+    o8, lse8, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=bm8, block_n=bn8, p_round=fp8_p_round(),
                                  q_descale=c["q_descale"], k_descale=c["k_descale"], v_descale=c["v_descale"])
     assert (out.float().cpu() - o8).abs().max().item() <= 0.05 * o8.abs().max().item() + 2e-2
     assert (lse.cpu() - lse8).abs().max().item() <= fp8_lse_tol()
@@ -169,7 +169,7 @@ def test_other_head_dims_run_on_the_next_instantiated_kernel(D, dtype):
         rd, wr = att._skip_list[rd_idx].cpu(), att._skip_list[1 - rd_idx].cpu()
         wr_orc = torch.zeros_like(wr)
         o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=rd, write_list=wr_orc, thr=-3.0,
-                                           margins=margins, p_round="fp8" if dtype == "fp8" else True)
+                                           margins=margins, p_round=fp8_p_round() if dtype == "fp8" else True)
         tol = (0.05 * o_ref.abs().max().item() + 2e-2) if dtype == "fp8" else _oracle_tol(o_ref)
         assert (out.float().cpu() - o_ref).abs().max().item() <= tol
         assert (lse.cpu() - lse_ref).abs().max().item() <= (fp8_lse_tol() if dtype == "fp8" else 1e-3)
@@ -210,7 +210,7 @@ def test_malformed_read_lists_are_memory_safe(dtype, D):
     out = L.flash_attn_func(qd, kd, vd, attn_read_list=rows[0].cuda(), attn_write_list=rows[1].cuda(), thr=-3.0)
     wr = torch.zeros_like(rows[1])
     o_ref, _, n_tiles = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=rows[0], write_list=wr, thr=-3.0,
-                                       p_round="fp8" if dtype == "fp8" else True)
+                                       p_round=fp8_p_round() if dtype == "fp8" else True)
     assert n_tiles == B * H * Qt
     tol = (0.05 * o_ref.abs().max().item() + 2e-2) if dtype == "fp8" else _oracle_tol(o_ref)
     assert (out.float().cpu() - o_ref).abs().max().item() <= tol

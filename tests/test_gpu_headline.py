@@ -30,13 +30,16 @@ def qkv():
     return [torch.randn(1, S, H, D, device="cuda", generator=g, dtype=torch.float32).to(torch.bfloat16) for _ in range(3)]
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp8", "fp8-exact-rowsum"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp8", "fp8-exact-exp", "fp8-exact-rowsum"])
 @pytest.mark.parametrize("sparsity", [0.42, 0.77, None])
 def test_headline_shape(qkv, dtype, sparsity, monkeypatch):
     import liteattention_amd as L
     exact_rowsum = dtype == "fp8-exact-rowsum"                            # LA_FLAG_EXACT_ROWSUM: the reference's fp32 row sums
     if exact_rowsum:
         monkeypatch.setenv("LA_FP8_ROWSUM", "exact")
+        dtype = "fp8"
+    if dtype == "fp8-exact-exp":                                          # LA_FLAG_EXACT_EXP: v_exp_f32 + hardware e4m3 rounding of P
+        monkeypatch.setenv("LA_FP8_EXP", "exact")
         dtype = "fp8"
     from liteattention_amd import selfcheck as sc
     from liteattention_amd.flash_attn_interface import mha_fwd

@@ -11,7 +11,7 @@ import sys
 import pytest
 import torch
 
-from helpers import structured_qkv, fp8_lse_tol
+from helpers import structured_qkv, fp8_lse_tol, fp8_p_round
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -167,7 +167,7 @@ def test_key_sequences_shorter_than_a_dma_piece(dtype, Sk, H, Hk):
     k = cast(torch.randn(2, Sk, Hk, 128, generator=g))
     v = cast(torch.randn(2, Sk, Hk, 128, generator=g))
     out, lse = L.flash_attn_func(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
-    o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, p_round="fp8" if dtype == "fp8" else True)
+    o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, p_round=fp8_p_round() if dtype == "fp8" else True)
     tol = (0.05 * o_ref.abs().max().item() + 2e-2) if dtype == "fp8" else _tol(o_ref)
     assert (out.float().cpu() - o_ref).abs().max().item() <= tol
     assert (lse.cpu() - lse_ref).abs().max().item() <= (fp8_lse_tol() if dtype == "fp8" else 1e-3)

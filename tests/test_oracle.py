@@ -193,6 +193,41 @@ def test_fp8_oracle_matches_reference_outputs(name):
     assert (o8 - o32).abs().max().item() > 1e-4          # the e4m3 rounding of P really is in the path
 
 
+@pytest.mark.parametrize("name", FP8_CASES + ["gqa_fp8_b1_s260_h4_hk2_d128"])
+def test_fp8_log_linear_encoding_of_p_stays_inside_the_reference_rule(name):
+    """The build's default fp8 form of P (NOT the reference's: include/lite_attention_amd.h LA_FLAG_EXACT_EXP; oracle p_round="fp8_lin")
+    against the reference-generated fp8 outputs: inside the reference's own rule with room to spare, at most 1.6 x the error of the
+    hardware rounding, LSE within the bound tests/helpers.py::fp8_lse_tol states for it."""
+    c = load_dense_case(name)
+    kw = dict(q_descale=c["q_descale"], k_descale=c["k_descale"], v_descale=c["v_descale"])
+    o8, lse8, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=256, block_n=64, p_round="fp8", **kw)
+    ol, lsel, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=256, block_n=64, p_round="fp8_lin", **kw)
+    e8 = (o8 - c["out_ref"]).abs().max().item()
+    el = (ol - c["out_ref"]).abs().max().item()
+    assert el <= 0.5 * ref_tolerance(c["out_ref"], c["pt_maxerr"]), (el, ref_tolerance(c["out_ref"], c["pt_maxerr"]))
+    assert el <= 1.6 * e8 + 1e-3, (el, e8)
+    rms8 = (o8 - c["out_ref"]).pow(2).mean().sqrt().item()
+    rmsl = (ol - c["out_ref"]).pow(2).mean().sqrt().item()
+    assert rmsl <= 1.6 * rms8 + 1e-4, (rmsl, rms8)                      # (the short flat-softmax GQA case is the 1.6; the others 1.2)
+    assert (lsel - c["lse_ref"]).abs().max().item() <= 0.084
+    assert (ol - o8).abs().max().item() > 1e-4                           # a different encoding really is in the path
+
+
+def test_fp8_log_linear_byte_decoding():
+    """p_round 4's byte -> value map is OCP e4m3fn (torch's view of the byte), round-to-nearest-even and saturating like v_cvt_pk_u8_f32
+    (probed on the hardware: tools/valu_microbench.py probe), NaN / -inf -> 0; and P~ / P over a fine scan of y stays in [0.920, 1.065]
+    with a mean within 5e-4 of 1 (delta = 0.0575 centres the linear-mantissa error)."""
+    y8 = torch.tensor([0.0, 0.49, 0.5, 0.51, 1.5, 2.5, 3.5, 119.5, 120.5, 103.54, 7.999, -0.6, -5.0, float("-inf"), float("nan")])
+    want_bytes = torch.tensor([0, 0, 0, 1, 2, 2, 4, 120, 120, 104, 8, 0, 0, 0, 0], dtype=torch.uint8)
+    assert torch.equal(orc.round_like_p(y8, "fp8_lin"), want_bytes.view(torch.float8_e4m3fn).float())
+    allb = torch.arange(0, 127, dtype=torch.uint8)
+    assert torch.equal(orc.round_like_p(allb.float(), "fp8_lin"), allb.view(torch.float8_e4m3fn).float())
+    y = torch.linspace(-3.0, 3.0, 600001, dtype=torch.float64)[:-1]
+    p = orc.round_like_p((8 * y + 56 - 8 * 0.0575).float(), "fp8_lin").double()
+    r = p / torch.exp2(y)
+    assert 0.920 <= r.min().item() and r.max().item() <= 1.065 and abs(r.mean().item() - 1.0) <= 5e-4
+
+
 def test_e4m3_rounding_matches_torch():
     """The oracle's e4m3 rounding equals torch's float8_e4m3fn cast on the range P can take ([0, 256])."""
     x = torch.cat([torch.linspace(0, 256, 20001), torch.logspace(-12, 8, 4001, base=2.0)])

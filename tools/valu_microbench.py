@@ -50,6 +50,8 @@ FP8_F16B = ["v_fma_f32 {d}, {s0}, s20, {s1}", "v_fma_f32 {d}, {s1}, s20, {s2}", 
             "v_exp_f16 {d}, {s0}", "v_exp_f16 {d}, {s1}", "v_pack_b32_f16 {d}, {s0}, {s1}",
             "v_dot2_f32_f16 {acc}, {s0}, v49, {acc}", "v_cvt_scalef32_pk_fp8_f16 {d}, {s0}, v50"]
 
+FP8_LIN = ["v_fma_f32 {d}, {s0}, s20, {s1}", "v_fma_f32 {d}, {s1}, s20, {s2}", "v_cvt_pk_u8_f32 {acc}, {s0}, 0, {acc}",
+           "v_cvt_pk_u8_f32 {acc}, {s1}, 1, {acc}"]
 FP8_PK = ["v_pk_fma_f32 {d2}, {p0}, s[22:23], {p1} op_sel_hi:[1,0,1]", "v_exp_f32 {d}, {s0}", "v_exp_f32 {d}, {s1}",
           "v_pk_add_f32 v[96:97], v[96:97], {p0}", "v_cvt_pk_fp8_f32 {d}, {s0}, {s1}"]
 FP8_PK_V = ["v_pk_fma_f32 {d2}, {p0}, v[52:53], {p1}", "v_exp_f32 {d}, {s0}", "v_exp_f32 {d}, {s1}",
@@ -138,6 +140,17 @@ CASES = [
     case("fp8 group f16+sdwa + 1 fp8 MFMA per 21", FP8_F16, MFMA_F8, 21),
     case("bf16 MFMA only (8 per 64 slots)", ["s_nop 0"], MFMA_BF16, 8),
     case("fp8 group as built + 1 bf16 MFMA per 7", FP8_NOW, MFMA_BF16, 7),
+    # round 3: the log-linear e4m3 encoding of P (gen_fwd_x64_fp8.py "lin"): one FMA + one byte convert per score, no v_exp_f32
+    case("v_cvt_pk_u8_f32", ["v_cvt_pk_u8_f32 {d}, {s0}, 1, {s1}"]),
+    case("v_cvt_pk_u8_f32 chained x4", ["v_cvt_pk_u8_f32 {acc}, {s0}, 0, {acc}", "v_cvt_pk_u8_f32 {acc}, {s1}, 1, {acc}",
+                                        "v_cvt_pk_u8_f32 {acc}, {s2}, 2, {acc}", "v_cvt_pk_u8_f32 {acc}, {s0}, 3, {acc}"]),
+    case("v_cvt_pk_u8_f32 + 1 fp8 MFMA per 16", ["v_cvt_pk_u8_f32 {d}, {s0}, 1, {s1}"], MFMA_F8, 16),
+    case("lin group (fma, fma, cvt_u8, cvt_u8)", FP8_LIN),
+    case("lin group + 1 fp8 MFMA per 16", FP8_LIN, MFMA_F8, 16),
+    case("lin group + 1 fp8 MFMA per 12", FP8_LIN, MFMA_F8, 12),
+    case("lin group + 1 fp8 MFMA per 10", FP8_LIN, MFMA_F8, 10),
+    case("lin group + 1 fp8 MFMA per 8", FP8_LIN, MFMA_F8, 8),
+    case("fp8 group as built + 1 fp8 MFMA per 16", FP8_NOW, MFMA_F8, 16),
 ]
 
 
@@ -173,6 +186,7 @@ __global__ void __launch_bounds__(256, 1) k{idx}(unsigned long long* out, int it
     return f'''// GENERATED by tools/valu_microbench.py — VALU issue-cost microbenchmark (gfx950, one wave per SIMD)
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 #define INIT {init}
 #define CLOB {clob}
@@ -208,11 +222,40 @@ static void run(const char* name, K kern, int n_instr) {{
     hipFree(d);
 }}
 
-int main() {{
+static void probe();
+int main(int argc, char** argv) {{
+    if (argc > 1 && argv[1][0] == 'p') {{ probe(); return 0; }}
+    const char* only = argc > 1 ? argv[1] : nullptr;
+#define run(name, k, n) if (!only || strstr(name, only)) run(name, k, n)
 {chr(10).join(calls)}
+#undef run
     return 0;
 }}
-'''
+''' + PROBE
+
+
+PROBE = r"""
+__global__ void probe_k(const float* x, unsigned* y, int n) {
+    int i = threadIdx.x;
+    if (i < n) {
+        unsigned r = 0xAABBCCDDu;
+        asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(r) : "v"(x[i]));
+        y[i] = r;
+    }
+}
+static void probe() {
+    const float xs[] = {0.f, 0.49f, 0.5f, 0.51f, 1.5f, 2.5f, 3.5f, 119.5f, 120.5f, 254.4f, 254.5f, 255.5f, 300.f, 1e9f, -0.4f, -0.6f, -5.f,
+                        -INFINITY, INFINITY, NAN, 103.54f, 7.999f};
+    const int n = sizeof(xs) / sizeof(xs[0]);
+    float* dx; unsigned* dy;
+    hipMalloc(&dx, sizeof(xs)); hipMalloc(&dy, n * 4);
+    hipMemcpy(dx, xs, sizeof(xs), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(probe_k, dim3(1), dim3(64), 0, 0, dx, dy, n);
+    unsigned ys[64];
+    hipMemcpy(ys, dy, n * 4, hipMemcpyDeviceToHost);
+    for (int i = 0; i < n; ++i) printf("cvt_pk_u8_f32(%g) byte1 -> 0x%08x (%u)\n", xs[i], ys[i], (ys[i] >> 8) & 255);
+}
+"""
 
 
 def build():
