@@ -210,8 +210,10 @@ __device__ __forceinline__ void work_item(const FwdParams& p, int vid, int& bh, 
 // 50 %, 46 -> 138 GB of L2 fills per launch). So there are EIGHT ticket queues, one per XCD (HW_REG_XCC_ID), each a
 // sequence of CHUNKS of C consecutive q-tiles of one head (C = the workgroups co-resident on an XCD): the CUs of an XCD
 // walk the same K/V in the same order, as under the static map. Chunks are dealt to the queues round-robin from a chunk
-// order that interleaves groups of 4 heads (the last round then has 4x as many chunks to pack; K/V live set 4 heads =
-// 155 MB at S = 75 600, inside the 256 MB Infinity Cache) and takes each head's q-tiles in the order [last, 0, 1, ...]
+// order that interleaves groups of G = 8 heads - with 8 queues queue x then walks head (8 j + x) from end to end, so a head's K/V is
+// filled into ONE L2 (G = 4, rounds 1-2: two XCDs alternate on a head's chunks and both fill it; measured on the real step-49 lists,
+// G = 8 is +1.9 % at 44 % and +1.0-3.1 % at 78 % sparsity, +0.5 % on banded lists, 170 vs 180 GB of L2 fills: profiles/r03_sched_sweep.md;
+// the last round has 8x as many chunks to pack) and takes each head's q-tiles in the order [last, 0, 1, ...]
 // (long items first, see work_item). A workgroup whose own queue is empty STEALS from the queue with the most tickets
 // left, so the XCDs finish together (list-scheduling simulation on the per-row counts of a real 78 % list: makespan /
 // ideal 1.09 for a head-major global stream, 1.01-1.03 here; tools/frag_bench.py).
@@ -219,7 +221,7 @@ __device__ __forceinline__ void work_item(const FwdParams& p, int vid, int& bh, 
 // one caller (atomicAdd), and a workgroup leaves only after it has seen all eight queues empty: every item is taken.
 // ------------------------------------------------------------------------------------------------
 #ifndef LA_SCHED_G
-#define LA_SCHED_G 4          // heads whose chunks are interleaved in the ticket order (K/V live set = G heads); tools/sched_sweep.sh
+#define LA_SCHED_G 8          // heads whose chunks are interleaved in the ticket order: 8 = the queues, so every XCD queue walks ONE head at a time (its K/V is filled into one L2 only); measured against 1 / 2 / 4 / 16 on real lists: profiles/r03_sched_sweep.md
 #endif
 #ifndef LA_SCHED_C
 #define LA_SCHED_C 32         // q-tiles per chunk of the one-workgroup-per-CU kernels (= workgroups co-resident on an XCD)

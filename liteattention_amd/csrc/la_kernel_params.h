@@ -22,6 +22,8 @@ struct FwdParams {
     int q_tile_begin;       // this launch covers q-tiles [q_tile_begin, q_tile_begin + q_tile_count) of every (batch, head):
     int q_tile_count;       // a window of the SAME problem (tensors, LSE and lists are indexed by the global q-tile)
     int seq_cap;            // int32 slots reserved in LDS for the expanded tile sequence
+    int walk_buffers;       // x64 kernels: 2 = a second walk buffer (tile sequence + vote / range-end flags) fits in LDS beside the first: the next
+                            // item's read list is expanded while this item's write list is serialised; 1 = serial (very long key sequences, head_dim > 128)
     float scale_log2;       // softmax_scale * log2(e)   (flash_api.cpp:125-126)
     float rescale_tau;      // x64 kernel: O/l follow the running max only when it grew by more than this (log2 units)
     float thr;
@@ -78,9 +80,9 @@ inline hipError_t prepare_work_queue(FwdParams& p, bool skipable, int total, int
 
 size_t fwd_lds_bytes_v2(int head_dim, int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, bool f16, hipStream_t stream);   // 128-row hipcc-scheduled template: head_dim 64; 128 / 256 as the A/B kernels (LA_FLAG_KERNEL_128ROW)
-size_t fwd_lds_bytes_x64(int k_tiles, int* seq_cap_out, int head_dim);
+size_t fwd_lds_bytes_x64(int k_tiles, int* seq_cap_out, int head_dim, int* walk_buffers_out = nullptr);
 hipError_t launch_fwd_bf16_d128_x64(const FwdParams& p, int head_dim, bool skipable, bool f16, hipStream_t stream);  // 1 wave/SIMD; head_dim 128: 64 rows/wave, q-tile 256; 256: 32 rows/wave, q-tile 128
-size_t fwd_lds_bytes_x64_fp8(int k_tiles, int* seq_cap_out);
+size_t fwd_lds_bytes_x64_fp8(int k_tiles, int* seq_cap_out, int* walk_buffers_out = nullptr);
 hipError_t launch_fwd_fp8_d128_x64(const FwdParams& p, bool skipable, int p_mode, hipStream_t stream);   // 1 wave/SIMD, 64 rows/wave; p.v = V^T workspace
 size_t fp8_workspace_bytes(int batch, int num_heads_k, int k_tiles);
 hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_row_stride, int64_t v_head_stride,
