@@ -94,7 +94,8 @@ typedef enum la_status {
 typedef enum la_dtype {
     LA_DTYPE_BF16 = 0,
     LA_DTYPE_FP16 = 1,           /* q/k/v/o fp16; every path of LA_DTYPE_BF16 (lists, varlen, flags) */
-    LA_DTYPE_FP8_E4M3 = 2        /* OCP e4m3fn (gfx950), bf16 output                              */
+    LA_DTYPE_FP8_E4M3 = 2,       /* OCP e4m3fn (gfx950), bf16 output                              */
+    LA_DTYPE_FP32 = 3            /* la_combine only: fp32 result of fp32 partials                */
 } la_dtype;
 
 /*
@@ -173,7 +174,8 @@ typedef struct la_fwd_args {
      * Both given: q is (total_q, H, D), k/v (total_k, Hk, D), o (total_q, H, D) — the *_batch_stride fields are ignored —
      * cu_seqlens_* are DEVICE int32[batch + 1] prefix sums (sequence b = rows [cu[b], cu[b+1])), seqlen_q / seqlen_k are the
      * MAXIMUM sequence lengths (they size the grid; longer sequences are truncated to them), and lse is (H, total_q):
-     * lse[h * total_q + row]. Sequences with no keys get o = 0, lse = +inf. bf16 and fp16 (fp8: LA_ERR_UNSUPPORTED).
+     * lse[h * total_q + row]. Sequences with no keys get o = 0, lse = +inf. bf16, fp16 and (round 3) fp8: the V^T prepare pass
+     * reads cu_seqlens_k itself and lays every sequence's tiles on the [B, Hk, tiles of the longest sequence] grid of `workspace`.
      * One launch for the whole batch, no host sync.
      * Skip lists with cu_seqlens (round 3; the reference's varlen entry point has none): read_list / write_list / a 4-D
      * must_do_list are [>= batch, H, ceil(seqlen_q / block_m), ceil(seqlen_k / block_n) + 1] - the geometry of the MAXIMA - and
@@ -208,7 +210,8 @@ int la_skip_list_stats(const int32_t* list, int32_t n_batch, int32_t num_heads, 
 /* LSE-weighted merge of `num_splits` partial attention results (sequence-parallel K/V splits):
  *   o_partial   [num_splits, B, Sq, H, Dv] contiguous: fp32, or (partial_is_16bit != 0) the element type of o
  *   lse_partial fp32 [num_splits, B, H, Sq] contiguous
- *   o [B,Sq,H,Dv] contiguous of o_dtype (LA_DTYPE_BF16 or LA_DTYPE_FP16), lse fp32 [B,H,Sq] (may be NULL). */
+ *   o [B,Sq,H,Dv] contiguous of o_dtype (LA_DTYPE_BF16, LA_DTYPE_FP16, or LA_DTYPE_FP32 for fp32 partials: the reference's default there,
+ *   hopper/_internal/flash_attn_interface.py:684-685), lse fp32 [B,H,Sq] (may be NULL). */
 int la_combine(const void* o_partial, int32_t partial_is_16bit, const float* lse_partial,
                void* o, int32_t o_dtype, float* lse, int32_t num_splits, int32_t batch, int32_t seqlen_q,
                int32_t num_heads, int32_t head_dim_v, void* stream);

@@ -14,7 +14,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LITEATTENTION_AMD_LIB") or os.path.join(_PKG_DIR, "libliteattention_amd.so")
 
 LA_ABI_VERSION = 4
-LA_DTYPE_BF16, LA_DTYPE_FP16, LA_DTYPE_FP8_E4M3 = 0, 1, 2
+LA_DTYPE_BF16, LA_DTYPE_FP16, LA_DTYPE_FP8_E4M3, LA_DTYPE_FP32 = 0, 1, 2, 3
 
 LA_OK = 0
 LA_ERR_NULL_ARG, LA_ERR_STRUCT_SIZE, LA_ERR_DTYPE, LA_ERR_HEAD_DIM, LA_ERR_SHAPE = -1, -2, -3, -4, -5

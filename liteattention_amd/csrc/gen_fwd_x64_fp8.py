@@ -589,7 +589,7 @@ def step(variant):
     label(slow_back)
     deferred.append(lambda: rescale_o_block(slow, slow_back))
     emit(("DRAIN",))
-    if "nobarrier" not in OPT:                 # pricing only
+    if "nobarrier" not in OPT and not ("halfbarrier" in OPT and variant == 0):                 # pricing only
         emit("s_barrier")
     emit(f"s_add_u32 {s(S_I)}, {s(S_I)}, 1")
 

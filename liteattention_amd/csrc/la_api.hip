@@ -126,7 +126,6 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     const bool varlen = a->cu_seqlens_q != nullptr || a->cu_seqlens_k != nullptr;
     if (varlen) {                                                                        // flash_api.cpp:736-760
         if (a->cu_seqlens_q == nullptr || a->cu_seqlens_k == nullptr) return LA_ERR_NULL_ARG;
-        if (fp8) return LA_ERR_UNSUPPORTED;                                               // needs a per-sequence V^T prepare pass
         if (a->read_list != nullptr && ((a->flags & LA_FLAG_KERNEL_128ROW) || a->head_dim > 128))
             return LA_ERR_UNSUPPORTED;                                                    // lists + cu_seqlens: the hand-scheduled kernels, head_dim <= 128
         if (a->total_q < 0 || a->q_tile_count != 0) return LA_ERR_SHAPE;
@@ -196,7 +195,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         hipError_t e8 = hipSuccess;
         if (!(a->flags & LA_FLAG_V_PREPARED))
             e8 = la::launch_prep_v_fp8(a->v, a->v_batch_stride, a->v_row_stride, a->v_head_stride, a->workspace,
-                                       a->batch, a->seqlen_k, a->num_heads_k, p.k_tiles, stream);
+                                       a->batch, a->seqlen_k, a->num_heads_k, p.k_tiles, stream, a->cu_seqlens_k);
         if (e8 == hipSuccess) {
             p.v = static_cast<const uint16_t*>(a->workspace);
             e8 = la::launch_fwd_fp8_d128_x64(p, a->read_list != nullptr,
@@ -243,13 +242,14 @@ int la_combine(const void* o_partial, int32_t partial_is_16bit, const float* lse
                int32_t num_splits, int32_t batch, int32_t seqlen_q, int32_t num_heads, int32_t head_dim_v,
                void* stream_) {
     if (!o_partial || !lse_partial || !o) return LA_ERR_NULL_ARG;
-    if (o_dtype != LA_DTYPE_BF16 && o_dtype != LA_DTYPE_FP16) return LA_ERR_DTYPE;
+    if (o_dtype != LA_DTYPE_BF16 && o_dtype != LA_DTYPE_FP16 && o_dtype != LA_DTYPE_FP32) return LA_ERR_DTYPE;
+    if (o_dtype == LA_DTYPE_FP32 && partial_is_16bit) return LA_ERR_DTYPE;      // an fp32 result is the merge of fp32 partials
     if (num_splits <= 0 || batch <= 0 || seqlen_q <= 0 || num_heads <= 0 || head_dim_v <= 0) return LA_ERR_SHAPE;
     if (head_dim_v % 8 != 0) return LA_ERR_HEAD_DIM;
     if (!aligned16(o_partial) || !aligned16(o)) return LA_ERR_STRIDE;
     const hipError_t err = la::launch_combine(o_partial, partial_is_16bit != 0, o_dtype == LA_DTYPE_FP16, lse_partial, static_cast<uint16_t*>(o), lse,
                                               num_splits, batch, seqlen_q, num_heads, head_dim_v,
-                                              static_cast<hipStream_t>(stream_));
+                                              static_cast<hipStream_t>(stream_), o_dtype == LA_DTYPE_FP32);
     if (err != hipSuccess) { g_last_hip_error = static_cast<int>(err); return LA_ERR_LAUNCH; }
     return LA_OK;
 }

@@ -84,7 +84,7 @@ hipError_t launch_empty_k_fill(uint16_t* o, float* lse, int64_t o_batch_stride, 
 }
 
 // One thread = 8 consecutive d of one (b, s, h) row. Memory-bound; 16-byte accesses.
-template <bool PARTIAL_16BIT, bool F16>     // 16-bit partials have the element type of o (bf16, or fp16 when F16)
+template <bool PARTIAL_16BIT, bool F16, bool OUT_F32 = false>     // 16-bit partials have the element type of o (bf16, or fp16 when F16); OUT_F32: o is fp32
 __global__ void __launch_bounds__(256) combine_kernel(const void* __restrict__ o_partial,
                                                        const float* __restrict__ lse_partial,
                                                        uint16_t* __restrict__ o, float* __restrict__ lse_out,
@@ -129,7 +129,13 @@ __global__ void __launch_bounds__(256) combine_kernel(const void* __restrict__ o
         }
         const float inv = denom > 0.f ? 1.f / denom : 0.f;
         acc *= inv;
-        *reinterpret_cast<ex8*>(o + row * dv + ch * 8) = __builtin_convertvector(acc, ex8);
+        if constexpr (OUT_F32) {
+            float* const of = reinterpret_cast<float*>(o) + row * dv + ch * 8;
+            *reinterpret_cast<f32x4*>(of) = __builtin_shufflevector(acc, acc, 0, 1, 2, 3);
+            *reinterpret_cast<f32x4*>(of + 4) = __builtin_shufflevector(acc, acc, 4, 5, 6, 7);
+        } else {
+            *reinterpret_cast<ex8*>(o + row * dv + ch * 8) = __builtin_convertvector(acc, ex8);
+        }
         if (lse_out != nullptr && ch == 0) lse_out[lse_idx] = denom > 0.f ? m_safe + __logf(denom) : -INFINITY;
     }
 }
@@ -143,14 +149,17 @@ static void launch_combine_t(unsigned blocks, hipStream_t stream, const void* o_
 
 hipError_t launch_combine(const void* o_partial, bool partial_is_16bit, bool f16, const float* lse_partial, uint16_t* o,
                           float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v,
-                          hipStream_t stream) {
+                          hipStream_t stream, bool out_f32) {
     const int64_t total = static_cast<int64_t>(batch) * seqlen_q * num_heads * (head_dim_v / 8);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
     (void)hipGetLastError();
     const unsigned g = static_cast<unsigned>(blocks);
-    if (partial_is_16bit && f16)
+    if (out_f32)     // fp32 partials -> fp32 result (the reference's default for fp32 partials, flash_attn_interface.py:684-685)
+        hipLaunchKernelGGL((combine_kernel<false, false, true>), dim3(g), dim3(256), 0, stream, o_partial, lse_partial, o, lse, num_splits,
+                           batch, seqlen_q, num_heads, head_dim_v);
+    else if (partial_is_16bit && f16)
         launch_combine_t<true, true>(g, stream, o_partial, lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v);
     else if (partial_is_16bit)
         launch_combine_t<true, false>(g, stream, o_partial, lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v);

@@ -86,12 +86,13 @@ size_t fwd_lds_bytes_x64_fp8(int k_tiles, int* seq_cap_out, int* walk_buffers_ou
 hipError_t launch_fwd_fp8_d128_x64(const FwdParams& p, bool skipable, int p_mode, hipStream_t stream);   // 1 wave/SIMD, 64 rows/wave; p.v = V^T workspace
 size_t fp8_workspace_bytes(int batch, int num_heads_k, int k_tiles);
 hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_row_stride, int64_t v_head_stride,
-                             void* vt, int batch, int seqlen_k, int num_heads_k, int k_tiles, hipStream_t stream);
+                             void* vt, int batch, int seqlen_k, int num_heads_k, int k_tiles, hipStream_t stream,
+                             const int* cu_seqlens_k = nullptr);
 hipError_t launch_empty_k_fill(uint16_t* o, float* lse, int64_t o_batch_stride, int64_t o_row_stride, int64_t o_head_stride,
                                int batch, int seqlen_q, int num_heads, int head_dim_v, hipStream_t stream);
 hipError_t launch_skip_list_stats(const int32_t* list, int rows, int k_tiles, int64_t* out, hipStream_t stream);
 hipError_t launch_combine(const void* o_partial, bool partial_is_16bit, bool f16, const float* lse_partial, uint16_t* o,
                           float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v,
-                          hipStream_t stream);
+                          hipStream_t stream, bool out_f32 = false);
 
 }  // namespace la

@@ -30,16 +30,23 @@ __device__ __forceinline__ constexpr int f8_v_swz(int row) { return (row >> 2) &
 // ------------------------------------------------------------------------------------------------
 // Prepare kernel: V (B,Sk,H,128) e4m3 -> V^T tiles [B,H,Kt][128][64] (key order and swizzle as above).
 // One workgroup per (b, h, k-tile); rows past seqlen_k become zeros (P is 0 there anyway).
+// Packed variable-length batches (cu_seqlens_k != nullptr): v is (total_k, H, 128), sequence b owns rows [cu[b], cu[b + 1]) and its
+// tiles are written to the same [B, H, Kt] grid (Kt = tiles of the longest sequence; the tiles past a sequence's end are zeros).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) la_prep_v_fp8_kernel(const uint8_t* __restrict__ v, int64_t v_batch_stride,
                                                             int64_t v_row_stride, int64_t v_head_stride,
                                                             uint8_t* __restrict__ vt, int seqlen_k, int num_heads,
-                                                            int k_tiles) {
+                                                            int k_tiles, const int* __restrict__ cu_seqlens_k) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[F8_BN][F8_D + 16];   // [key][d], padded rows
     const int n = blockIdx.x % k_tiles;
     const int bh = blockIdx.x / k_tiles;
     const int h = bh % num_heads, b = bh / num_heads;
     const uint8_t* src = v + b * v_batch_stride + h * v_head_stride;
+    if (cu_seqlens_k != nullptr) {
+        const int k0 = cu_seqlens_k[b];
+        seqlen_k = min(max(cu_seqlens_k[b + 1] - k0, 0), seqlen_k);
+        src = v + static_cast<int64_t>(k0) * v_row_stride + h * v_head_stride;
+    }
     const int tid = threadIdx.x;
     // coalesced load: 64 rows x 128 bytes = 512 chunks of 16 bytes, 2 per thread
 #pragma unroll
@@ -79,11 +86,12 @@ __global__ void __launch_bounds__(256) la_prep_v_fp8_kernel(const uint8_t* __res
 }
 
 hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_row_stride, int64_t v_head_stride,
-                             void* vt, int batch, int seqlen_k, int num_heads, int k_tiles, hipStream_t stream) {
+                             void* vt, int batch, int seqlen_k, int num_heads, int k_tiles, hipStream_t stream,
+                             const int* cu_seqlens_k) {
     (void)hipGetLastError();
     hipLaunchKernelGGL(la_prep_v_fp8_kernel, dim3(batch * num_heads * k_tiles), dim3(256), 0, stream,
                        static_cast<const uint8_t*>(v), v_batch_stride, v_row_stride, v_head_stride,
-                       static_cast<uint8_t*>(vt), seqlen_k, num_heads, k_tiles);
+                       static_cast<uint8_t*>(vt), seqlen_k, num_heads, k_tiles, cu_seqlens_k);
     return hipGetLastError();
 }
 

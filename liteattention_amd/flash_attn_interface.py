@@ -299,7 +299,8 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
 def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, q_descale, k_descale, v_descale,
                     softmax_scale, attn_read_list, attn_write_list, attn_must_do_list=None, thr=-3.0, _must_do_is_1d=False):
     """Packed variable-length batches (flash_api.cpp:672-674, 736-760): q (total_q, H, D), k/v (total_k, Hk, D), cu_seqlens_*
-    int32 [B+1] on the device, max_seqlen_* size the grid. ONE launch, no host sync. bf16 / fp16 only. lse is (H, total_q).
+    int32 [B+1] on the device, max_seqlen_* size the grid. ONE launch, no host sync (fp8: plus the V^T prepare pass, which reads
+    cu_seqlens_k itself). bf16 / fp16 at every head dim, e4m3 at head_dim 128 with descales (B, Hk). lse is (H, total_q).
     Skip lists (extension; the reference's varlen entry point has none, hopper/_internal/flash_attn_interface.py:638-682):
     ``[>= B, H, ceil(max_seqlen_q / kBlockM), ceil(max_seqlen_k / kBlockN) + 1]``, row (b, h, m) describing q-tile m of sequence b
     over THAT sequence's k-tiles - what the static block-sparse adapter needs to run a packed batch in one launch."""
@@ -307,8 +308,9 @@ def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
         raise RuntimeError("cu_seqlens_q and cu_seqlens_k must be given together")
     if (attn_read_list is None) != (attn_write_list is None):
         raise RuntimeError("attn_read_list and attn_write_list must be given together")
-    if q.dtype not in (torch.bfloat16, torch.float16) or q_descale is not None or k_descale is not None or v_descale is not None:
-        raise NotImplementedError("varlen is built for bf16 and fp16 (fp8 needs a per-sequence V^T prepare pass)")
+    if q.dtype not in (torch.bfloat16, torch.float16, torch.float8_e4m3fn):
+        raise RuntimeError("FlashAttention only supports fp16, bf16, and fp8_e4m3 type")          # :715
+    is_fp8 = q.dtype == torch.float8_e4m3fn
     if k.dtype != q.dtype or v.dtype != q.dtype:
         raise RuntimeError("query and key must have the same dtype")
     if q.dim() != 3 or k.dim() != 3 or v.dim() != 3:
@@ -328,12 +330,23 @@ def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
         raise RuntimeError("k/v shape mismatch: expected k, v (total_k, nheads_k, headdim)")
     if H % Hk != 0:
         raise RuntimeError("Number of heads in key/value must divide number of heads in query")
-    if D % 8 != 0:
-        raise RuntimeError("head_size should be a multiple of 8")
+    if D % (16 if is_fp8 else 8) != 0:
+        raise RuntimeError("head_size should be a multiple of " + ("16" if is_fp8 else "8"))
     if softmax_scale is None:
         softmax_scale = D ** -0.5
     B = cu_seqlens_q.numel() - 1
-    D_kernel = kernel_head_dim(D, 2)
+    descales = []
+    for name, t in (("q_descale", q_descale), ("k_descale", k_descale), ("v_descale", v_descale)):
+        if t is not None:
+            if not is_fp8:
+                raise RuntimeError(f"{name} is only supported for fp8 inputs")
+            if t.dtype != torch.float32 or tuple(t.shape) != (B, Hk) or t.device != q.device:      # :1003-1022
+                raise RuntimeError(f"{name} must be a float32 tensor of shape (batch_size, nheads_k) on the input device")
+        descales.append(t)
+    out_dtype = torch.bfloat16 if is_fp8 else q.dtype                                              # :859-863
+    D_kernel = kernel_head_dim(D, q.element_size())
+    if D_kernel != D and is_fp8:
+        raise NotImplementedError("fp8 varlen is built for head_dim 128")
     if D_kernel != D:
         if out is not None and (out.dtype != q.dtype or tuple(out.shape) != (Tq, H, D) or out.stride(-1) != 1):
             raise RuntimeError("out must have the input dtype, shape (total_q, nheads, headdim) and a contiguous last dimension")
@@ -345,18 +358,23 @@ def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
         out.copy_(res[0][..., :D])
         return (out, *res[1:])
     if out is None:
-        out = torch.empty((Tq, H, D), dtype=q.dtype, device=q.device)
-    elif out.dtype != q.dtype or tuple(out.shape) != (Tq, H, D) or out.stride(-1) != 1:
-        raise RuntimeError("out must have the input dtype, shape (total_q, nheads, headdim) and a contiguous last dimension")
+        out = torch.empty((Tq, H, D), dtype=out_dtype, device=q.device)
+    elif out.dtype != out_dtype or tuple(out.shape) != (Tq, H, D) or out.stride(-1) != 1:
+        raise RuntimeError("out must have the input dtype (bf16 for fp8 inputs), shape (total_q, nheads, headdim) and a contiguous last dimension")
     softmax_lse = torch.empty((H, Tq), dtype=torch.float32, device=q.device)
     empty = torch.empty(0, dtype=torch.float32, device=q.device)
     if Tq == 0 or max_seqlen_q <= 0:
         return out, softmax_lse, empty, empty
     flags = _cabi.default_flags()
-    block_m, block_n = _cabi.get_tile_sizes(D, 2, flags)
+    block_m, block_n = _cabi.get_tile_sizes(D, q.element_size(), flags)
     a = _cabi.LaFwdArgs()
     a.struct_size = ctypes.sizeof(_cabi.LaFwdArgs)
-    a.dtype = _cabi.LA_DTYPE_FP16 if q.dtype == torch.float16 else _cabi.LA_DTYPE_BF16
+    a.dtype = _cabi.LA_DTYPE_FP8_E4M3 if is_fp8 else (_cabi.LA_DTYPE_FP16 if q.dtype == torch.float16 else _cabi.LA_DTYPE_BF16)
+    for name, t in zip(("q", "k", "v"), descales):
+        if t is not None:
+            setattr(a, f"{name}_descale", t.data_ptr())
+            setattr(a, f"{name}_descale_batch_stride", t.stride(0))
+            setattr(a, f"{name}_descale_head_stride", t.stride(1))
     workspace = None
     if attn_read_list is not None:
         q_tiles, k_tiles = -(-int(max_seqlen_q) // block_m), -(-max(int(max_seqlen_k), 0) // block_n)
@@ -385,9 +403,10 @@ def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
     a.num_heads, a.num_heads_k, a.head_dim, a.head_dim_v = H, Hk, D, D
     a.softmax_scale = float(softmax_scale)
     a.block_m, a.block_n = block_m, block_n
-    a.flags = flags & (_cabi.LA_FLAG_KERNEL_128ROW | _cabi.LA_FLAG_EXACT_RESCALE | _cabi.LA_FLAG_STATIC_SCHED)
+    a.flags = flags & ((_cabi.LA_FLAG_EXACT_ROWSUM | _cabi.LA_FLAG_EXACT_EXP | _cabi.LA_FLAG_STATIC_SCHED) if is_fp8 else
+                       (_cabi.LA_FLAG_KERNEL_128ROW | _cabi.LA_FLAG_EXACT_RESCALE | _cabi.LA_FLAG_STATIC_SCHED))
     a.cu_seqlens_q, a.cu_seqlens_k, a.total_q = cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), Tq
-    if attn_read_list is not None:                # ticket counters of the dynamic work distribution (as in the fixed-length path)
+    if attn_read_list is not None or is_fp8:      # ticket counters of the dynamic work distribution (as in the fixed-length path); fp8: + the V^T tiles
         need = _cabi.load().la_fwd_workspace_bytes(ctypes.byref(a))
         if need < 0:
             raise RuntimeError(f"lite_attention::fwd (varlen): {_cabi.status_string(int(need))}")
@@ -518,16 +537,16 @@ def flash_attn_combine(out_partial: torch.Tensor, lse_partial: torch.Tensor, out
     out_partial: (num_splits, batch, seqlen, nheads, headdim) fp32, bf16 or fp16; lse_partial:
     (num_splits, batch, nheads, seqlen) fp32 (the layout ``flash_attn_func`` returns). Counterpart of
     the reference's flash_attn_combine (hopper/_internal/flash_attn_interface.py:684, fwd_combine op,
-    flash_api.cpp:1620-1680). ``out_dtype``: bf16 or fp16; default = the dtype of 16-bit partials, bf16 for fp32 partials
-    (the reference would return fp32 there; an fp32 result is not built)."""
+    flash_api.cpp:1620-1680). ``out_dtype``: default = the dtype of the partials, as in the reference (fp32 partials -> fp32 result,
+    hopper/_internal/flash_attn_interface.py:684-685); fp32 partials may also be merged into bf16 / fp16."""
     if not out_partial.is_cuda:
         raise RuntimeError("flash_attn_combine has no CPU implementation")
     if out_partial.dtype not in (torch.float32, torch.bfloat16, torch.float16):
         raise RuntimeError("out_partial must be fp32, bf16 or fp16")
     if out_dtype is None:
-        out_dtype = out.dtype if out is not None else (torch.bfloat16 if out_partial.dtype == torch.float32 else out_partial.dtype)
-    if out_dtype not in (torch.bfloat16, torch.float16):
-        raise RuntimeError("Output type must be FP16 or BF16 (an FP32 result is not built)")
+        out_dtype = out.dtype if out is not None else out_partial.dtype
+    if out_dtype not in (torch.bfloat16, torch.float16, torch.float32):
+        raise RuntimeError("Output type must be FP32, FP16 or BF16")
     if out_partial.dtype != torch.float32 and out_partial.dtype != out_dtype:
         raise RuntimeError("16-bit partial results must have the output dtype")
     if lse_partial.dtype != torch.float32:
@@ -546,7 +565,7 @@ def flash_attn_combine(out_partial: torch.Tensor, lse_partial: torch.Tensor, out
         stream = torch.cuda.current_stream(out_partial.device).cuda_stream
         rc = _cabi.load().la_combine(out_partial.data_ptr(), int(out_partial.dtype != torch.float32),
                                      lse_partial.data_ptr(), out.data_ptr(),
-                                     _cabi.LA_DTYPE_FP16 if out_dtype == torch.float16 else _cabi.LA_DTYPE_BF16,
+                                     {torch.float16: _cabi.LA_DTYPE_FP16, torch.float32: _cabi.LA_DTYPE_FP32}.get(out_dtype, _cabi.LA_DTYPE_BF16),
                                      lse.data_ptr() if lse is not None else None,
                                      ns, B, S, H, Dv, ctypes.c_void_p(stream))
     if rc != _cabi.LA_OK:

@@ -57,8 +57,10 @@ class LiteAttention:
     def get_MN(head_dim, element_size, v_colmajor=False):
         """(kTileM, kTileN) of the kernel, from ``la_get_tile_sizes`` (one table shared with the HIP code;
         the reference hand-copies it, lite_attention.py:87-111 vs tile_size.h:10-62)."""
-        if v_colmajor:
-            raise NotImplementedError("column-major V (fp8 layout of the reference) is not built")
+        # v_colmajor: accepted and ignored. In the reference it only switches the fp8 head_dim-128 tile (224 -> 192 keys,
+        # tile_size.h:55) - and only on the Python side: its op passes v_colmajor = false to tile_size_fwd_sm90 and requires
+        # v.stride(-1) == 1 (flash_api.cpp:413,728), so a column-major V never reaches its kernel. This build's tiles do not
+        # depend on the layout of V.
         return get_tile_sizes(head_dim, element_size)
 
     @staticmethod
@@ -71,8 +73,6 @@ class LiteAttention:
                        seq_len_k=None) -> Tensor:
         """``[2, batch, heads, q_tiles, k_tiles+1]`` int32, rows ``[2, k_tiles-1, 0, ...]`` (:113-153).
         ``seq_len_k`` (extension) defaults to ``seq_len``."""
-        if v_colmajor:
-            raise NotImplementedError("column-major V (fp8 layout of the reference) is not built")
         _, bn, qt, kt = _sl.tile_geometry(seq_len, seq_len if seq_len_k is None else seq_len_k, head_dim,
                                           dtype.itemsize)
         row = None if must_skip_list is None else _sl.must_skip_row(must_skip_list, bn, kt)

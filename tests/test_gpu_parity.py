@@ -430,9 +430,15 @@ def test_seq_parallel_splits_plus_combine_equal_full_attention():
     assert (lse.cpu() - lse_c.transpose(1, 2)).abs().max().item() <= 1e-4
     assert (out.float().cpu() - o_ref.float()).abs().max().item() <= 3e-2
     assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
-    # fp32 partials too
-    out32, _ = L.flash_attn_combine(torch.stack(outs).float(), torch.stack(lses))
-    assert torch.equal(out32, out)
+    # fp32 partials: an fp32 result by default, as in the reference (hopper/_internal/flash_attn_interface.py:684-685: the output
+    # dtype defaults to that of the partials) - it is the merge oracle to fp32 round-off; bf16 on request, equal to the bf16 merge
+    out32, lse32 = L.flash_attn_combine(torch.stack(outs).float(), torch.stack(lses))
+    assert out32.dtype == torch.float32
+    assert (out32.cpu() - o_c).abs().max().item() <= 2e-6 and torch.equal(lse32, lse)
+    out16, _ = L.flash_attn_combine(torch.stack(outs).float(), torch.stack(lses), out_dtype=torch.bfloat16)
+    assert torch.equal(out16, out)
+    with pytest.raises(RuntimeError, match="16-bit partial"):
+        L.flash_attn_combine(torch.stack(outs), torch.stack(lses), out_dtype=torch.float32)
 
 
 # -------------------------------------------------------------------- full-size properties (C2 shape)

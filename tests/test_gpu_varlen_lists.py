@@ -130,3 +130,76 @@ def test_block_sparse_packed_batch_is_one_launch_and_matches_the_per_sequence_fo
     bad[1, 12] = True                                          # q-tile 1 keeps only k-tile 12: beyond the 333-token sequence's 6 tiles
     with pytest.raises(ValueError):
         L.flash_blocksparse_attn_qkvpacked_func(qkv, torch.tensor(cu, dtype=torch.int32).cuda(), bad, 0.0, max_s)
+
+
+@pytest.mark.parametrize("with_lists", [False, True])
+@pytest.mark.parametrize("p_mode", ["encoded", "exp"])
+def test_fp8_packed_batch_equals_the_fixed_length_path(with_lists, p_mode, monkeypatch):
+    """fp8 (e4m3) with cu_seqlens (round 3): the V^T prepare pass reads cu_seqlens_k itself and writes every sequence's tiles onto the
+    [B, Hk, Kt_max] grid, the forward kernel takes each item's rows / lengths from cu_seqlens - ONE forward launch. Per sequence the
+    result must equal a fixed-length fp8 launch on that sequence with that sequence's descales - O, LSE and (with lists, three steps at
+    thr = -2.5) the write list bit for bit; GQA, an empty query sequence, a sequence without keys, one shorter than a tile."""
+    import liteattention_amd as L
+    from liteattention_amd.flash_attn_interface import mha_fwd
+    monkeypatch.delenv("LA_FP8_ROWSUM", raising=False)
+    monkeypatch.delenv("LA_FP8_EXP", raising=False)
+    if p_mode == "exp":
+        monkeypatch.setenv("LA_FP8_EXP", "exact")
+    F8 = torch.float8_e4m3fn
+    D, H, Hk, thr = 128, 4, 2, -2.5
+    bm, bn = L.get_tile_sizes(D, 1)
+    lens_q = [700, 0, 40, 1300, 513, 100]
+    lens_k = [900, 64, 130, 1300, 200, 0]
+    B = len(lens_q)
+    qs, ks, vs = [], [], []
+    for b in range(B):
+        q, _, _ = structured_qkv(1, max(lens_q[b], 1), H, D, seed=70 + b, alpha=7.0, dtype=torch.float32)
+        _, k, v = structured_qkv(1, max(lens_k[b], 1), Hk, D, seed=70 + b, alpha=7.0, dtype=torch.float32)
+        qs.append(q[0, : lens_q[b]].to(F8)); ks.append(k[0, : lens_k[b]].to(F8)); vs.append(v[0, : lens_k[b]].to(F8))
+    (qp, cq), (kp, ck), (vp, _) = _pack(qs), _pack(ks), _pack(vs)
+    cq_d, ck_d = torch.tensor(cq, dtype=torch.int32).cuda(), torch.tensor(ck, dtype=torch.int32).cuda()
+    g = torch.Generator().manual_seed(5)
+    qd, kd, vd = [(0.5 + torch.rand(B, Hk, generator=g)).cuda() for _ in range(3)]
+    Qt, Kt = math.ceil(max(lens_q) / bm), math.ceil(max(lens_k) / bn)
+    lists = torch.zeros(2, B, H, Qt, Kt + 1, dtype=torch.int32)
+    for b in range(B):
+        lists[:, b, :, :, 0] = 2
+        lists[:, b, :, :, 1] = max(math.ceil(lens_k[b] / bn) - 1, 0)
+    lists = lists.cuda()
+    must_do = torch.tensor([2, 0, 0], dtype=torch.int32).cuda()
+    rd, dropped = 0, 0
+    for step in range(3 if with_lists else 1):
+        kw = {}
+        if with_lists:
+            lists[1 - rd].fill_(-7)
+            kw = dict(attn_read_list=lists[rd], attn_must_do_list=must_do, attn_write_list=lists[1 - rd], thr=thr, _must_do_is_1d=True)
+        out = torch.full((sum(lens_q), H, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+        o, lse, *_ = mha_fwd(qp.cuda(), kp.cuda(), vp.cuda(), out=out, cu_seqlens_q=cq_d, cu_seqlens_k=ck_d, max_seqlen_q=max(lens_q),
+                             max_seqlen_k=max(lens_k), q_descale=qd, k_descale=kd, v_descale=vd, **kw)
+        assert o.dtype == torch.bfloat16 and tuple(lse.shape) == (H, sum(lens_q))
+        assert bool(torch.isfinite(o.float()).all())
+        for b in range(B):
+            if lens_q[b] == 0:
+                continue
+            sq = slice(cq[b], cq[b + 1])
+            qt_b, kt_b = math.ceil(lens_q[b] / bm), math.ceil(lens_k[b] / bn)
+            kw_b = {}
+            if with_lists and lens_k[b] > 0:
+                rd_b = lists[rd, b: b + 1, :, :qt_b, : kt_b + 1].contiguous()
+                wr_b = torch.zeros_like(rd_b)
+                kw_b = dict(attn_read_list=rd_b, attn_must_do_list=must_do, attn_write_list=wr_b, thr=thr, _must_do_is_1d=True)
+            o_b, lse_b, *_ = mha_fwd(qs[b][None].cuda(), ks[b][None].cuda(), vs[b][None].cuda(), q_descale=qd[b: b + 1],
+                                     k_descale=kd[b: b + 1], v_descale=vd[b: b + 1], **kw_b)
+            assert torch.equal(o[sq], o_b[0]) and torch.equal(lse[:, sq], lse_b[0]), (step, b)
+            if lens_k[b] == 0:
+                assert bool((o[sq] == 0).all()) and bool(torch.isinf(lse[:, sq]).all())          # flash_api.cpp:1241-1245
+            elif with_lists:
+                got = lists[1 - rd, b, :, :qt_b, : kt_b + 1]
+                live = torch.arange(kt_b + 1, device="cuda") <= wr_b[0, ..., 0:1]
+                assert bool(((got == wr_b[0]) | ~live).all()), (step, b)
+                dropped += int((rd_b[..., 0] != wr_b[..., 0]).sum()) + int((rd_b[..., 1:3] != wr_b[..., 1:3]).sum())
+        rd = 1 - rd
+    assert dropped > 0 or not with_lists
+    with pytest.raises(RuntimeError, match="descale"):
+        mha_fwd(qp.cuda(), kp.cuda(), vp.cuda(), cu_seqlens_q=cq_d, cu_seqlens_k=ck_d, max_seqlen_q=max(lens_q),
+                max_seqlen_k=max(lens_k), q_descale=qd[:2])
