@@ -510,7 +510,16 @@ def main():
             f8.pop("_bm_bn_tiles")
             result["fp8"] = {"value": f8["value"], "unit": result["unit"], "ms_per_step": f8["ms_per_step"], "dtype": "fp8 (e4m3 in, fp32 accumulate, bf16 out)",
                              "steps": max(5, args.steps // 2), "sparsity": f8["sparsity"], "tiles": f8["tiles"],
-                             "roofline": f8["roofline"], "verified": f8.get("verified"), "power": f8.get("power")}
+                             "roofline": f8["roofline"], "verified": f8.get("verified"), "power": f8.get("power"),
+                             "p_form": "default: block-scaled log-linear e4m3 encoding of P (include/lite_attention_amd.h, LA_FLAG_EXACT_EXP)"}
+            # beside it, the reference's form of P (v_exp_f32 + hardware e4m3 rounding: LA_FLAG_EXACT_EXP) on the same lists, same box
+            os.environ["LA_FP8_EXP"] = "exact"
+            try:
+                fx = run_dtype("fp8", max(5, args.steps // 2), 2, sweep=False, distributed=False)
+                result["fp8"]["exact_exp"] = {"value": fx["value"], "ms_per_step": fx["ms_per_step"], "frac": fx["roofline"]["frac"],
+                                              "verified": {k: fx.get("verified", {}).get(k) for k in ("ok", "max_err", "max_err_lse", "tol")}}
+            finally:
+                os.environ.pop("LA_FP8_EXP", None)
         except Exception as e:  # noqa: BLE001
             result["fp8"] = {"value": None, "error": repr(e)}
 

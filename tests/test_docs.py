@@ -1,0 +1,31 @@
+"""CPU: the measured tables of DESIGN.md are the ones tools/gen_design_tables.py writes from the committed evidence of ONE run
+(profiles/r03_*): prose may interpret the numbers, it may not drift from them."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_design_tables_are_generated_from_the_committed_profiles():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_design_tables.py"), "r03", "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for name in ("headline", "rocprof_bf16", "rocprof_fp8", "traffic", "sched_sweep", "denoise50"):
+        body = text.split(f"<!-- GEN:{name} -->")[1].split(f"<!-- /GEN:{name} -->")[0]
+        assert body.strip(), f"generated block {name} is empty"
+
+
+def test_committed_traffic_figure_belongs_to_the_committed_kernel_sources():
+    """bench.py takes roofline.traffic from profiles/pmc_summary*.json only when the summary was measured on the kernel sources of the
+    run; the committed summaries must be the ones of the tree (otherwise the driver's line says traffic: null)."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    csrc = os.path.join(ROOT, "liteattention_amd", "csrc")
+    if not os.path.exists(os.path.join(csrc, "la_fwd_x64_body.inc")):
+        import pytest
+        pytest.skip("generated bodies not built yet")
+    sha = bench.kernel_source_hash()
+    for fn in ("pmc_summary.json", "pmc_summary_fp8.json"):
+        assert json.load(open(os.path.join(ROOT, "profiles", fn)))["kernel_source_sha16"] == sha, fn

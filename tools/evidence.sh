@@ -1,9 +1,9 @@
 #!/bin/bash
-# GPU box: every profile the round-2 documents cite, in one call. Outputs under gpurun_out/ev_<tag>/ ; summarise with
-#   python tools/summarize_r02.py gpurun_out/ev_<tag> <tag>          (writes profiles/<tag>_*)
+# GPU box: every profile the documents cite, in one call. Outputs under gpurun_out/ev_<tag>/ ; summarise with
+#   python tools/summarize_evidence.py gpurun_out/ev_<tag> <tag>          (writes profiles/<tag>_*)
 # PMC counters are collected in their own rocprofv3 passes (never together with trace domains), FETCH_SIZE alone (3 TCC slots).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/ev_$TAG
 mkdir -p $OUT
@@ -46,6 +46,16 @@ for t in d64 d96 d192 d256; do
 done
 # the hipcc-scheduled A/B kernels on the same box (head dims 192 / 96 zero-padded onto 256 / 128 by the host)
 want other && LA_FWD_KERNEL=v2 python $R/tools/d256_bench.py > $OUT/v2_bench.txt 2>&1
+# 5b. fp8: the three forms of P (default block-scaled log-linear encoding / LA_FP8_EXP=exact / LA_FP8_ROWSUM=exact) on the same box: banded
+#     headline lists (ms, TFLOP/s) and the real step-49 lists with the error against fp32 torch on sampled rows
+if want fp8forms; then
+  { for m in default exp rowsum; do
+      unset LA_FP8_EXP LA_FP8_ROWSUM; [ $m = exp ] && export LA_FP8_EXP=exact; [ $m = rowsum ] && export LA_FP8_ROWSUM=exact
+      echo "P form $m: $(python $R/tools/fp8_quick.py 2>&1 | grep 's=')"
+    done; unset LA_FP8_EXP LA_FP8_ROWSUM
+    python $R/tools/debug/fp8_tail_probe.py -4.22 2>&1 | grep "real lists"
+    python $R/tools/debug/fp8_tail_probe.py -2.462 2>&1 | grep "real lists"; } > $OUT/fp8_p_forms.txt 2>&1
+fi
 # 6. socket power and clocks under the kernels (rocm-smi)
 want power && (cd $R && bash tools/power_probe.sh $OUT/power_probe.txt > /dev/null 2>&1)
 ls $OUT | head -80

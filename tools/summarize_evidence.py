@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Summarise a tools/evidence_r02.sh output directory into profiles/<tag>_* (the committed evidence).
+"""Summarise a tools/evidence.sh output directory into profiles/<tag>_* (the committed evidence).
 
-usage: python tools/summarize_r02.py gpurun_out/ev_<tag> <tag>
+usage: python tools/summarize_evidence.py gpurun_out/ev_<tag> <tag>
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE count the L2's memory-side requests in
 KiB (Infinity-Cache hits included), collected in their own --pmc passes; on gfx950 FETCH_SIZE reports exactly half of a wide
 coalesced streaming read, so the read side is doubled. Counters are averaged over the forward-kernel dispatches of a pass (for
@@ -116,7 +116,7 @@ for dt in ("bf16", "fp8"):
     line = kt_line if dt == "bf16" else (kt_line or {}).get("fp8")
     name = f"{tag}_rocprof_summary" if dt == "bf16" else f"{tag}_fp8_rocprof_summary"
     md = [f"# rocprofv3 summary `{tag}` ({dt}), kernel sources {sha}", "",
-          "Commands (tools/evidence_r02.sh): `rocprofv3 --kernel-trace --stats -- python bench.py --no-sweep --no-cpu-baseline --no-denoise --no-head-dims --no-power --steps 5 --warmup 2` "
+          "Commands (tools/evidence.sh): `rocprofv3 --kernel-trace --stats -- python bench.py --no-sweep --no-cpu-baseline --no-denoise --no-head-dims --no-power --steps 5 --warmup 2` "
           f"for the kernel statistics; PMC in separate `rocprofv3 --pmc ... -- python bench.py --no-sweep --no-cpu-baseline --no-fp8 --no-verify --no-denoise --no-head-dims --no-power --steps 3 --warmup 1 --dtype {dt}` passes.", ""]
     if line:
         md += [f"bench record under the profiler: value={line.get('value')} TFLOP/s, ms_per_step={line.get('ms_per_step')}, "
@@ -134,6 +134,20 @@ for dt in ("bf16", "fp8"):
         json.dump({"hbm_bytes_per_launch": d["hbm_bytes_per_launch"], "kernel_source_sha16": sha, "n_gpus": 1,
                    "source": f"profiles/{name}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)"},
                   open(os.path.join(PROF, "pmc_summary_fp8.json" if dt == "fp8" else "pmc_summary.json"), "w"), indent=1)
+
+# the bench line of record was taken BEFORE the PMC passes of the same session existed (bench.py reads profiles/pmc_summary*.json, which this
+# script writes): put the traffic of the same session, same kernel sources, into the committed copy of the line
+bl = os.path.join(PROF, f"{tag}_bench_line.json")
+line = json.load(open(bl))
+for key, fn in ((None, "pmc_summary.json"), ("fp8", "pmc_summary_fp8.json")):
+    rec = line if key is None else line.get(key)
+    pm = os.path.join(PROF, fn)
+    if rec and rec.get("roofline") and rec["roofline"].get("traffic") is None and os.path.exists(pm):
+        pmj = json.load(open(pm))
+        if pmj.get("kernel_source_sha16") == sha:
+            rec["roofline"]["traffic"] = pmj["hbm_bytes_per_launch"]
+            rec["roofline"]["traffic_source"] = pmj["source"] + " - same session as this line, filled in by tools/summarize_evidence.py"
+json.dump(line, open(bl, "w"), indent=1)
 
 # ---- bytes vs sparsity
 rows = []
@@ -189,6 +203,8 @@ for t in ("d64", "d96", "d192", "d256"):
     md += ["", f"PMC (all forward dispatches of the tool averaged): {json.dumps({k: round(v, 4) if isinstance(v, float) else v for k, v in d.items()})}",
            f"kernel resources: {meta}", ""]
 open(os.path.join(PROF, f"{tag}_other_head_dims.md"), "w").write("\n".join(md) + "\n")
+if os.path.exists(os.path.join(src, "fp8_p_forms.txt")):
+    shutil.copy(os.path.join(src, "fp8_p_forms.txt"), os.path.join(PROF, f"{tag}_fp8_p_forms.txt"))
 if os.path.exists(os.path.join(src, "power_probe.txt")):
     shutil.copy(os.path.join(src, "power_probe.txt"), os.path.join(PROF, f"{tag}_power_probe.txt"))
 print(open(os.path.join(PROF, f"{tag}_rocprof_summary.md")).read()[:3000])

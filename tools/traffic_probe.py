@@ -1,5 +1,5 @@
 """GPU box: ONE configuration of the headline shape (B1 S75600 H40 D128 bf16) for the bytes-vs-sparsity table (north_star: "rocprof
-HBM GB/s on skipped tiles"): warm-up, then 3 timed steps; run it under `rocprofv3 --pmc ...` passes (tools/evidence_r02.sh) -
+HBM GB/s on skipped tiles"): warm-up, then 3 timed steps; run it under `rocprofv3 --pmc ...` passes (tools/evidence.sh) -
 the LAST three forward-kernel dispatches are the probe's.
 
     --imposed S     banded list of sparsity S (bench.py's lists; thr = -inf)
