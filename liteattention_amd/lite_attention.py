@@ -42,7 +42,7 @@ class LiteAttention:
         self._skip_list: Optional[Tensor] = None   # [2, max_batch, H, Qt, Kt+1] int32
         self._phase = 0                            # index of the buffer the NEXT call reads
         self._shape_key = None                     # what the lists were built for
-        self._must_do_rows = {}                    # tuple(must_do_list) -> device row
+        self._must_do_rows = {}                    # (tokens, block_n, row width, device) -> device row (LRU, _MUST_DO_ROWS_MAX)
         self._last_percentage = 0.0
         self.enable_skipping = enable_skipping
         self.max_batch_size = max_batch_size
@@ -112,7 +112,6 @@ class LiteAttention:
             self._skip_list = self._init_skip_list(query, value, must_skip_list)
             self._shape_key = key
             self._phase = 0
-            self._must_do_rows = {}
             if _verbose():
                 print("[Warning]: reinitialized skip list during the forward pass")
         elif query.shape[0] > self._skip_list.shape[1]:
@@ -126,11 +125,14 @@ class LiteAttention:
     _MUST_DO_ROWS_MAX = 8          # distinct must_do_list values whose device rows are kept (least recently used go first)
 
     def _must_do_device_row(self, must_do_list, query: Tensor, width: int) -> Tensor:
-        key = (0, 0) if must_do_list is None else tuple(must_do_list)   # [0,0] = empty must-do (:267)
+        toks = (0, 0) if must_do_list is None else tuple(must_do_list)   # [0,0] = empty must-do (:267)
+        _, bn = get_tile_sizes(query.shape[-1], query.dtype.itemsize)
+        # the row depends on nothing but (tokens, tile size, row width, device): it survives list re-initialisation, reset and
+        # load_state_dict, so a call captured in a HIP graph never needs the host-to-device copy that builds it
+        key = (toks, bn, width, str(query.device))
         row = self._must_do_rows.pop(key, None)
         if row is None:
-            _, bn = get_tile_sizes(query.shape[-1], query.dtype.itemsize)
-            row = _sl.must_do_row(key, bn, width, query.device)
+            row = _sl.must_do_row(toks, bn, width, query.device)
             while len(self._must_do_rows) >= self._MUST_DO_ROWS_MAX:
                 self._must_do_rows.pop(next(iter(self._must_do_rows)))
         self._must_do_rows[key] = row                                    # (re)inserted last = most recently used
@@ -191,7 +193,6 @@ class LiteAttention:
         self._skip_list = None
         self._phase = 0
         self._shape_key = None
-        self._must_do_rows = {}
         self._last_percentage = 0.0
 
     def set_threshold(self, threshold: float):

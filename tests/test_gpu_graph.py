@@ -1,0 +1,48 @@
+"""GPU: a denoising loop captured in a HIP graph. Nothing on the call path syncs with the host or depends on host state that changes
+between replays EXCEPT the ping-pong phase of the lists (`LiteAttention._phase`, hopper/lite_attention.py:164-204): a captured call
+replays with the read / write list pointers it was captured with, so the unit of capture is TWO consecutive calls (phases 0 and 1) -
+one graph then advances the skip state by two denoising steps per replay, with no Python between the launches (la_fwd itself is a
+memset of the ticket counters + one kernel on the capture stream; the library allocates nothing and keeps no state). The reference
+has no counterpart (one op call per step from Python, flash_fwd_launch_template.h:359); this is the MI355X-side answer to launch-bound
+inner loops: 40 layers x 2 phases of a Wan2.x step can sit in one graph."""
+import pytest
+import torch
+
+from helpers import structured_qkv
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+def test_two_steps_per_replay_equal_the_eager_loop(dtype):
+    import liteattention_amd as L
+    B, S, H, D, thr, steps = 1, 2304, 4, 128, -3.0, 8
+    cast = (lambda x: x.to(torch.float8_e4m3fn)) if dtype == "fp8" else (lambda x: x)
+    data = [[cast(x.cuda()) for x in structured_qkv(B, S, H, D, seed=400, alpha=9.0 - 0.3 * t)] for t in range(steps)]
+    # eager loop
+    att_e = L.LiteAttention(threshold=thr, max_batch_size=B)
+    outs_e = [att_e(*data[t], return_softmax_lse=True) for t in range(steps)]
+    # graph: steps 0, 1 eagerly on the current stream (allocates the lists and the must-do row; they are the warm-up), then one graph of two calls
+    att_g = L.LiteAttention(threshold=thr, max_batch_size=B)
+    for t in (0, 1):
+        o, lse = att_g(*data[t], return_softmax_lse=True)
+        assert torch.equal(o, outs_e[t][0])
+    static = [[torch.empty_like(x) for x in data[0]] for _ in range(2)]
+    phase0 = att_g._phase
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        o0, l0 = att_g(*static[0], return_softmax_lse=True)
+        o1, l1 = att_g(*static[1], return_softmax_lse=True)
+    assert att_g._phase == phase0                         # two calls: the host-side phase is back where the graph starts
+    for t in range(2, steps, 2):
+        for i in range(2):
+            for buf, src in zip(static[i], data[t + i]):
+                buf.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(o0, outs_e[t][0]) and torch.equal(l0, outs_e[t][1]), t
+        assert torch.equal(o1, outs_e[t + 1][0]) and torch.equal(l1, outs_e[t + 1][1]), t + 1
+    n = int(att_e._skip_list[..., 0].max())
+    live = torch.arange(n + 1, device="cuda") <= att_e._skip_list[..., 0:1]
+    assert bool(((att_g._skip_list[..., : n + 1] == att_e._skip_list[..., : n + 1]) | ~live).all())     # same skip state after 8 steps
+    assert att_g.get_skip_fraction() == att_e.get_skip_fraction() > 0.05
