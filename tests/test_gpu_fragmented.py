@@ -132,3 +132,65 @@ def test_hand_built_alternating_list_through_flash_attn_func(dtype, D, thr):
     if thr == float("-inf"):
         assert orc.walk_tiles(wr[0, 0, 0].tolist()) == kept
         assert orc.walk_tiles(wr[1, 1, 1].tolist()) == [t for pr in kept2 for t in pr]
+
+
+def _random_row(kt, g, keep_first=True):
+    """A random VALID read-list row: descending inclusive ranges, even length; starts with tile kt - 1 when asked."""
+    n_cuts = int(torch.randint(0, max(1, kt // 2), (1,), generator=g))
+    cuts = sorted(set(torch.randint(0, kt, (2 * n_cuts,), generator=g).tolist()), reverse=True)
+    if len(cuts) % 2:
+        cuts = cuts[:-1]
+    pairs = [(cuts[i], cuts[i + 1]) for i in range(0, len(cuts), 2)]
+    ranges, last_end = [], kt
+    for s_, e_ in pairs:                                  # keep them disjoint and strictly descending
+        s_ = min(s_, last_end - 1)
+        if s_ < 0 or e_ > s_:
+            continue
+        ranges.append((s_, e_)); last_end = e_
+    if keep_first and (not ranges or ranges[0][0] != kt - 1):
+        ranges = [(kt - 1, kt - 1)] + [r for r in ranges if r[0] < kt - 1]
+    if not ranges:
+        ranges = [(kt - 1, 0)]
+    return [2 * len(ranges)] + [t for r in ranges for t in r]
+
+
+@pytest.mark.parametrize("dtype,D", [("bf16", 128), ("fp8", 128), ("bf16", 64), ("bf16", 96), ("bf16", 256), ("fp16", 192)])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_random_valid_lists_with_must_do_ranges_match_the_oracle(dtype, D, seed):
+    """Every (batch, head, q-tile) row gets its OWN random valid list (0 ... Kt / 2 ranges of random lengths; some rows do not start at
+    tile Kt - 1, so the ragged last key tile is masked away from the first walked position), a multi-range must-do list keeps the
+    serial writer in play (mainloop...:154-162), Sq != Sk, GQA, ragged lengths. One call at thr = -1.5: O, LSE and the write list
+    against the oracle on the same list. Complements the generator-driven tests above: nothing here is structured."""
+    L, orc, bm, bn, cast, p_round, tol, lse_tol = _setup(dtype, D)
+    B, Sq, Sk, H, Hk, thr = 2, 1100, 4000 - 13, 4, 2, -1.5
+    Qt, Kt = math.ceil(Sq / bm), math.ceil(Sk / bn)
+    g = torch.Generator().manual_seed(100 + seed)
+    u = torch.randn(B, 1, Hk, D, generator=g)
+    u = u / u.norm(dim=-1, keepdim=True)
+    gain = torch.linspace(0.1, 1.0, Sk).view(1, Sk, 1, 1)                         # late keys (walked first) score highest: flags fire further down
+    q = cast(9.0 * u.repeat_interleave(H // Hk, dim=2) + 0.5 * torch.randn(B, Sq, H, D, generator=g))
+    k = cast(9.0 * gain * u + 0.5 * torch.randn(B, Sk, Hk, D, generator=g))
+    v = cast(torch.randn(B, Sk, Hk, D, generator=g))
+    lists = torch.zeros(2, B, H, Qt, Kt + 1, dtype=torch.int32)
+    for b in range(B):
+        for h in range(H):
+            for m in range(Qt):
+                row = _random_row(Kt, g, keep_first=(b + h + m) % 4 != 0)
+                lists[0, b, h, m, : len(row)] = torch.tensor(row, dtype=torch.int32)
+    must_do_tokens = [Sk - 200, Sk - 900, 1500, 1100, 300, 0]                        # three ranges, descending (README.md:180-191)
+    md_row = orc.expand_must_do_ref(must_do_tokens, bn, Kt + 1)
+    dl = lists.cuda()
+    out, lse = L.flash_attn_func(q.cuda(), k.cuda(), v.cuda(), attn_read_list=dl[0], attn_write_list=dl[1],
+                                 attn_must_do_list=md_row.cuda(), thr=thr, return_softmax_lse=True)
+    margins = torch.empty(B, H, Qt, Kt)
+    wr_orc = torch.zeros_like(lists[1])
+    o_ref, lse_ref, n_tiles = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=lists[0], write_list=wr_orc,
+                                             must_do_list=md_row, thr=thr, margins=margins, p_round=p_round)
+    assert n_tiles == orc.listed_tiles(lists[0])
+    assert (out.float().cpu() - o_ref).abs().max().item() <= tol(o_ref)
+    assert (lse.cpu() - lse_ref).abs().max().item() <= lse_tol
+    wr = dl[1].cpu()
+    bad, border = _compare_lists(orc, lists[0], wr, wr_orc, margins, thr, B)
+    assert bad == 0 and border <= 3
+    assert torch.equal(dl[0].cpu(), lists[0])
+    assert orc.listed_tiles(wr) < orc.listed_tiles(lists[0])                          # and the call really dropped tiles
