@@ -70,7 +70,7 @@ def must_do_row(must_do_list: Sequence[int], block_n: int, width: int, device) -
     row = [len(must_do_list)]
     for i, tok in enumerate(must_do_list):
         row.append(cdiv(tok, block_n) if i % 2 == 0 else tok // block_n)
-    if len(row) > width:
+    if len(row) > max(width, 3):          # (a single key tile: the list row is 2 ints wide, the must-do row still [len, start, end])
         raise ValueError("must_do_list has more entries than k tiles")
     row += [0] * (max(width, 3) - len(row))
     return torch.tensor(row, dtype=torch.int32, device=device)

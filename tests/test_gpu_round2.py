@@ -173,6 +173,43 @@ def test_key_sequences_shorter_than_a_dma_piece(dtype, Sk, H, Hk):
     assert (lse.cpu() - lse_ref).abs().max().item() <= (fp8_lse_tol() if dtype == "fp8" else 1e-3)
 
 
+@pytest.mark.parametrize("dtype,D", [("bf16", 128), ("fp8", 128), ("bf16", 192), ("bf16", 64)])
+@pytest.mark.parametrize("Sk", [1, 13, 64])
+def test_a_single_key_tile_through_the_class(dtype, D, Sk):
+    """Key sequences of at most one k-tile through ``LiteAttention.__call__`` (lists walked, dynamic work distribution), three steps.
+    The list rows are 2 ints wide there - too short for the one range [0, 0] they describe ([len, start, end]; the reference's format
+    has no room for it and its writer stores past the row): the reader takes the missing end as 0, the writer counts but does not
+    store the entry behind the row (kernels and oracle alike). Regression of round 3 (tools/fuzz_parity.py): the host raised
+    'must_do_list has more entries than k tiles' for the default must-do row, so ``LiteAttention`` could not be called at all."""
+    import liteattention_amd as L
+    from oracle import oracle as orc
+    from test_gpu_parity import _compare_lists
+    es = 1 if dtype == "fp8" else 2
+    bm, bn = _tiles(D, es)
+    B, Sq, H, thr = 2, 300, 2, -1.0
+    Qt, Kt = -(-Sq // bm), 1
+    cast = (lambda x: x.to(torch.float8_e4m3fn)) if dtype == "fp8" else (lambda x: x.bfloat16())
+    att = L.LiteAttention(threshold=thr, max_batch_size=B)
+    md_row = orc.expand_must_do_ref([0, 0], bn, 3)
+    margins = torch.empty(B, H, Qt, Kt)
+    for step in range(3):
+        g = torch.Generator().manual_seed(Sk * 7 + step)
+        q, k, v = cast(torch.randn(B, Sq, H, D, generator=g)), cast(torch.randn(B, Sk, H, D, generator=g)), cast(torch.randn(B, Sk, H, D, generator=g))
+        rd_idx = att._phase if att._skip_list is not None else 0
+        out, lse = att(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
+        assert att._skip_list.shape[-1] == 2
+        rd, wr = att._skip_list[rd_idx].cpu(), att._skip_list[1 - rd_idx].cpu()
+        wr_orc = torch.zeros_like(wr)
+        o_ref, lse_ref, n_tiles = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=rd, write_list=wr_orc, must_do_list=md_row, thr=thr,
+                                                 margins=margins, p_round=fp8_p_round() if dtype == "fp8" else True)
+        assert n_tiles == B * H * Qt
+        tol = (0.05 * o_ref.abs().max().item() + 2e-2) if dtype == "fp8" else 2.0 ** -7 * o_ref.abs().max().item() + 1e-3
+        assert (out.float().cpu() - o_ref).abs().max().item() <= tol
+        assert (lse.cpu() - lse_ref).abs().max().item() <= (fp8_lse_tol() if dtype == "fp8" else 1e-3)
+        bad, _ = _compare_lists(orc, rd, wr, wr_orc, margins, thr, B)
+        assert bad == 0 and torch.equal(wr[..., 1], torch.zeros_like(wr[..., 1]))
+
+
 # ------------------------------------------------------------------------------------------ f3: must_skip_list
 @pytest.mark.parametrize("with_must_do", [False, True])
 def test_must_skip_list_through_the_kernel(with_must_do):

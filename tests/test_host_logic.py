@@ -179,6 +179,18 @@ def test_must_do_row_is_cached_and_lse_flag_forwarded(rec):
     assert rec.calls[1]["must_do"] is rec.calls[0]["must_do"]            # no per-call H2D / repeat (B-6)
 
 
+def test_a_single_key_tile_still_gets_a_three_int_must_do_row(rec):
+    """Key sequences of at most one k-tile (Sk <= 64): the list rows are [len, start] + 1 = 2 ints wide, the 1-D must-do row the kernel
+    reads is still [len, start, end] (found by tools/fuzz_parity.py: LiteAttention raised 'more entries than k tiles' for Sk <= 64)."""
+    att = L.LiteAttention(max_batch_size=1)
+    q = torch.zeros(1, 300, 1, 128, dtype=torch.bfloat16)
+    k = torch.zeros(1, 13, 1, 128, dtype=torch.bfloat16)
+    att(q, k, k)
+    assert att._skip_list.shape[-1] == 2 and rec.calls[0]["must_do"].tolist() == [2, 0, 0]
+    with pytest.raises(ValueError, match="more entries than k tiles"):
+        att(q, k, k, must_do_list=[12, 8, 4, 0])                            # two ranges cannot fit one tile
+
+
 def test_must_skip_list_readme_example(rec):
     """README.md:193-197 `must_skip_list=[80, 40]`-style call must not raise (Appendix B-4)."""
     att = L.LiteAttention(max_batch_size=1)
