@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-MFMA_FP8_PEAK_TFLOPS = 5000.0      # dense fp8 peak: the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 the fp8 kernel issues (unit scales)
+MFMA_FP8_PEAK_TFLOPS = 5000.0      # dense fp8 peak: the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 the fp8 kernel issues
 SPARSITIES = (0.0, 0.21, 0.42, 0.57, 0.77)
 HEADLINE_SPARSITY = 0.42
 

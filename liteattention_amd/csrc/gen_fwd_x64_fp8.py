@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Generates la_fwd_x64_fp8_body.inc: hand-scheduled gfx950 main loop of the fp8 (e4m3) / head_dim-128 QK-Skip forward with
 ONE wave per SIMD and 64 query rows per wave (q-tile 256 x k-tile 64) - the structure of gen_fwd_x64.py (bf16) on the
-block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales (2x the bf16 MFMA rate; the non-scaled
-v_mfma_f32_32x32x16_fp8_fp8 runs at the bf16 rate). One instruction contracts 64 indices, 32 bytes of A and of B per lane; the
+block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 (2x the bf16 MFMA rate; the non-scaled v_mfma_f32_32x32x16_fp8_fp8 runs at the
+bf16 rate). The E8M0 scales are 2^0 everywhere except on P in the default body, which is block-scaled per (row, tile): "mx" below. One instruction contracts 64 indices, 32 bytes of A and of B per lane; the
 contraction index is permuted freely (A and B only have to agree), which lets P go from the S^T accumulators straight into
 the B operand. Operand layout: K rows / Q fragments as 2 x 16-byte chunks per 64-wide contraction step, V^T tiles
 pre-transposed by la_prep_v_fp8 so that the PV operand is two plain ds_read_b128).
@@ -17,11 +17,14 @@ Register file (per lane):  AGPR  a[0:127]   O^T  (2 q-blocks x 4 d-blocks x 16)
                            VGPR  v[0:63] / v[64:127]  S^T ping / pong, q-block major: (q-block, key block, 16). P (e4m3) is
                                  compacted IN PLACE into the first 8 registers of a q-block's 32 = the B operand of PV
                                  v[128:159] the four V^T fragments of the tile (A operand of PV, 8 registers each)
+Three bodies are generated (LA_X64F8_OPT): the default ("lin" + "mx": the e4m3 byte of P computed directly and block-scaled, row sums
+from the matrix pipe), "exp" (v_exp_f32 + hardware rounding, row sums from the matrix pipe) and "lvalu" (that with fp32 row sums on
+the vector unit: the reference's arithmetic); the comments at LMFMA / LIN / MX below say what each changes. The step, in "exp" form:
 Step i:  phase 1   8 MFMA  S_nxt = K(i+1) Q^T  ||  rest of P(i) = exp2(S c - m_ref c + OFF), row sums, e4m3 compaction;
                                                     LDS-DMA of V^T(i+1), K(i+3); the 8 V^T fragment reads
          phase 2   8 MFMA  O^T += V^T(i) P(i)^T ||  K(i+2) fragment reads -> AGPRs; next step's tile lookup / DMA bases;
                                                     row max of S_nxt, running max, skip vote, lazy-rescale test; start of P(i+1)
-P offset: the reference scales P by 2^8 before the e4m3 cast (softmax.h:85-87). With the lazy rescale P can reach 2^tau, so
+P offset ("exp" / "lvalu"): the reference scales P by 2^8 before the e4m3 cast (softmax.h:85-87). With the lazy rescale P can reach 2^tau, so
 OFF = 8 - tau with tau = 2: P 2^6 <= 256 < 448 (e4m3 max). e4m3 rounding is scale-invariant away from the subnormal end, so
 results equal the offset-8 ones except for P < 2^-12 (absolute 2.4e-4 of a weight <= 1).
 """

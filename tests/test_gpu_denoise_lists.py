@@ -8,7 +8,7 @@ device (liteattention_amd/selfcheck.py), each citing the reference lines it foll
         bf16 |O - ref| <= 2^-7 max|ref| + 1e-4 (one bf16 ulp at the maximum: these rows are peaked — a few keys carry 5-10 % of
         the weight each — and under the lazy rescale the bf16 rounding of a dominant P does not vanish as it does for P = 2^0:
         tests/test_gpu_fragmented.py docstring; measured 0.0031 at max|ref| 0.52), |LSE - ref| <= 2e-4;
-        fp8 <= 0.05 max|ref| + 1e-3, |LSE - ref| <= 2e-2 (row sums of the e4m3-rounded P, helpers.fp8_lse_tol)
+        fp8 <= 0.05 max|ref| + 1e-3, |LSE - ref| <= 2e-2 (row sums of the encoded P, helpers.fp8_lse_tol)
   * step-49 write list: for 24 sampled (head, q-tile) rows the skip vote of every walked tile (softmax.h:190-194) and the
     writer state machine (mainloop...:142-192) restated in torch; rows equal except those with a tile within 1e-3 of thr
   * walked(write) is a subset of walked(read) for ALL 11 840 rows (a skipped tile is never revisited), both start at Kt-1

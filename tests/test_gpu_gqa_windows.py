@@ -242,9 +242,9 @@ def test_longest_supported_key_sequence_and_the_typed_error_beyond_it(dtype):
     ref = torch.softmax(sc, -1) @ vf
     tol = 0.05 * ref.abs().max().item() + 2e-2 if dtype == "fp8" else 2.0 ** -7 * ref.abs().max().item() + 1e-3
     assert (out.float()[0, :, 0] - ref).abs().max().item() <= tol
-    # fp8 default: row sums of the e4m3-rounded P. Over 288 k keys the rounding noise averages out but its BIAS does not: P is
-    # log-uniform inside an e4m3 rounding interval, so round-to-nearest loses (step / value)^2 / 12 ~ 7e-4 of the sum (measured
-    # 6e-4 .. 1e-3, every row low); LA_FLAG_EXACT_ROWSUM has neither (tests/test_gpu_fp8.py runs both modes)
+    # fp8 default: row sums of the encoded P. Over 288 k keys the noise averages out but its BIAS does not (log-linear encoding: about
+    # -3e-4; hardware rounding under LA_FLAG_EXACT_EXP: P is log-uniform inside an e4m3 rounding interval, so round-to-nearest loses
+    # (step / value)^2 / 12 ~ 7e-4 of the sum, every row low); LA_FLAG_EXACT_ROWSUM has neither (tests/test_gpu_fp8.py runs all three)
     assert (lse[0, 0] - torch.logsumexp(sc, -1)).abs().max().item() <= (2.5e-3 if dtype == "fp8" else 1e-3)
     assert att.get_skip_fraction() == 0.0
     too_long = torch.zeros(1, 40000 * 64, H, D, dtype=q.dtype, device="cuda")
@@ -256,7 +256,7 @@ def test_longest_supported_key_sequence_and_the_typed_error_beyond_it(dtype):
 @pytest.mark.parametrize("dtype,D", [("bf16", 128), ("bf16", 64), ("fp8", 128)])
 @pytest.mark.parametrize("B,H,S", [(1, 5, 2400), (3, 3, 700), (1, 1, 9000), (2, 7, 260)])
 def test_dynamic_work_distribution_computes_every_item_exactly(dtype, D, B, H, S):
-    """Per-XCD ticket queues + stealing must hand out every (batch, head, q-tile) once: head groups of 4 with a short last
+    """Per-XCD ticket queues + stealing must hand out every (batch, head, q-tile) once: head groups of 8 with a short last
     group (B*H = 5, 9, 1, 14), chunks with a short last chunk, fewer items than workgroups. `out` is pre-filled with NaN
     (a fresh allocation could still hold an earlier, identical result), and the result must equal the static map's bit for bit."""
     L = _L()

@@ -9,11 +9,11 @@ hopper/tests/test_flash_attn.py:152-177; property style of test_gpu_parity.py::t
   * the write list equals the read list at thr = -inf (nothing new may be dropped; bit-exact);
   * dynamic (ticket queues, persistent workgroups) == static (one workgroup per item, XCD map) bit-exactly: O, LSE, lists;
   * >= 256 sampled query rows per checked head against an fp32 torch attention over exactly the listed keys:
-        bf16: |O - ref| <= 2^-8 max|ref| + 1e-4      fp8: |O - ref| <= 0.05 max|ref| + 1e-3 (P is rounded to e4m3)
+        bf16: |O - ref| <= 2^-8 max|ref| + 1e-4      fp8: |O - ref| <= 0.05 max|ref| + 1e-3 (P is an 8-bit quantity)
         LSE:  |LSE - ref| <= 2e-4 (bf16, and fp8 with LA_FLAG_EXACT_ROWSUM: one missing 64-key tile of a 43 k-key row moves the LSE
-              by 1.5e-3, so a skipped, doubled or mis-masked tile cannot hide); fp8 default <= 2.5e-3: the row sums are those of
-              the e4m3-rounded P, whose rounding noise averages out over a long row but whose bias (about -7e-4: P is log-uniform
-              inside a rounding interval) does not. The walk is the same code in both fp8 modes.
+              by 1.5e-3, so a skipped, doubled or mis-masked tile cannot hide); fp8 default and LA_FLAG_EXACT_EXP <= 2.5e-3: the row sums are those
+              of the ENCODED P, whose noise averages out over a long row but whose bias (about -3e-4 / -7e-4) does not. The walk is
+              the same code in all three fp8 forms.
 """
 import pytest
 import torch
