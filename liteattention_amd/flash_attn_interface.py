@@ -90,7 +90,10 @@ def kernel_head_dim(head_dim: int, element_size: int, flags: Optional[int] = Non
 
 
 def get_tile_sizes(head_dim: int, element_size: int) -> Tuple[int, int]:
-    """(kBlockM, kBlockN) of the gfx950 kernel that serves this head_dim — the single source for skip-list geometry."""
+    """(kBlockM, kBlockN) of the gfx950 kernel that serves this head_dim — the single source for skip-list geometry.
+    e4m3 above head_dim 128 is served by the bf16 kernel of that head dim (``mha_fwd``): its tiles."""
+    if element_size == 1 and head_dim > 128:
+        element_size = 2
     flags = _cabi.default_flags()
     return _cabi.get_tile_sizes(kernel_head_dim(head_dim, element_size, flags), element_size, flags)
 
@@ -187,6 +190,24 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
         softmax_scale = D ** -0.5
 
     host_flags = _cabi.default_flags()                       # the environment is read ONCE per call
+    if is_fp8 and D > 128:
+        # e4m3 at head dims 192 / 256 (and the padded sizes between): no fp8 kernel is built there (the reference's fp8
+        # instantiations are compiled out of its default build, hopper/setup.py:55). Served by the bf16 kernel of that head dim
+        # on up-converted operands - one extra pass over q, k, v. e4m3 values are exact in bf16, so S is the fp8 kernel's S; the
+        # descales ride on q (q_descale * k_descale) and v (v_descale), each rounded to bf16 once (exact when they are 1 or
+        # powers of two); P is bf16, i.e. MORE precise than an fp8 kernel's. Lists use the bf16 kernel's tiles (get_tile_sizes).
+        g = H // Hk
+
+        def per_head(t):                                     # (B, Hk) -> (B, 1, H, 1)
+            return t.repeat_interleave(g, dim=1)[:, None, :, None]
+        qs = None if (descales[0] is None and descales[1] is None) else \
+            (1.0 if descales[0] is None else descales[0]) * (1.0 if descales[1] is None else descales[1])
+        q16 = q.to(torch.bfloat16) if qs is None else (q.float() * per_head(qs)).to(torch.bfloat16)
+        v16 = v.to(torch.bfloat16) if descales[2] is None else (v.float() * descales[2][:, None, :, None]).to(torch.bfloat16)
+        return mha_fwd(q16, k.to(torch.bfloat16), v16, out=out, softmax_scale=softmax_scale, attn_read_list=attn_read_list,
+                       attn_must_do_list=attn_must_do_list, attn_write_list=attn_write_list, thr=thr, _must_do_is_1d=_must_do_is_1d,
+                       _q_windows=_q_windows, _window_hook=_window_hook, _static_sched=_static_sched,
+                       _flags=_flags & _cabi.LA_FLAG_EXACT_RESCALE)
     D_kernel = kernel_head_dim(D, q.element_size(), host_flags)
     if D_kernel != D:
         # head_dim between the instantiated sizes: zero-pad the last dim (one extra pass over q, k, v; exact, see
@@ -344,9 +365,21 @@ def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
                 raise RuntimeError(f"{name} must be a float32 tensor of shape (batch_size, nheads_k) on the input device")
         descales.append(t)
     out_dtype = torch.bfloat16 if is_fp8 else q.dtype                                              # :859-863
+    if is_fp8 and D > 128:
+        # as in mha_fwd: e4m3 above head_dim 128 runs on the bf16 kernel of that head dim after an up-conversion pass; the per-(sequence,
+        # K/V head) descales are spread over the packed rows on the device (no host sync: the output sizes are the packed totals)
+        g = H // Hk
+        lens_q = (cu_seqlens_q[1:] - cu_seqlens_q[:-1]).long()
+        lens_k = (cu_seqlens_k[1:] - cu_seqlens_k[:-1]).long()
+        qs = None if (descales[0] is None and descales[1] is None) else \
+            (1.0 if descales[0] is None else descales[0]) * (1.0 if descales[1] is None else descales[1])
+        q16 = q.to(torch.bfloat16) if qs is None else \
+            (q.float() * torch.repeat_interleave(qs.repeat_interleave(g, dim=1), lens_q, dim=0, output_size=Tq)[:, :, None]).to(torch.bfloat16)
+        v16 = v.to(torch.bfloat16) if descales[2] is None else \
+            (v.float() * torch.repeat_interleave(descales[2], lens_k, dim=0, output_size=Tk)[:, :, None]).to(torch.bfloat16)
+        return _mha_fwd_varlen(q16, k.to(torch.bfloat16), v16, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, None, None, None,
+                               softmax_scale, attn_read_list, attn_write_list, attn_must_do_list, thr, _must_do_is_1d)
     D_kernel = kernel_head_dim(D, q.element_size())
-    if D_kernel != D and is_fp8:
-        raise NotImplementedError("fp8 varlen is built for head_dim 128")
     if D_kernel != D:
         if out is not None and (out.dtype != q.dtype or tuple(out.shape) != (Tq, H, D) or out.stride(-1) != 1):
             raise RuntimeError("out must have the input dtype, shape (total_q, nheads, headdim) and a contiguous last dimension")

@@ -117,9 +117,9 @@ def test_fp8_errors():
     qb = torch.randn(1, 256, 2, 128, device="cuda").bfloat16()
     with pytest.raises(RuntimeError, match="only supported for fp8"):
         L.flash_attn_func(qb, qb, qb, q_descale=torch.ones(1, 2, device="cuda"))
-    q192 = torch.randn(1, 256, 2, 192, device="cuda").to(F8)
+    q272 = torch.randn(1, 256, 2, 272, device="cuda").to(F8)
     with pytest.raises(RuntimeError, match="head_size"):
-        L.flash_attn_func(q192, q192, q192)                                                 # fp8 head_dim > 128 not built
+        L.flash_attn_func(q272, q272, q272)                                                 # head_dim > 256: no kernel for any type
     q72 = torch.randn(1, 256, 2, 72, device="cuda").bfloat16().view(torch.int16)[..., :72].view(torch.bfloat16)
     with pytest.raises(RuntimeError, match="multiple of 16"):
         L.flash_attn_func(q72.to(F8), q72.to(F8), q72.to(F8))                               # fp8: head_size % 16 (:854-856)
@@ -157,4 +157,45 @@ def test_fp8_running_max_that_grows_late_in_the_walk(gain):
         assert (out.float().cpu() - o_ref).abs().max().item() <= _tol(o_ref)
         assert (lse.cpu() - lse_ref).abs().max().item() <= fp8_lse_tol()
         bad, _ = _compare_lists(orc, rd, wr, wr_orc, margins, -1.0, B)
+        assert bad == 0
+
+
+@pytest.mark.parametrize("D", [192, 256, 160])
+def test_fp8_above_head_dim_128_runs_on_the_bf16_kernel_of_that_head_dim(D):
+    """No fp8 kernel is built above head_dim 128 (the reference's fp8 instantiations are compiled out of its default build,
+    hopper/setup.py:55): the host up-converts e4m3 -> bf16 (exact), puts q_descale * k_descale on q and v_descale on v, and runs the
+    bf16 kernel of that head dim with ITS tiles. Dense with GQA + descales against the oracle with fp32 P (the result is more precise
+    than an fp8 kernel's: P is bf16), then three steps of lists with power-of-two descales (exact) against the oracle."""
+    import liteattention_amd as L
+    from oracle import oracle as orc
+    from test_gpu_parity import _compare_lists
+    bm, bn = L.get_tile_sizes(D, 1)
+    assert (bm, bn) == L.get_tile_sizes(D, 2)
+    g = torch.Generator().manual_seed(D)
+    B, Sq, Sk, H, Hk = 2, 300, 1000, 4, 2
+    q, k, v = torch.randn(B, Sq, H, D, generator=g).to(F8), torch.randn(B, Sk, Hk, D, generator=g).to(F8), torch.randn(B, Sk, Hk, D, generator=g).to(F8)
+    qd, kd, vd = [0.5 + torch.rand(B, Hk, generator=g) for _ in range(3)]
+    out, lse = L.flash_attn_func(q.cuda(), k.cuda(), v.cuda(), q_descale=qd.cuda(), k_descale=kd.cuda(), v_descale=vd.cuda(), return_softmax_lse=True)
+    assert out.dtype == torch.bfloat16
+    o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, p_round=False, q_descale=qd, k_descale=kd, v_descale=vd)
+    assert (out.float().cpu() - o_ref).abs().max().item() <= 2.0 ** -6 * o_ref.abs().max().item() + 1e-3    # bf16 out + descales rounded onto q, v
+    assert (lse.cpu() - lse_ref).abs().max().item() <= 2e-2
+    # lists over steps: descales that are powers of two ride on q / v exactly
+    S, thr = 1536, -3.0
+    Qt, Kt = -(-S // bm), -(-S // bn)
+    att = L.LiteAttention(threshold=thr, max_batch_size=1)
+    md_row = orc.expand_must_do_ref([0, 0], bn, Kt + 1)
+    margins = torch.empty(1, 2, Qt, Kt)
+    qd2, kd2, vd2 = torch.tensor([[2.0, 0.5]]), torch.tensor([[0.5, 1.0]]), torch.tensor([[4.0, 0.25]])
+    for step in range(3):
+        q, k, v = [x.to(F8) for x in structured_qkv(1, S, 2, D, seed=310 + D, alpha=9.0 - step, dtype=torch.float32)]
+        rd_idx = att._phase if att._skip_list is not None else 0
+        out, lse = att(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True, q_descale=qd2.cuda(), k_descale=kd2.cuda(), v_descale=vd2.cuda())
+        rd, wr = att._skip_list[rd_idx].cpu(), att._skip_list[1 - rd_idx].cpu()
+        wr_orc = torch.zeros_like(wr)
+        o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=rd, write_list=wr_orc, must_do_list=md_row, thr=thr,
+                                           margins=margins, p_round=True, q_descale=qd2, k_descale=kd2, v_descale=vd2)
+        assert (out.float().cpu() - o_ref).abs().max().item() <= 2.0 ** -7 * o_ref.abs().max().item() + 1e-3
+        assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
+        bad, _ = _compare_lists(orc, rd, wr, wr_orc, margins, thr, 1)
         assert bad == 0
