@@ -11,7 +11,7 @@ def test_design_tables_are_generated_from_the_committed_profiles():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_design_tables.py"), "r03", "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     text = open(os.path.join(ROOT, "DESIGN.md")).read()
-    for name in ("headline", "rocprof_bf16", "rocprof_fp8", "traffic", "sched_sweep", "denoise50"):
+    for name in ("headline", "rocprof_bf16", "rocprof_fp8", "traffic", "real_gap", "fp8_forms", "sched_sweep", "denoise50"):
         body = text.split(f"<!-- GEN:{name} -->")[1].split(f"<!-- /GEN:{name} -->")[0]
         assert body.strip(), f"generated block {name} is empty"
 

@@ -44,8 +44,9 @@ def test_g1_reference_tile_table_is_recorded_and_build_table_comes_from_library(
     assert L.get_tile_sizes(192, 2) == L.get_tile_sizes(256, 2) == (128, 64)     # the reference's 192 / 256 instantiations
     with pytest.raises(RuntimeError):
         L.get_tile_sizes(320, 2)                           # above 256: nothing instantiated
+    assert L.get_tile_sizes(192, 1) == L.get_tile_sizes(192, 2)    # e4m3 above 128: the host runs the bf16 kernel of that head dim
     with pytest.raises(RuntimeError):
-        L.get_tile_sizes(192, 1)                           # fp8: head_dim 128 only
+        L.get_tile_sizes(320, 1)
     with pytest.raises(RuntimeError):
         L.get_tile_sizes(100, 2)                           # not a multiple of 8 (flash_api.cpp:854)
 

@@ -92,6 +92,27 @@ def blocks(tag):
             rows.append(f"| {x['list']} | {x['sparsity']:.3f} | {x['kernel_ms_under_pmc']:.2f} | {x['executed_tflops']:.0f} | {x['hbm_read_GB']:.1f} | {x['hbm_write_GB']:.2f} | "
                         f"{100 * (x['l2_hit_rate'] or 0):.1f} % | {100 * (x['mfma_util'] or 0):.1f} % | {(x['clock_GHz'] or 0):.2f} | {(x['hbm_GBps'] or 0):.0f} |")
         out["traffic"] = rows
+        by = {x["list"]: x for x in tr["rows"]}
+        if all(k in by for k in ("imposed 0.42", "imposed 0.77", "real -4.22", "real -2.46")):
+            g44 = 100 * (by["real -4.22"]["executed_tflops"] / by["imposed 0.42"]["executed_tflops"] - 1)
+            g78 = 100 * (by["real -2.46"]["executed_tflops"] / by["imposed 0.77"]["executed_tflops"] - 1)
+            out["real_gap"] = [f"Against the banded list of nearest sparsity the real lists are at {g44:+.1f} % (44 %) and {g78:+.1f} % (78 %) executed TFLOP/s in "
+                               f"this session, at {by['real -4.22']['clock_GHz']:.2f} / {by['real -2.46']['clock_GHz']:.2f} GHz against "
+                               f"{by['imposed 0.42']['clock_GHz']:.2f} / {by['imposed 0.77']['clock_GHz']:.2f} (round 2: -6 % / -10 %)."]
+    pf = os.path.join(PROF, f"{tag}_fp8_p_forms.txt")
+    if os.path.exists(pf):
+        txt = open(pf).read()
+        tf = {m.group(1): (float(m.group(2)), float(m.group(3))) for m in re.finditer(r"P form (\w+): .*?s=0.0: [0-9.]+ ms (\d+) TF \| s=0.42: [0-9.]+ ms (\d+) TF", txt)}
+        err = {(m.group(1), m.group(2)): (m.group(3), m.group(4), m.group(5)) for m in
+               re.finditer(r"(default|exp|rowsum)\s+real lists thr (-[0-9.]+): max\|O-ref\| ([0-9.]+) \(tol ([0-9.]+)\)\s+max\|LSE-ref\| ([0-9.]+)", txt)}
+        if all(k in tf for k in ("default", "exp", "rowsum")):
+            base = tf["rowsum"][1]
+            rows = ["| form of P | C3 dense / imposed 42 %, TFLOP/s | vs the reference's form | real step-49 lists thr -4.22 / -2.46: max abs O error (bound), max abs LSE error |", "|---|---|---|---|"]
+            for key, name in (("rowsum", "`LA_FLAG_EXACT_ROWSUM` (the reference's arithmetic)"), ("exp", "`LA_FLAG_EXACT_EXP`"), ("default", "**default** (block-scaled log-linear encoding)")):
+                e1, e2 = err.get((key, "-4.22")), err.get((key, "-2.462"))
+                es = f"{e1[0]} ({e1[1]}), {e1[2]} / {e2[0]} ({e2[1]}), {e2[2]}" if e1 and e2 else "n/a"
+                rows.append(f"| {name} | {tf[key][0]:.0f} / {tf[key][1]:.0f} | {100 * (tf[key][1] / base - 1):+.1f} % | {es} |")
+            out["fp8_forms"] = rows
     if ss:
         rows = ["| list | variant (chunk C, heads interleaved G) | ms | executed TFLOP/s | L2 fills GB | L2 hit | clock GHz | MFMA busy |", "|---|---|---|---|---|---|---|---|"]
         for thr in sorted({x["thr"] for x in ss["rows"]}):
