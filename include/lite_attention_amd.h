@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LA_ABI_VERSION 4
+#define LA_ABI_VERSION 5   /* 5 = 4 + la_blockmask_to_lists, skip lists and fp8 with cu_seqlens, LA_FLAG_EXACT_ROWSUM / LA_FLAG_EXACT_EXP, LA_DTYPE_FP32 (la_combine); la_fwd_args unchanged */
 
 typedef enum la_status {
     LA_OK = 0,

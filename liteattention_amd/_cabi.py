@@ -13,7 +13,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # LITEATTENTION_AMD_LIB overrides the in-tree location (deployment / tests of the failure path)
 LIB_PATH = os.environ.get("LITEATTENTION_AMD_LIB") or os.path.join(_PKG_DIR, "libliteattention_amd.so")
 
-LA_ABI_VERSION = 4
+LA_ABI_VERSION = 5
 LA_DTYPE_BF16, LA_DTYPE_FP16, LA_DTYPE_FP8_E4M3, LA_DTYPE_FP32 = 0, 1, 2, 3
 
 LA_OK = 0
