@@ -455,6 +455,8 @@ def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True, st=0):
         if do_v:
             o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {V_REGION + vbuf_imm + 4096 * grp}")
             o += [f"    global_load_lds_dwordx4 {v(LV[4 * grp + j])}, {sr(VBS[st])} offset:{1024 * j}{DMA_POLICY}" for j in range(per)]
+    if "dma2x" in OPT:                     # pricing only (two 128-row workgroups per CU): every piece staged twice
+        o = [x + "\n" + x if "global_load_lds" in x else x for x in o]
     return o
 
 
