@@ -214,3 +214,47 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(text), f
+
+
+# ------------------------------------------------------------------------------------------ the documents say only true things
+DOCS = ("include/lite_attention_amd.h", "DESIGN.md", "INTEGRATION.md", "README.md")
+CSRC = os.path.join(ROOT, "liteattention_amd", "csrc")
+
+
+def _nm_exports():
+    """Dynamic symbols `la_*` of the built library (nm -D): the entry points a non-Python host can bind."""
+    out = subprocess.run(["nm", "-D", "--defined-only", _cabi.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    return sorted({ln.split()[-1] for ln in out.splitlines() if re.fullmatch(r"la_[a-z0-9_]+", ln.split()[-1])})
+
+
+def _header_type_names():
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    return set(re.findall(r"\b(?:struct|enum)\s+(la_\w+)", src)) | set(re.findall(r"}\s*(la_\w+)\s*;", src))
+
+
+def test_every_la_name_in_the_documents_exists():
+    """ABI 5 advertised `la_blockmask_to_lists` in the header comment, DESIGN.md and INTEGRATION.md while no
+    source defined it. Every `la_*` token of the boundary documents must be (a) a dynamic symbol of the built library, (b) a
+    struct / enum / typedef of the header, (c) a source file of csrc/ (token == file stem), or (d) a device kernel defined there."""
+    exports, types = set(_nm_exports()), _header_type_names()
+    stems = {os.path.splitext(f)[0] for f in os.listdir(CSRC)}
+    kernel_src = "\n".join(open(os.path.join(CSRC, f)).read() for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    bad = []
+    for doc in DOCS:
+        for tok in sorted(set(re.findall(r"\bla_[a-z0-9_]+\b", open(os.path.join(ROOT, doc)).read()))):
+            if tok in exports or tok in types or tok in stems:
+                continue
+            if re.search(r"__global__[^;{]*\b" + re.escape(tok) + r"\s*\(", kernel_src):
+                continue
+            bad.append((doc, tok))
+    assert not bad, f"names the documents mention that exist nowhere: {bad}"
+
+
+def test_every_exported_symbol_is_declared_bound_and_documented():
+    """... and vice versa: what `nm -D` shows is exactly what the header declares and the ctypes layer binds, and INTEGRATION.md
+    names each entry point."""
+    exports = _nm_exports()
+    assert exports == declared_functions() == sorted(_cabi.EXPORTED_SYMBOLS)
+    integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name in exports:
+        assert re.search(r"\b" + name + r"\b", integration), f"INTEGRATION.md never mentions {name}"
