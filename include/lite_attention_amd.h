@@ -14,6 +14,9 @@
  *                            (and its Python twin LiteAttention.get_MN, hopper/lite_attention.py:87-111)
  *   la_skip_list_stats    <- LiteAttention.calc_percentage   hopper/lite_attention.py:61-85
  *                            (device-side, corrected statistic)
+ *   la_blockmask_to_lists <- convert_blockmask + the (missing) fwd_block entry point of the block-sparse adapter
+ *                            flash_attn/flash_blocksparse_attn_interface.py:7-39,185-200: a static 0/1 block mask becomes
+ *                            the read lists la_fwd walks
  *   la_combine            <- mha_combine / flash_fwd_combine (LSE-weighted merge of partial outputs,
  *                            hopper/_internal/cpp/flash_api.cpp fwd_combine; oracle
  *                            hopper/tests/test_flash_attn.py:1178-1187)
@@ -36,7 +39,8 @@
 extern "C" {
 #endif
 
-#define LA_ABI_VERSION 5   /* 5 = 4 + la_blockmask_to_lists, skip lists and fp8 with cu_seqlens, LA_FLAG_EXACT_ROWSUM / LA_FLAG_EXACT_EXP, LA_DTYPE_FP32 (la_combine); la_fwd_args unchanged */
+#define LA_ABI_VERSION 6   /* 6 = 5 + la_blockmask_to_lists, la_device_slots (5 = 4 + skip lists and fp8 with cu_seqlens, LA_FLAG_EXACT_ROWSUM /
+                            * LA_FLAG_EXACT_EXP, LA_DTYPE_FP32 for la_combine); la_fwd_args unchanged since 4 */
 
 typedef enum la_status {
     LA_OK = 0,
@@ -215,6 +219,26 @@ int la_skip_list_stats(const int32_t* list, int32_t n_batch, int32_t num_heads, 
 int la_combine(const void* o_partial, int32_t partial_is_16bit, const float* lse_partial,
                void* o, int32_t o_dtype, float* lse, int32_t num_splits, int32_t batch, int32_t seqlen_q,
                int32_t num_heads, int32_t head_dim_v, void* stream);
+
+/* Static block mask -> read-list rows, on the device (one wave per row; no host round trip).
+ *   blockmask      uint8 (0 = tile masked out, non-zero = computed), rows [q_tiles, k_tiles] contiguous; element strides between
+ *                  batches and heads are arguments (0 = the same mask for every batch / head).
+ *   q_tiles_valid, k_tiles_valid   device int32[batch] or NULL: the sequence of batch b has only that many q- / k-tiles (packed batches
+ *                  under cu_seqlens use the mask's top-left corner): k-tiles >= k_tiles_valid[b] are dropped, rows of q-tiles >=
+ *                  q_tiles_valid[b] (never read by la_fwd) get the whole corner.
+ *   lists          int32 [batch, num_heads, q_tiles, k_tiles + 1] contiguous, every element written:
+ *                  row = [2 * runs, start_0, end_0, ...] (descending, both ends inclusive), zero padded.
+ *   empty_rows     device int32[1] or NULL: number of rows that keep no tile (row[0] = 0). Such a row has no skip-list
+ *                  representation - the reader always walks its first range (mainloop_fwd_sm90_tma_gmma_ws.hpp:93-101) - the
+ *                  caller decides whether to read the counter back. */
+int la_blockmask_to_lists(const uint8_t* blockmask, int64_t mask_batch_stride, int64_t mask_head_stride, int32_t batch,
+                          int32_t num_heads, int32_t q_tiles, int32_t k_tiles, const int32_t* q_tiles_valid,
+                          const int32_t* k_tiles_valid, int32_t* lists, int32_t* empty_rows, void* stream);
+
+/* How many workgroups of the kernel la_fwd runs for (head_dim, element size, flags) are resident at once on the current device:
+ * compute units x workgroups per compute unit. A host that splits one attention into q-tile windows (la_fwd_args.q_tile_begin)
+ * sizes them in whole rounds of this number. No counterpart in the reference (one launch per call). */
+int la_device_slots(int head_dim, int element_size, uint32_t flags, int* compute_units, int* workgroups_per_cu);
 
 const char* la_status_string(int status);
 int         la_abi_version(void);

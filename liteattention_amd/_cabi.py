@@ -13,7 +13,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # LITEATTENTION_AMD_LIB overrides the in-tree location (deployment / tests of the failure path)
 LIB_PATH = os.environ.get("LITEATTENTION_AMD_LIB") or os.path.join(_PKG_DIR, "libliteattention_amd.so")
 
-LA_ABI_VERSION = 5
+LA_ABI_VERSION = 6
 LA_DTYPE_BF16, LA_DTYPE_FP16, LA_DTYPE_FP8_E4M3, LA_DTYPE_FP32 = 0, 1, 2, 3
 
 LA_OK = 0
@@ -25,7 +25,7 @@ LA_ERR_Q_WINDOW = -13
 
 EXPORTED_SYMBOLS = (
     "la_abi_version", "la_get_tile_sizes", "la_get_tile_sizes_ex", "la_fwd", "la_fwd_workspace_bytes", "la_skip_list_stats", "la_combine",
-    "la_status_string", "la_last_hip_error",
+    "la_status_string", "la_last_hip_error", "la_blockmask_to_lists", "la_device_slots",
 )
 
 
@@ -131,6 +131,11 @@ def load() -> ctypes.CDLL:
                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                ctypes.c_void_p]
     lib.la_combine.restype = ctypes.c_int
+    lib.la_blockmask_to_lists.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.la_blockmask_to_lists.restype = ctypes.c_int
+    lib.la_device_slots.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    lib.la_device_slots.restype = ctypes.c_int
     lib.la_status_string.argtypes = [ctypes.c_int]
     lib.la_status_string.restype = ctypes.c_char_p
     lib.la_last_hip_error.restype = ctypes.c_int
@@ -170,3 +175,16 @@ def get_tile_sizes(head_dim: int, element_size: int, flags: int = None) -> Tuple
         raise RuntimeError(f"la_get_tile_sizes(head_dim={head_dim}, element_size={element_size}): {status_string(rc)}")
     _TILE_SIZES[key] = (m.value, n.value)
     return m.value, n.value
+
+
+def device_slots(head_dim: int, element_size: int, flags: int = None) -> Tuple[int, int]:
+    """(compute units of the current device, resident workgroups per compute unit) for the kernel la_fwd runs: what a host that
+    issues one attention as several q-tile windows sizes its windows with (``parallel.plan_q_windows``)."""
+    cu, per = ctypes.c_int(0), ctypes.c_int(0)
+    f = (default_flags() if flags is None else flags) & LA_FLAG_KERNEL_128ROW
+    if element_size == 1:
+        f = 0
+    rc = load().la_device_slots(int(head_dim), int(element_size), f, ctypes.byref(cu), ctypes.byref(per))
+    if rc != LA_OK:
+        raise RuntimeError(f"la_device_slots(head_dim={head_dim}, element_size={element_size}): {status_string(rc)}")
+    return cu.value, per.value

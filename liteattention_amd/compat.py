@@ -200,11 +200,8 @@ def blockmask_to_rows(blockmask: torch.Tensor) -> List[List[int]]:
     return rows
 
 
-def blockmask_to_lists(blockmask: torch.Tensor, k_tiles_valid: Optional[torch.Tensor] = None, validate: bool = True) -> torch.Tensor:
-    """Vectorised ``blockmask_to_rows`` on whatever device holds the mask: bool ``[..., q_tiles, k_tiles]`` -> int32 list rows
-    ``[..., q_tiles, k_tiles + 1]`` (``[L, start0, end0, ...]``, descending ranges, both ends inclusive). No Python loop over rows
-    and no host round trip except the optional check that every row keeps a tile. ``k_tiles_valid`` (int tensor broadcastable to
-    the leading dims): tiles >= it are dropped first — a sequence shorter than the mask uses the mask's top-left corner."""
+def _blockmask_to_lists_host(blockmask: torch.Tensor, k_tiles_valid: Optional[torch.Tensor] = None, validate: bool = True) -> torch.Tensor:
+    """Host-side form of ``blockmask_to_lists`` for a mask that lives in host memory (tensor ops, no loop over rows)."""
     m = blockmask.to(torch.bool)
     kt = m.shape[-1]
     tile = torch.arange(kt - 1, -1, -1, device=m.device)                       # position j of the descending walk <-> tile kt-1-j
@@ -227,17 +224,76 @@ def blockmask_to_lists(blockmask: torch.Tensor, k_tiles_valid: Optional[torch.Te
     return lists[..., : kt + 1].contiguous()
 
 
+def blockmask_to_lists(blockmask: torch.Tensor, k_tiles_valid: Optional[torch.Tensor] = None, validate: bool = True,
+                       q_tiles_valid: Optional[torch.Tensor] = None, batch: Optional[int] = None,
+                       heads: Optional[int] = None) -> torch.Tensor:
+    """0/1 block mask -> int32 read-list rows ``[L, start0, end0, ...]`` (descending ranges, both ends inclusive, zero padded).
+
+    A mask on the GPU is converted by the library (``la_blockmask_to_lists``, one wave per row, no host round trip except the optional
+    ``validate`` read of the empty-row counter): mask ``[q_tiles, k_tiles]`` (shared), ``[batch, q_tiles, k_tiles]`` or
+    ``[batch, heads, q_tiles, k_tiles]`` -> lists ``[batch, heads, q_tiles, k_tiles + 1]`` when ``batch`` / ``heads`` are given (the mask is
+    broadcast through zero strides, not materialised), else lists shaped like the mask's leading dims. ``k_tiles_valid`` /
+    ``q_tiles_valid`` (int ``[batch]``): the sequence of batch b has only that many tiles — k-tiles beyond are dropped, q-tile rows beyond
+    (never read by the kernel) get the whole corner. A mask in host memory goes through the tensor-op form (host bookkeeping, like
+    ``init_skip_list``); it has no ``q_tiles_valid``."""
+    if not blockmask.is_cuda:
+        if q_tiles_valid is not None:
+            raise NotImplementedError("q_tiles_valid: device masks only")
+        out = _blockmask_to_lists_host(blockmask, k_tiles_valid, validate)
+        if batch is not None and heads is not None and out.dim() < 4:
+            out = (out[None, None] if out.dim() == 2 else out[:, None]).expand(batch, heads, -1, -1).contiguous()
+        return out
+    from . import _cabi
+    if blockmask.dtype == torch.uint8:
+        m = blockmask
+    else:                                                       # bool is one byte of 0 / 1: reinterpreted, not copied
+        m = (blockmask if blockmask.dtype == torch.bool else blockmask != 0).view(torch.uint8)
+    lead = tuple(m.shape[:-2])
+    qt, kt = m.shape[-2], m.shape[-1]
+    if m.dim() > 4:
+        raise ValueError("blockmask must be [q_tiles, k_tiles], [batch, q_tiles, k_tiles] or [batch, heads, q_tiles, k_tiles]")
+    if m.stride(-1) != 1 or m.stride(-2) != kt:
+        m = m.contiguous()
+    B = batch if batch is not None else (lead[0] if len(lead) >= 1 else 1)
+    H = heads if heads is not None else (lead[1] if len(lead) == 2 else 1)
+    if len(lead) >= 1 and lead[0] not in (1, B) or len(lead) == 2 and lead[1] not in (1, H):
+        raise ValueError("blockmask batch/heads do not match")
+    sb = m.stride(0) if len(lead) >= 1 and lead[0] == B and B > 1 else 0
+    sh = m.stride(1) if len(lead) == 2 and lead[1] == H and H > 1 else 0
+    lists = torch.empty((B, H, qt, kt + 1), dtype=torch.int32, device=m.device)
+    empty = torch.empty(1, dtype=torch.int32, device=m.device) if validate else None
+
+    def _valid(t):
+        if t is None:
+            return None
+        t = t.to(device=m.device, dtype=torch.int32).contiguous()
+        if t.numel() != B:
+            raise ValueError("k_tiles_valid / q_tiles_valid must hold one entry per batch")
+        return t
+    kv, qv = _valid(k_tiles_valid), _valid(q_tiles_valid)
+    with torch.cuda.device(m.device):
+        rc = _cabi.load().la_blockmask_to_lists(m.data_ptr(), sb, sh, B, H, qt, kt, qv.data_ptr() if qv is not None else None,
+                                                kv.data_ptr() if kv is not None else None, lists.data_ptr(),
+                                                empty.data_ptr() if empty is not None else None,
+                                                torch.cuda.current_stream(m.device).cuda_stream)
+    if rc != _cabi.LA_OK:
+        raise RuntimeError(f"la_blockmask_to_lists: {_cabi.status_string(rc)}")
+    if validate and int(empty.item()) != 0:
+        raise ValueError("a q-tile keeps no k-tile: not representable as a skip list")
+    if batch is None and heads is None:
+        return lists.reshape(*lead, qt, kt + 1)
+    return lists
+
+
 def blockmask_to_skip_lists(blockmask: torch.Tensor, batch: int, heads: int, device) -> torch.Tensor:
     """blockmask [q_tiles, k_tiles] (shared by all batches/heads) or [batch, heads, q_tiles, k_tiles] ->
     int32 skip lists ``[2, batch, heads, q_tiles, k_tiles + 1]`` (both ping-pong buffers identical). Converted on ``device``
-    by tensor ops (``blockmask_to_lists``); a shared mask is converted once and broadcast."""
-    if blockmask.dim() == 2:
-        rows = blockmask_to_lists(blockmask.to(device))
-        lists = rows[None, None].expand(batch, heads, -1, -1)
-    else:
-        if tuple(blockmask.shape[:2]) != (batch, heads):
-            raise ValueError("blockmask batch/heads do not match")
-        lists = blockmask_to_lists(blockmask.to(device))
+    (``blockmask_to_lists``: the library's kernel on a GPU, which broadcasts a shared mask through zero strides)."""
+    if blockmask.dim() not in (2, 4):
+        raise ValueError("blockmask must be [q_tiles, k_tiles] or [batch, heads, q_tiles, k_tiles]")
+    if blockmask.dim() == 4 and tuple(blockmask.shape[:2]) != (batch, heads):
+        raise ValueError("blockmask batch/heads do not match")
+    lists = blockmask_to_lists(blockmask.to(device), batch=batch, heads=heads)
     return torch.stack([lists, lists]).contiguous()
 
 
@@ -320,12 +376,9 @@ def flash_blocksparse_attn_qkvpacked_func(qkv, cu_seqlens, blockmask, dropout_p,
     if bool((lens > max_s).any()):
         raise RuntimeError("a sequence is longer than max_s")
     kt_b, qt_b = (lens + bn - 1) // bn, (lens + bm - 1) // bm
-    # rows of q-tiles past a sequence's end are never read: give them the full corner so that the "keeps a tile" check only
+    # rows of q-tiles past a sequence's end are never read: the kernel gives them the full corner, so the "keeps a tile" check only
     # speaks about real rows
-    live_row = torch.arange(qt, device=qkv.device)[None, :] < qt_b[:, None]                                   # [B, qt]
-    clipped = mask[None] | ~live_row[:, :, None]
-    rows = blockmask_to_lists(clipped, k_tiles_valid=torch.clamp(kt_b, min=1), validate=True)                 # [B, qt, kt + 1]
-    lists = rows[:, None].expand(B, H, qt, kt + 1).contiguous()
+    lists = blockmask_to_lists(mask, k_tiles_valid=torch.clamp(kt_b, min=1), q_tiles_valid=qt_b, validate=True, batch=B, heads=H)
     write = torch.empty_like(lists)
     must_do = torch.tensor([2, 0, 0], dtype=torch.int32, device=qkv.device)
     out, lse, *_ = mha_fwd(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens_q=cu, cu_seqlens_k=cu, max_seqlen_q=int(max_s),

@@ -50,7 +50,7 @@ const char* la_status_string(int status) {
         case LA_ERR_STRIDE: return "Input tensor must have contiguous last dimension and 16-byte aligned rows";
         case LA_ERR_TILE_MISMATCH: return "block_m/block_n do not match la_get_tile_sizes(): skip lists would be mis-indexed";
         case LA_ERR_LISTS: return "attn_read_list and attn_write_list must be given together";
-        case LA_ERR_UNSUPPORTED: return "feature outside the QK-Skip hot path (head_dim_v != head_dim, unknown flags, fp8 with cu_seqlens, skip lists with cu_seqlens on the 128-row kernels)";
+        case LA_ERR_UNSUPPORTED: return "feature outside the QK-Skip hot path (head_dim_v != head_dim, unknown flags, skip lists with cu_seqlens on the 128-row kernels or above head_dim 128)";
         case LA_ERR_LAUNCH: return "HIP kernel launch failed (see la_last_hip_error)";
         case LA_ERR_SEQLEN: return "seqlen_k too long: expanded skip list does not fit in LDS";
         case LA_ERR_WORKSPACE: return "fp8 needs a 16-byte aligned workspace of la_fwd_workspace_bytes() bytes";
@@ -235,6 +235,32 @@ int la_skip_list_stats(const int32_t* list, int32_t n_batch, int32_t num_heads, 
     const hipError_t err = la::launch_skip_list_stats(list, static_cast<int>(rows), k_tiles, out_counts,
                                                       static_cast<hipStream_t>(stream_));
     if (err != hipSuccess) { g_last_hip_error = static_cast<int>(err); return LA_ERR_LAUNCH; }
+    return LA_OK;
+}
+
+int la_blockmask_to_lists(const uint8_t* blockmask, int64_t mask_batch_stride, int64_t mask_head_stride, int32_t batch,
+                          int32_t num_heads, int32_t q_tiles, int32_t k_tiles, const int32_t* q_tiles_valid,
+                          const int32_t* k_tiles_valid, int32_t* lists, int32_t* empty_rows, void* stream_) {
+    if (!blockmask || !lists) return LA_ERR_NULL_ARG;
+    if (batch <= 0 || num_heads <= 0 || q_tiles <= 0 || k_tiles <= 0) return LA_ERR_SHAPE;
+    if (mask_batch_stride < 0 || mask_head_stride < 0) return LA_ERR_STRIDE;
+    if (static_cast<int64_t>(batch) * num_heads * q_tiles > 0x7fffffffLL) return LA_ERR_SHAPE;
+    const hipError_t err = la::launch_blockmask_to_lists(blockmask, mask_batch_stride, mask_head_stride, batch, num_heads, q_tiles,
+                                                         k_tiles, q_tiles_valid, k_tiles_valid, lists, empty_rows,
+                                                         static_cast<hipStream_t>(stream_));
+    if (err != hipSuccess) { g_last_hip_error = static_cast<int>(err); return LA_ERR_LAUNCH; }
+    return LA_OK;
+}
+
+int la_device_slots(int head_dim, int element_size, uint32_t flags, int* compute_units, int* workgroups_per_cu) {
+    int bm = 0, bn = 0;
+    const int rc = la_get_tile_sizes_ex(head_dim, element_size, flags, &bm, &bn);
+    if (rc != LA_OK) return rc;
+    // the hand-scheduled kernels fill a CU with one workgroup (512 registers x 4 waves, 64-130 KiB of LDS); the hipcc-scheduled
+    // 128-row template runs two per CU at head_dim <= 128 (la_fwd_kernel_v2.hip)
+    const bool v2 = element_size == 2 && (flags & LA_FLAG_KERNEL_128ROW) != 0;
+    if (compute_units) *compute_units = la::compute_units();
+    if (workgroups_per_cu) *workgroups_per_cu = (v2 && head_dim <= 128) ? 2 : 1;
     return LA_OK;
 }
 

@@ -3,6 +3,9 @@
 //  * skip_list_stats: number of listed tiles of a skip list, computed on the device. Replaces
 //    LiteAttention.calc_percentage (/root/reference/hopper/lite_attention.py:61-85), whose
 //    arithmetic is wrong; same input, corrected statistic.
+//  * blockmask_to_lists: static 0/1 block mask -> read-list rows, one wave per row. The reference's block-sparse adapter converts
+//    its mask on the host for a CUDA entry point that exists nowhere (/root/reference/flash_attn/flash_blocksparse_attn_interface.py:7-39,
+//    185-200); here the mask becomes the skip lists the forward kernel walks (row format: mainloop_fwd_sm90_tma_gmma_ws.hpp:47-115).
 //  * empty_k_fill: o = 0, lse = +inf for a call with seqlen_k == 0 (flash_api.cpp:1241-1245), on strided o.
 //  * combine: LSE-weighted merge of partial outputs of K/V splits — the device counterpart of
 //    attention_combine_ref (/root/reference/hopper/tests/test_flash_attn.py:1178-1187) and of the
@@ -47,6 +50,65 @@ hipError_t launch_skip_list_stats(const int32_t* list, int rows, int k_tiles, in
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(skip_list_stats_kernel, dim3(blocks), dim3(256), 0, stream, list, rows, k_tiles,
                        reinterpret_cast<unsigned long long*>(out));
+    return hipGetLastError();
+}
+
+// One wave per (batch, head, q-tile) row. Position j of the descending walk is tile kt-1-j; a kept run [start .. end] (start >= end)
+// becomes the pair (start, end) of the row, runs in descending order: row = [2 * runs, start0, end0, start1, end1, ..., 0 ...].
+// HBM-bound byte work: kt mask bytes in (three cached loads per lane: the tile and its two neighbours), kt+1 ints out.
+__global__ void __launch_bounds__(256) blockmask_to_lists_kernel(const uint8_t* __restrict__ mask, int64_t mask_batch_stride,
+                                                                  int64_t mask_head_stride, int batch, int num_heads, int q_tiles,
+                                                                  int k_tiles, const int32_t* __restrict__ q_tiles_valid,
+                                                                  const int32_t* __restrict__ k_tiles_valid,
+                                                                  int32_t* __restrict__ lists, int32_t* __restrict__ empty_rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rows = static_cast<int64_t>(batch) * num_heads * q_tiles;
+    const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t r = wave0; r < rows; r += n_waves) {
+        const int m = static_cast<int>(r % q_tiles);
+        const int64_t bh = r / q_tiles;
+        const int h = static_cast<int>(bh % num_heads), b = static_cast<int>(bh / num_heads);
+        const uint8_t* mrow = mask + b * mask_batch_stride + h * mask_head_stride + static_cast<int64_t>(m) * k_tiles;
+        int32_t* out = lists + r * (k_tiles + 1);
+        int kv = k_tiles_valid ? k_tiles_valid[b] : k_tiles;          // tiles >= kv do not exist for this sequence
+        kv = kv < 0 ? 0 : (kv > k_tiles ? k_tiles : kv);
+        const bool all = q_tiles_valid != nullptr && m >= q_tiles_valid[b];   // a q-tile past the sequence's end: never read; full corner
+        int runs = 0;                                                  // kept runs that START at positions before this chunk
+        for (int j0 = 0; j0 < k_tiles; j0 += 64) {
+            const int j = j0 + lane, t = k_tiles - 1 - j;
+            const bool in = j < k_tiles;
+            const bool keep = in && t < kv && (all || mrow[t] != 0);
+            const bool prev = in && t + 1 < kv && (all || mrow[t + 1] != 0);          // t + 1 < kv <= k_tiles: in bounds
+            const bool next = in && t >= 1 && t - 1 < kv && (all || mrow[t - 1] != 0);
+            const bool is_start = keep && !prev, is_end = keep && !next;
+            const unsigned long long sb = __ballot(is_start);
+            const int ridx = runs + __popcll(sb & ((2ull << lane) - 1ull)) - 1;       // the run this position belongs to
+            if (is_start && 1 + 2 * ridx <= k_tiles) out[1 + 2 * ridx] = t;
+            if (is_end && 2 + 2 * ridx <= k_tiles) out[2 + 2 * ridx] = t;              // a last end behind the row is counted, not stored
+            runs += __popcll(sb);
+        }
+        for (int i = 2 * runs + 1 + lane; i <= k_tiles; i += 64) out[i] = 0;
+        if (lane == 0) {
+            out[0] = 2 * runs;
+            if (runs == 0 && empty_rows != nullptr) atomicAdd(empty_rows, 1);
+        }
+    }
+}
+
+hipError_t launch_blockmask_to_lists(const uint8_t* mask, int64_t mask_batch_stride, int64_t mask_head_stride, int batch,
+                                     int num_heads, int q_tiles, int k_tiles, const int32_t* q_tiles_valid,
+                                     const int32_t* k_tiles_valid, int32_t* lists, int32_t* empty_rows, hipStream_t stream) {
+    if (empty_rows != nullptr) {
+        const hipError_t err = hipMemsetAsync(empty_rows, 0, sizeof(int32_t), stream);
+        if (err != hipSuccess) return err;
+    }
+    const int64_t rows = static_cast<int64_t>(batch) * num_heads * q_tiles;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 16384) blocks = 16384;      // >> 256 CUs; rows beyond are taken by the grid-stride loop
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(blockmask_to_lists_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, mask, mask_batch_stride,
+                       mask_head_stride, batch, num_heads, q_tiles, k_tiles, q_tiles_valid, k_tiles_valid, lists, empty_rows);
     return hipGetLastError();
 }
 

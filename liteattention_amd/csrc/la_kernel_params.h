@@ -91,6 +91,9 @@ hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_ro
 hipError_t launch_empty_k_fill(uint16_t* o, float* lse, int64_t o_batch_stride, int64_t o_row_stride, int64_t o_head_stride,
                                int batch, int seqlen_q, int num_heads, int head_dim_v, hipStream_t stream);
 hipError_t launch_skip_list_stats(const int32_t* list, int rows, int k_tiles, int64_t* out, hipStream_t stream);
+hipError_t launch_blockmask_to_lists(const uint8_t* mask, int64_t mask_batch_stride, int64_t mask_head_stride, int batch,
+                                     int num_heads, int q_tiles, int k_tiles, const int32_t* q_tiles_valid,
+                                     const int32_t* k_tiles_valid, int32_t* lists, int32_t* empty_rows, hipStream_t stream);
 hipError_t launch_combine(const void* o_partial, bool partial_is_16bit, bool f16, const float* lse_partial, uint16_t* o,
                           float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v,
                           hipStream_t stream, bool out_f32 = false);

@@ -24,7 +24,7 @@ import torch
 
 from . import _cabi
 
-__all__ = ["flash_attn_func", "FlashAttnFunc", "flash_attn_combine", "get_tile_sizes", "skip_list_stats"]
+__all__ = ["flash_attn_func", "FlashAttnFunc", "flash_attn_combine", "mha_combine", "get_tile_sizes", "skip_list_stats"]
 
 _FWD_SCHEMA = (
     "fwd("
@@ -381,13 +381,17 @@ def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
                                softmax_scale, attn_read_list, attn_write_list, attn_must_do_list, thr, _must_do_is_1d)
     D_kernel = kernel_head_dim(D, q.element_size())
     if D_kernel != D:
-        if out is not None and (out.dtype != q.dtype or tuple(out.shape) != (Tq, H, D) or out.stride(-1) != 1):
-            raise RuntimeError("out must have the input dtype, shape (total_q, nheads, headdim) and a contiguous last dimension")
-        pad = lambda t: torch.nn.functional.pad(t, (0, D_kernel - D))                                          # noqa: E731
-        res = _mha_fwd_varlen(pad(q), pad(k), pad(v), None, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, None,
-                              None, None, softmax_scale, attn_read_list, attn_write_list, attn_must_do_list, thr, _must_do_is_1d)
+        if out is not None and (out.dtype != out_dtype or tuple(out.shape) != (Tq, H, D) or out.stride(-1) != 1):
+            raise RuntimeError("out must have the input dtype (bf16 for fp8 inputs), shape (total_q, nheads, headdim) and a contiguous last dimension")
+
+        def pad(t):                                              # fp8: pad the bytes (0x00 is +0.0 in e4m3), as mha_fwd does
+            if is_fp8:
+                return torch.nn.functional.pad(t.view(torch.uint8), (0, D_kernel - D)).view(t.dtype)
+            return torch.nn.functional.pad(t, (0, D_kernel - D))
+        res = _mha_fwd_varlen(pad(q), pad(k), pad(v), None, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, descales[0],
+                              descales[1], descales[2], softmax_scale, attn_read_list, attn_write_list, attn_must_do_list, thr, _must_do_is_1d)
         if out is None:
-            out = torch.empty((Tq, H, D), dtype=q.dtype, device=q.device)           # contiguous (total_q, H, D), as the reference's
+            out = torch.empty((Tq, H, D), dtype=out_dtype, device=q.device)        # contiguous (total_q, H, D), as the reference's
         out.copy_(res[0][..., :D])
         return (out, *res[1:])
     if out is None:
@@ -563,47 +567,109 @@ def flash_attn_func(q, k, v, softmax_scale=None, causal=False, qv=None, q_descal
                                attn_read_list, attn_must_do_list, attn_write_list, thr, return_softmax_lse)
 
 
-def flash_attn_combine(out_partial: torch.Tensor, lse_partial: torch.Tensor, out: Optional[torch.Tensor] = None,
-                       out_dtype: Optional[torch.dtype] = None, return_lse: bool = True):
-    """LSE-weighted merge of per-split partial results (sequence-parallel K/V splits).
-
-    out_partial: (num_splits, batch, seqlen, nheads, headdim) fp32, bf16 or fp16; lse_partial:
-    (num_splits, batch, nheads, seqlen) fp32 (the layout ``flash_attn_func`` returns). Counterpart of
-    the reference's flash_attn_combine (hopper/_internal/flash_attn_interface.py:684, fwd_combine op,
-    flash_api.cpp:1620-1680). ``out_dtype``: default = the dtype of the partials, as in the reference (fp32 partials -> fp32 result,
-    hopper/_internal/flash_attn_interface.py:684-685); fp32 partials may also be merged into bf16 / fp16."""
-    if not out_partial.is_cuda:
-        raise RuntimeError("flash_attn_combine has no CPU implementation")
-    if out_partial.dtype not in (torch.float32, torch.bfloat16, torch.float16):
-        raise RuntimeError("out_partial must be fp32, bf16 or fp16")
+def mha_combine(out_partial: torch.Tensor, lse_partial: torch.Tensor, out: Optional[torch.Tensor] = None,
+                out_dtype: Optional[torch.dtype] = None):
+    """``lite_attention::fwd_combine`` with the reference's contract (mha_combine, flash_api.cpp:1620-1718; schema :1787-1791):
+    out_partial (num_splits, batch, seqlen, nheads, headdim), last dim contiguous; lse_partial LOGICAL shape (num_splits, batch,
+    seqlen, nheads) with the seqlen dimension contiguous (``stride(-2) == 1``: physically (num_splits, batch, nheads, seqlen), i.e. the
+    transposed view of what ``flash_attn_func`` returns per split, exactly what the reference's test feeds it,
+    hopper/tests/test_flash_attn.py:1211-1212). Returns ``(out (batch, seqlen, nheads, headdim), softmax_lse (batch, seqlen, nheads))``,
+    the latter the transposed view of a (batch, nheads, seqlen) buffer as in flash_api.cpp:1682. The reference takes fp32 partials only
+    (:1631); 16-bit partials of the output type are accepted here in addition."""
+    if not out_partial.is_cuda or not lse_partial.is_cuda:
+        raise RuntimeError("Input tensor must be on CUDA device")
+    if out_partial.dtype not in (torch.float32, torch.bfloat16, torch.float16) or lse_partial.dtype != torch.float32:
+        raise RuntimeError("Attention combine function only support fp32 data type")
+    if out_partial.dim() != 5 or lse_partial.dim() != 4:
+        raise RuntimeError("out_partial must be (num_splits, batch, seqlen, nheads, headdim), lse_partial (num_splits, batch, seqlen, nheads)")
+    if out_partial.stride(-1) != 1:
+        raise RuntimeError("Input tensor must have contiguous last dimension")
+    ns, B, S, H, Dv = out_partial.shape
+    if ns > 256:
+        raise RuntimeError("FlashAttention combine only supports num_splits at most 256")
+    if tuple(lse_partial.shape) != (ns, B, S, H):
+        raise RuntimeError(f"lse_partial must have shape ({ns}, {B}, {S}, {H})")
+    if lse_partial.stride(-2) != 1 and S > 1:
+        raise RuntimeError("LSE tensor must be contiguous in the seqlen dimension")
     if out_dtype is None:
-        out_dtype = out.dtype if out is not None else out_partial.dtype
+        out_dtype = out_partial.dtype
     if out_dtype not in (torch.bfloat16, torch.float16, torch.float32):
         raise RuntimeError("Output type must be FP32, FP16 or BF16")
     if out_partial.dtype != torch.float32 and out_partial.dtype != out_dtype:
         raise RuntimeError("16-bit partial results must have the output dtype")
-    if lse_partial.dtype != torch.float32:
-        raise RuntimeError("lse_partial must be fp32")
-    out_partial = out_partial.contiguous()
-    lse_partial = lse_partial.contiguous()
-    ns, B, S, H, Dv = out_partial.shape
-    if tuple(lse_partial.shape) != (ns, B, H, S):
-        raise RuntimeError("lse_partial must have shape (num_splits, batch, nheads, seqlen)")
-    if out is None:
-        out = torch.empty((B, S, H, Dv), dtype=out_dtype, device=out_partial.device)
-    elif out.dtype != out_dtype or tuple(out.shape) != (B, S, H, Dv) or not out.is_contiguous():
-        raise RuntimeError("out must be contiguous (batch, seqlen, nheads, headdim) of out_dtype")
-    lse = torch.empty((B, H, S), dtype=torch.float32, device=out_partial.device) if return_lse else None
+    if out is not None:
+        if out.dtype != out_dtype or tuple(out.shape) != (B, S, H, Dv) or not out.is_cuda or out.stride(-1) != 1:
+            raise RuntimeError("out must be (batch, seqlen, nheads, headdim) of the output dtype with a contiguous last dimension")
+    Dp = -(-Dv // 8) * 8                                     # the kernel moves 8 elements per access (the reference pads to 4, :1651-1659)
+    op = out_partial if Dp == Dv else torch.nn.functional.pad(out_partial, (0, Dp - Dv))
+    op = op.contiguous()
+    lp = lse_partial.transpose(-1, -2).contiguous()          # physical (num_splits, batch, nheads, seqlen); no copy for the reference's layout
+    direct = out is not None and Dp == Dv and out.is_contiguous()
+    res = out if direct else torch.empty((B, S, H, Dp), dtype=out_dtype, device=out_partial.device)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=out_partial.device)
     with torch.cuda.device(out_partial.device):
         stream = torch.cuda.current_stream(out_partial.device).cuda_stream
-        rc = _cabi.load().la_combine(out_partial.data_ptr(), int(out_partial.dtype != torch.float32),
-                                     lse_partial.data_ptr(), out.data_ptr(),
+        rc = _cabi.load().la_combine(op.data_ptr(), int(op.dtype != torch.float32), lp.data_ptr(), res.data_ptr(),
                                      {torch.float16: _cabi.LA_DTYPE_FP16, torch.float32: _cabi.LA_DTYPE_FP32}.get(out_dtype, _cabi.LA_DTYPE_BF16),
-                                     lse.data_ptr() if lse is not None else None,
-                                     ns, B, S, H, Dv, ctypes.c_void_p(stream))
+                                     lse.data_ptr(), ns, B, S, H, Dp, ctypes.c_void_p(stream))
     if rc != _cabi.LA_OK:
         raise RuntimeError(f"la_combine: {_cabi.status_string(rc)}")
-    return (out, lse) if return_lse else out
+    if not direct:
+        if out is not None:
+            out.copy_(res[..., :Dv])
+            res = out
+        elif Dp != Dv:
+            res = res[..., :Dv]
+    return res, lse.transpose(1, 2)
+
+
+def _combine_meta(out_partial, lse_partial, out=None, out_dtype=None):
+    ns, B, S, H, Dv = out_partial.shape
+    if out is None:
+        out = torch.empty((B, S, H, Dv), dtype=out_dtype or out_partial.dtype, device=out_partial.device)
+    return out, torch.empty((B, H, S), dtype=torch.float32, device=out_partial.device).transpose(1, 2)
+
+
+def _register_combine_op():
+    """``lite_attention::fwd_combine`` beside ``fwd`` (flash_api.cpp:1787-1791, 1822)."""
+    _op_lib.define(_COMBINE_SCHEMA)
+    _op_lib.impl("fwd_combine", mha_combine, "CUDA")
+    _op_lib.impl("fwd_combine", _combine_meta, "Meta")
+
+
+_COMBINE_SCHEMA = "fwd_combine(Tensor out_partial, Tensor lse_partial, Tensor(out!)? out = None, ScalarType? out_dtype = None) -> (Tensor(out!), Tensor)"
+_register_combine_op()
+
+
+def flash_attn_combine(out_partial: torch.Tensor, lse_partial: torch.Tensor, out: Optional[torch.Tensor] = None,
+                       out_dtype: Optional[torch.dtype] = None, return_lse: bool = True):
+    """LSE-weighted merge of per-split partial results (sequence-parallel K/V splits): the reference's flash_attn_combine
+    (hopper/_internal/flash_attn_interface.py:684-685), a call of the ``lite_attention::fwd_combine`` op.
+
+    out_partial: (num_splits, batch, seqlen, nheads, headdim) fp32, bf16 or fp16. lse_partial, fp32, in either of two layouts, and
+    the returned LSE has the layout of the input:
+      * the reference op's: logical (num_splits, batch, seqlen, nheads) with the seqlen dimension contiguous -> lse (batch, seqlen, nheads);
+      * what ``flash_attn_func(..., return_softmax_lse=True)`` returns, stacked: contiguous (num_splits, batch, nheads, seqlen) -> lse
+        (batch, nheads, seqlen). (When seqlen == nheads the strides tell them apart.)
+    ``out_dtype``: default = the dtype of the partials, as in the reference (fp32 partials -> fp32 result); fp32 partials may also be merged
+    into bf16 / fp16."""
+    if not out_partial.is_cuda:
+        raise RuntimeError("flash_attn_combine has no CPU implementation")
+    if out_dtype is None and out is not None:
+        out_dtype = out.dtype
+    if out_partial.dim() != 5 or lse_partial.dim() != 4:
+        raise RuntimeError("out_partial must be (num_splits, batch, seqlen, nheads, headdim) and lse_partial 4-D")
+    ns, B, S, H, Dv = out_partial.shape
+    ref_layout = tuple(lse_partial.shape) == (ns, B, S, H) and (lse_partial.stride(-2) == 1 or S == 1)
+    own_layout = tuple(lse_partial.shape) == (ns, B, H, S) and (lse_partial.stride(-1) == 1 or S == 1)
+    if own_layout and (not ref_layout or S != 1 and lse_partial.stride(-1) == 1):
+        res, lse = torch.ops.lite_attention.fwd_combine(out_partial, lse_partial.transpose(-1, -2), out, out_dtype)
+        return (res, lse.transpose(1, 2)) if return_lse else res
+    if not ref_layout:
+        raise RuntimeError("lse_partial must have shape (num_splits, batch, nheads, seqlen), or the reference op's "
+                           "(num_splits, batch, seqlen, nheads) with the seqlen dimension contiguous")
+    res, lse = torch.ops.lite_attention.fwd_combine(out_partial, lse_partial, out, out_dtype)
+    return (res, lse) if return_lse else res
 
 
 def skip_list_stats(skip_list: torch.Tensor, batch: Optional[int] = None) -> torch.Tensor:

@@ -1,0 +1,187 @@
+"""GPU: round-4 additions at the boundary: ``la_blockmask_to_lists`` (device kernel, bit-exact against the pure-Python
+``blockmask_to_rows``), ``lite_attention::fwd_combine`` (the reference's op contract), ``la_device_slots``."""
+import ctypes
+
+import pytest
+import torch
+
+import liteattention_amd as L
+from liteattention_amd import _cabi, compat
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rows_ref(mask2d, kv=None):
+    """Pure-Python reference (compat.blockmask_to_rows) with the row padded / cut to k_tiles + 1 entries like the kernel's rows."""
+    kt = mask2d.shape[1]
+    m = mask2d.clone().bool()
+    if kv is not None:
+        m[:, kv:] = False
+    out = torch.zeros(m.shape[0], kt + 1, dtype=torch.int32)
+    for i in range(m.shape[0]):
+        if not bool(m[i].any()):
+            continue                                           # row[0] = 0: counted in empty_rows
+        r = compat.blockmask_to_rows(m[i:i + 1])[0]
+        out[i, : min(len(r), kt + 1)] = torch.tensor(r[: kt + 1], dtype=torch.int32)
+    return out
+
+
+@pytest.mark.parametrize("qt,kt,p", [(5, 1, 0.5), (7, 2, 0.5), (9, 3, 0.6), (33, 63, 0.5), (17, 64, 0.3), (12, 65, 0.7), (40, 130, 0.5),
+                                     (296, 1182, 0.56), (3, 257, 1.0), (4, 200, 0.02)])
+def test_blockmask_kernel_rows_equal_the_python_rows_bit_for_bit(qt, kt, p):
+    g = torch.Generator().manual_seed(qt * 1000 + kt)
+    mask = torch.rand(qt, kt, generator=g) < p
+    ref = _rows_ref(mask)
+    n_empty = int((~mask.any(-1)).sum())
+    got = compat.blockmask_to_lists(mask.to(DEV), validate=False)
+    assert got.dtype == torch.int32 and tuple(got.shape) == (qt, kt + 1)
+    assert torch.equal(got.cpu(), ref)
+    if n_empty:
+        with pytest.raises(ValueError):
+            compat.blockmask_to_lists(mask.to(DEV), validate=True)
+    # alternating mask: the maximum number of runs (the last end may fall behind the row: counted, not stored)
+    alt = (torch.arange(kt)[None, :] + torch.arange(qt)[:, None]) % 2 == 0
+    assert torch.equal(compat.blockmask_to_lists(alt.to(DEV), validate=False).cpu(), _rows_ref(alt))
+    # the host-side tensor-op form says the same
+    assert torch.equal(compat.blockmask_to_lists(mask, validate=False), ref)
+
+
+def test_blockmask_kernel_broadcast_strides_valid_counts_and_raw_cabi():
+    B, H, qt, kt = 3, 4, 11, 37
+    g = torch.Generator().manual_seed(5)
+    mask = torch.rand(qt, kt, generator=g) < 0.5
+    mask[:, 0] = True                                           # every row keeps a tile for every clip >= 1
+    kv = torch.tensor([37, 5, 1], dtype=torch.int32)
+    qv = torch.tensor([11, 3, 0], dtype=torch.int32)
+    got = compat.blockmask_to_lists(mask.to(DEV), k_tiles_valid=kv.to(DEV), q_tiles_valid=qv.to(DEV), batch=B, heads=H)
+    assert tuple(got.shape) == (B, H, qt, kt + 1)
+    for b in range(B):
+        ref = _rows_ref(mask, int(kv[b]))
+        full = _rows_ref(torch.ones(qt, kt, dtype=torch.bool), int(kv[b]))
+        ref[int(qv[b]):] = full[int(qv[b]):]                    # q-tiles past the sequence's end: the whole corner
+        for h in range(H):
+            assert torch.equal(got[b, h].cpu(), ref), (b, h)
+    # per-(batch, head) masks through the raw C-ABI, non-bool mask values, uint8 input
+    m4 = (torch.rand(B, H, qt, kt, generator=g) < 0.4).to(torch.uint8) * 7
+    m4[..., -1] = 1
+    d = m4.to(DEV)
+    lists = torch.full((B, H, qt, kt + 1), -1, dtype=torch.int32, device=DEV)
+    empty = torch.full((1,), 99, dtype=torch.int32, device=DEV)
+    rc = _cabi.load().la_blockmask_to_lists(d.data_ptr(), d.stride(0), d.stride(1), B, H, qt, kt, None, None, lists.data_ptr(),
+                                            empty.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == _cabi.LA_OK and int(empty.item()) == 0
+    for b in range(B):
+        for h in range(H):
+            assert torch.equal(lists[b, h].cpu(), _rows_ref(m4[b, h] != 0))
+    assert torch.equal(compat.blockmask_to_lists(d), lists)
+    lib = _cabi.load()
+    assert lib.la_blockmask_to_lists(None, 0, 0, 1, 1, 1, 1, None, None, lists.data_ptr(), None, None) == _cabi.LA_ERR_NULL_ARG
+    assert lib.la_blockmask_to_lists(d.data_ptr(), 0, 0, 0, 1, 1, 1, None, None, lists.data_ptr(), None, None) == _cabi.LA_ERR_SHAPE
+    assert lib.la_blockmask_to_lists(d.data_ptr(), -1, 0, 1, 1, 1, 1, None, None, lists.data_ptr(), None, None) == _cabi.LA_ERR_STRIDE
+
+
+def test_blockmask_lists_drive_the_kernel_like_a_masked_dense_attention():
+    """End to end: mask -> la_blockmask_to_lists -> la_fwd == the oracle walking the Python rows."""
+    B, S, H, D = 1, 1500, 2, 128
+    bm, bn = L.get_tile_sizes(D, 2)
+    qt, kt = -(-S // bm), -(-S // bn)
+    g = torch.Generator().manual_seed(11)
+    q, k, v = [torch.randn(B, S, H, D, generator=g).bfloat16() for _ in range(3)]
+    mask = torch.rand(qt, kt, generator=g) < 0.5
+    mask[:, -1] = True
+    out, lse = L.flash_blocksparse_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), mask.to(DEV), return_softmax_lse=True)
+    rows = _rows_ref(mask)[None, None].expand(B, H, qt, kt + 1).contiguous()
+    o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=rows, write_list=torch.zeros_like(rows), thr=float("-inf"))
+    assert (out.float().cpu() - o_ref).abs().max().item() <= 2.0 ** -8 * o_ref.abs().max().item() + 1e-3
+    assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("num_splits,seqlen,d", [(1, 1, 64), (2, 3, 128), (5, 113, 96), (17, 64, 256), (3, 108, 512), (4, 33, 59)])
+def test_fwd_combine_op_follows_the_reference_test(num_splits, seqlen, d, dtype):
+    """The reference's own test of the op (hopper/tests/test_flash_attn.py:1190-1229): non-contiguous partials, -inf splits, the
+    transposed LSE layout, its tolerance rule. ``flash_attn_combine`` is the same op call, bit for bit."""
+    torch.random.manual_seed(1)
+    batch_size, nheads = 5, 16
+    out_partial = torch.randn(num_splits * 2, batch_size, nheads, seqlen, d, device=DEV, dtype=torch.float32).transpose(2, 3)[:num_splits]
+    lse_partial = torch.randn(num_splits, batch_size, nheads * 2, seqlen, device=DEV, dtype=torch.float32).transpose(-1, -2)[:, :, :, :nheads]
+    lse_partial[num_splits // 2:, :batch_size // 3] = -float("inf")
+    out, lse = torch.ops.lite_attention.fwd_combine(out_partial, lse_partial, None, dtype)
+    out_ref, lse_ref = orc.attention_combine_ref(out_partial.cpu(), lse_partial.cpu())
+    out_pt = out_ref.to(dtype)
+    assert tuple(out.shape) == (batch_size, seqlen, nheads, d) and out.dtype == dtype and tuple(lse.shape) == (batch_size, seqlen, nheads)
+    assert torch.allclose(lse.cpu(), lse_ref, atol=1e-5, rtol=1e-5)
+    assert ((out.cpu() - out_ref).abs().max().item() <= 2 * (out_pt - out_ref).abs().max().item()) or torch.allclose(out.cpu(), out_pt, atol=1e-5, rtol=1e-5)
+    out2, lse2 = L.flash_attn_combine(out_partial, lse_partial, out_dtype=dtype)
+    assert torch.equal(out2, out) and torch.equal(lse2, lse)
+    # the layout flash_attn_func returns (num_splits, batch, nheads, seqlen) gives the same numbers, LSE in that layout
+    out3, lse3 = L.flash_attn_combine(out_partial, lse_partial.transpose(-1, -2).contiguous(), out_dtype=dtype)
+    assert torch.equal(out3, out) and torch.equal(lse3, lse.transpose(1, 2))
+    # out= is filled in place
+    buf = torch.empty(batch_size, seqlen, nheads, d, device=DEV, dtype=dtype)
+    out4, _ = torch.ops.lite_attention.fwd_combine(out_partial, lse_partial, buf, dtype)
+    assert out4.data_ptr() == buf.data_ptr() and torch.equal(buf, out)
+
+
+def test_fwd_combine_error_behaviour():
+    op = torch.zeros(2, 1, 4, 2, 64, device=DEV)
+    lp = torch.zeros(2, 1, 2, 4, device=DEV).transpose(-1, -2)
+    with pytest.raises(RuntimeError, match="fp32"):
+        torch.ops.lite_attention.fwd_combine(op, lp.double(), None, None)
+    with pytest.raises(RuntimeError, match="seqlen dimension"):
+        torch.ops.lite_attention.fwd_combine(op, torch.zeros(2, 1, 4, 2, device=DEV), None, None)
+    with pytest.raises(RuntimeError, match="Output type"):
+        torch.ops.lite_attention.fwd_combine(op, lp, None, torch.float64)
+    with pytest.raises(RuntimeError, match="at most 256"):
+        torch.ops.lite_attention.fwd_combine(torch.zeros(257, 1, 4, 2, 64, device=DEV), torch.zeros(257, 1, 2, 4, device=DEV).transpose(-1, -2), None, None)
+
+
+def test_device_slots_come_from_the_device():
+    cus, per = _cabi.device_slots(128, 2)
+    assert cus == torch.cuda.get_device_properties(0).multi_processor_count and per == 1
+    assert _cabi.device_slots(128, 1) == (cus, 1)
+    assert _cabi.device_slots(128, 2, _cabi.LA_FLAG_KERNEL_128ROW) == (cus, 2) and _cabi.device_slots(256, 2, _cabi.LA_FLAG_KERNEL_128ROW) == (cus, 1)
+    from liteattention_amd.parallel import HeadShardedLiteAttention   # noqa: F401  (plan_q_windows asks the library: test_distributed_cpu)
+
+
+@pytest.mark.parametrize("D", [64, 96])
+def test_fp8_packed_batch_below_head_dim_128_keeps_descales_and_returns_bf16(D):
+    """the zero-padded recursion of the varlen path dropped q/k/v_descale and allocated `out` as e4m3. Per
+    sequence the packed result must equal the fixed-length fp8 call (which pads the same way) bit for bit, with non-unit descales,
+    and stay inside the fp8 bound against the oracle on the descaled operands."""
+    from liteattention_amd.flash_attn_interface import mha_fwd
+    F8 = torch.float8_e4m3fn
+    H, Hk = 4, 2
+    lens_q, lens_k = [300, 77, 0, 520], [410, 64, 30, 520]
+    B = len(lens_q)
+    g = torch.Generator().manual_seed(21)
+    qs = [torch.randn(n, H, D, generator=g).to(F8) for n in lens_q]
+    ks = [torch.randn(n, Hk, D, generator=g).to(F8) for n in lens_k]
+    vs = [torch.randn(n, Hk, D, generator=g).to(F8) for n in lens_k]
+    cat8 = lambda ts: torch.cat([t.view(torch.uint8) for t in ts]).view(F8)          # noqa: E731
+    cu = lambda lens: torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)   # noqa: E731
+    qd, kd, vd = [(0.5 + 1.5 * torch.rand(B, Hk, generator=g)).to(DEV) for _ in range(3)]
+    o, lse, *_ = mha_fwd(cat8(qs).to(DEV), cat8(ks).to(DEV), cat8(vs).to(DEV), cu_seqlens_q=cu(lens_q), cu_seqlens_k=cu(lens_k),
+                         max_seqlen_q=max(lens_q), max_seqlen_k=max(lens_k), q_descale=qd, k_descale=kd, v_descale=vd)
+    assert o.dtype == torch.bfloat16 and tuple(o.shape) == (sum(lens_q), H, D) and tuple(lse.shape) == (H, sum(lens_q))
+    r0 = 0
+    for b in range(B):
+        if lens_q[b] == 0:
+            continue
+        sq = slice(r0, r0 + lens_q[b])
+        r0 += lens_q[b]
+        o_b, lse_b, *_ = mha_fwd(qs[b][None].to(DEV), ks[b][None].to(DEV), vs[b][None].to(DEV), q_descale=qd[b:b + 1],
+                                 k_descale=kd[b:b + 1], v_descale=vd[b:b + 1])
+        assert torch.equal(o[sq], o_b[0]) and torch.equal(lse[:, sq], lse_b[0]), b
+        # against the oracle on the descaled operands (softmax_scale = D^-0.5 of the ORIGINAL head dim)
+        rep = H // Hk
+        qf = qs[b].float() * (qd[b].cpu() * kd[b].cpu()).repeat_interleave(rep)[None, :, None]
+        vf = vs[b].float() * vd[b].cpu()[None, :, None]
+        ref, lse_ref = orc.attention_dense_ref(qf[None], ks[b].float()[None], vf[None])
+        assert (o[sq].float().cpu() - ref[0]).abs().max().item() <= 0.05 * ref.abs().max().item() + 2e-2, b
+        assert (lse[:, sq].cpu() - lse_ref[0]).abs().max().item() <= 0.09, b
+    with pytest.raises(RuntimeError, match="bf16 for fp8"):
+        mha_fwd(cat8(qs).to(DEV), cat8(ks).to(DEV), cat8(vs).to(DEV), out=torch.empty(sum(lens_q), H, D, dtype=F8, device=DEV).view(F8),
+                cu_seqlens_q=cu(lens_q), cu_seqlens_k=cu(lens_k), max_seqlen_q=max(lens_q), max_seqlen_k=max(lens_k))

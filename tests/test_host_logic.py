@@ -299,3 +299,33 @@ def test_head_dim_is_served_by_the_next_instantiated_size(monkeypatch):
     monkeypatch.setenv("LA_FWD_KERNEL", "v2")
     assert [kernel_head_dim(d, 2) for d in (64, 96, 128, 192, 256)] == [64, 128, 128, 256, 256]
     assert get_tile_sizes(96, 2) == get_tile_sizes(64, 2) == (128, 64) and get_tile_sizes(128, 1) == (256, 64)
+
+
+def test_op_schemas_are_backward_compatible_with_the_reference_registration():
+    """The reference pins its op schemas with ``is_backward_compatible_with`` (hopper/tests/test_flash_attn.py:1236-1274, under a stale
+    namespace). The same check against the schemas the reference REGISTERS for the two forward-path ops (flash_api.cpp:1723-1762 fwd with
+    the four LiteAttention arguments, :1787-1791 fwd_combine), under the namespace it registers them in."""
+    from torch._C import parse_schema
+    assert torch.ops.lite_attention.fwd.default._schema.is_backward_compatible_with(parse_schema(
+        "lite_attention::fwd(Tensor q, Tensor k, Tensor v, Tensor(k_new!)? k_new=None, "
+        "Tensor(v_new!)? v_new=None, Tensor? q_v=None, Tensor(out!)? out=None, "
+        "Tensor? cu_seqlens_q=None, Tensor? cu_seqlens_k=None, "
+        "Tensor? cu_seqlens_k_new=None, Tensor? seqused_q=None, Tensor? seqused_k=None, "
+        "int? max_seqlen_q=None, int? max_seqlen_k=None, Tensor? page_table=None, "
+        "Tensor? kv_batch_idx=None, Tensor? leftpad_k=None, Tensor? rotary_cos=None, Tensor? rotary_sin=None, "
+        "Tensor? seqlens_rotary=None, Tensor? q_descale=None, Tensor? k_descale=None, Tensor? v_descale=None, "
+        "float? softmax_scale=None, bool is_causal=False, int window_size_left=-1, int window_size_right=-1, "
+        "int attention_chunk=0, float softcap=0., bool is_rotary_interleaved=False, "
+        "Tensor? scheduler_metadata=None, int num_splits=0, bool? pack_gqa=None, int sm_margin=0, "
+        "Tensor? attn_read_list=None, Tensor? attn_must_do_list=None, Tensor? attn_write_list=None, float thr=-3.0) "
+        "-> (Tensor(out!), Tensor, Tensor, Tensor)"))
+    assert torch.ops.lite_attention.fwd_combine.default._schema.is_backward_compatible_with(parse_schema(
+        "lite_attention::fwd_combine(Tensor out_partial, Tensor lse_partial, Tensor(out!)? out=None, "
+        "ScalarType? out_dtype=None) -> (Tensor(out!), Tensor)"))
+    # shapes through the Meta key: lse comes back as the transposed view of (batch, nheads, seqlen), flash_api.cpp:1682
+    op = torch.empty(3, 2, 5, 4, 64, device="meta")
+    lp = torch.empty(3, 2, 4, 5, device="meta").transpose(-1, -2)
+    o, lse = torch.ops.lite_attention.fwd_combine(op, lp, None, torch.bfloat16)
+    assert o.shape == (2, 5, 4, 64) and o.dtype == torch.bfloat16 and lse.shape == (2, 5, 4) and lse.stride() == (20, 1, 5)
+    with pytest.raises((NotImplementedError, RuntimeError)):      # no CPU kernel, no fallback
+        torch.ops.lite_attention.fwd_combine(torch.zeros(2, 1, 4, 2, 64), torch.zeros(2, 1, 2, 4).transpose(-1, -2), None, None)
