@@ -375,8 +375,8 @@ def main():
         step_s, kern_s = timed(steps, warmup)
         flops_job = flops_rank * world
         listed_frac = listed_tiles_of_rows(rows) / (q_tiles * k_tiles)
-        kernel_name = ("la_prep_v_fp8_kernel + la_fwd_fp8_d128_x64_kernel<true>" if fp8 else
-                       f"la_fwd_bf16_d128_x64_kernel<true, {'true' if dtype_name == 'fp16' else 'false'}, 128>")   # <SKIPABLE, F16, D>
+        kernel_name = ("la_prep_v_fp8_kernel + la_fwd_x64_fp8_kernel<true>" if fp8 else
+                       f"la_fwd_x64_kernel<true, {'true' if dtype_name == 'fp16' else 'false'}, 128>")   # <SKIPABLE, F16, D>
         # algorithmic minimum HBM bytes of one launch: Q + K + V once at the input width, O once in bf16 (lists and LSE are <2 %)
         esz = 1 if fp8 else 2
         alg_bytes = B * S * Hl * D * (3 * esz + 2)

@@ -95,7 +95,7 @@ def _check_no_scratch(remarks: str, defines) -> None:
     for line in remarks.splitlines():
         if "Function Name:" in line:
             name = line.split("Function Name:")[1].split()[0]
-        elif "ScratchSize [bytes/lane]:" in line and name and "_x64_kernel" in name:
+        elif "ScratchSize [bytes/lane]:" in line and name and "la_fwd_x64_" in name:
             size = int(line.split("ScratchSize [bytes/lane]:")[1].split()[0])
             seen += 1
             if size != 0:

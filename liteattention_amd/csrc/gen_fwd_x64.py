@@ -839,7 +839,7 @@ def main():
     text = "\n".join(lines)
     path = sys.argv[1] if len(sys.argv) > 1 else "la_fwd_x64_body.inc"
     with open(path, "w") as f:
-        f.write("// GENERATED by gen_fwd_x64.py — do not edit. Inline-asm body of la_fwd_bf16_d128_x64_kernel.\n" if D == 128 else
+        f.write("// GENERATED by gen_fwd_x64.py — do not edit. Inline-asm body of la_fwd_x64_kernel.\n" if D == 128 else
                 f"// GENERATED by gen_fwd_x64.py (LA_X64_D={D}) — do not edit. Inline-asm body of la_fwd_bf16_x64_kernel<.., {D}>.\n")
         f.write('R"ASM(\n' + text + '\n)ASM"\n')
     print(f"wrote {path}: {len(lines)} lines, {text.count('v_mfma')} MFMAs")

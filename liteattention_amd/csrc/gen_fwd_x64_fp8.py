@@ -815,7 +815,7 @@ def main():
         f.write("// GENERATED by gen_fwd_x64_fp8.py together with the body of the same name — do not edit.\n")
         f.write(f"#define LA_X64F8_TAU_{mode} {TAU!r}f\n#define LA_X64F8_OFFSET_{mode} {P_OFFSET!r}f\n")
     with open(path, "w") as f:
-        f.write("// GENERATED by gen_fwd_x64_fp8.py — do not edit. Inline-asm body of la_fwd_fp8_d128_x64_kernel.\n")
+        f.write("// GENERATED by gen_fwd_x64_fp8.py — do not edit. Inline-asm body of la_fwd_x64_fp8_kernel.\n")
         f.write('R"ASM(\n' + text + '\n)ASM"\n')
     print(f"wrote {path}: {len(lines)} lines, {text.count('v_mfma')} MFMAs")
 

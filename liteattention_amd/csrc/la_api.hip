@@ -198,7 +198,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
                                        a->batch, a->seqlen_k, a->num_heads_k, p.k_tiles, stream, a->cu_seqlens_k);
         if (e8 == hipSuccess) {
             p.v = static_cast<const uint16_t*>(a->workspace);
-            e8 = la::launch_fwd_fp8_d128_x64(p, a->read_list != nullptr,
+            e8 = la::launch_fwd_x64_fp8(p, a->read_list != nullptr,
                                              (a->flags & LA_FLAG_EXACT_ROWSUM) ? 2 : (a->flags & LA_FLAG_EXACT_EXP) ? 1 : 0, stream);
         }
         if (e8 != hipSuccess) { g_last_hip_error = static_cast<int>(e8); return LA_ERR_LAUNCH; }
@@ -215,7 +215,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         p.work_counter = static_cast<unsigned*>(a->workspace);
     if (x64) {
         if (la::fwd_lds_bytes_x64(p.k_tiles, nullptr, a->head_dim) > 160 * 1024) return LA_ERR_SEQLEN;
-        err = la::launch_fwd_bf16_d128_x64(p, a->head_dim, skipable, f16, stream);
+        err = la::launch_fwd_x64(p, a->head_dim, skipable, f16, stream);
     } else {
         err = la::launch_fwd_bf16_v2(p, a->head_dim, skipable, f16, stream);
     }

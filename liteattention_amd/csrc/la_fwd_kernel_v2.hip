@@ -73,7 +73,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
 
 template <int D, bool SKIPABLE, bool F16>
 __global__ void __launch_bounds__(256, D > 128 ? 1 : 2)      // head_dim 256: O 128 + Q 64 + S 64 registers -> one wave per SIMD
-la_fwd_bf16_v2_kernel(const FwdParams p) {                   // (the name is historical: F16 selects fp16 instead of bf16 elements)
+la_fwd_v2_kernel(const FwdParams p) {                   // F16 selects fp16 instead of bf16 elements
     typedef Elem16<F16> E;
     typedef typename E::x8 ex8;
     typedef typename E::x4 ex4;
@@ -438,7 +438,7 @@ static hipError_t launch_v2(const FwdParams& p, hipStream_t stream) {
     FwdParams pp = p;
     const size_t lds = fwd_lds_bytes_v2(D, p.k_tiles, &pp.seq_cap);
     (void)hipGetLastError();   // drop any stale sticky error of this thread: only OUR launch is reported
-    auto kfn = la_fwd_bf16_v2_kernel<D, SKIPABLE, F16>;
+    auto kfn = la_fwd_v2_kernel<D, SKIPABLE, F16>;
     const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (err != hipSuccess) return err;

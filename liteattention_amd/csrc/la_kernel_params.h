@@ -81,9 +81,9 @@ inline hipError_t prepare_work_queue(FwdParams& p, bool skipable, int total, int
 size_t fwd_lds_bytes_v2(int head_dim, int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, bool f16, hipStream_t stream);   // 128-row hipcc-scheduled template: head_dim 64; 128 / 256 as the A/B kernels (LA_FLAG_KERNEL_128ROW)
 size_t fwd_lds_bytes_x64(int k_tiles, int* seq_cap_out, int head_dim, int* walk_buffers_out = nullptr);
-hipError_t launch_fwd_bf16_d128_x64(const FwdParams& p, int head_dim, bool skipable, bool f16, hipStream_t stream);  // 1 wave/SIMD; head_dim 128: 64 rows/wave, q-tile 256; 256: 32 rows/wave, q-tile 128
+hipError_t launch_fwd_x64(const FwdParams& p, int head_dim, bool skipable, bool f16, hipStream_t stream);  // 1 wave/SIMD; head_dim 128: 64 rows/wave, q-tile 256; 256: 32 rows/wave, q-tile 128
 size_t fwd_lds_bytes_x64_fp8(int k_tiles, int* seq_cap_out, int* walk_buffers_out = nullptr);
-hipError_t launch_fwd_fp8_d128_x64(const FwdParams& p, bool skipable, int p_mode, hipStream_t stream);   // 1 wave/SIMD, 64 rows/wave; p.v = V^T workspace
+hipError_t launch_fwd_x64_fp8(const FwdParams& p, bool skipable, int p_mode, hipStream_t stream);   // 1 wave/SIMD, 64 rows/wave; p.v = V^T workspace
 size_t fp8_workspace_bytes(int batch, int num_heads_k, int k_tiles);
 hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_row_stride, int64_t v_head_stride,
                              void* vt, int batch, int seqlen_k, int num_heads_k, int k_tiles, hipStream_t stream,

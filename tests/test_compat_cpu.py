@@ -103,9 +103,9 @@ def test_build_rejects_scratch_in_the_x64_kernels():
     spec = importlib.util.spec_from_file_location("la_build_t", os.path.join(os.path.dirname(L.__file__), "build.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    ok = ("f.hip:1:1: remark: Function Name: _ZN2la27la_fwd_bf16_d128_x64_kernelILb1EEEvNS_9FwdParamsE [-Rpass]\n"
+    ok = ("f.hip:1:1: remark: Function Name: _ZN2la27la_fwd_x64_kernelILb1EEEvNS_9FwdParamsE [-Rpass]\n"
           "f.hip:1:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass]\n"
-          "f.hip:1:1: remark: Function Name: _ZN2la21la_fwd_bf16_v2_kernelILi256ELb1EEEvNS_9FwdParamsE [-Rpass]\n"
+          "f.hip:1:1: remark: Function Name: _ZN2la21la_fwd_v2_kernelILi256ELb1EEEvNS_9FwdParamsE [-Rpass]\n"
           "f.hip:1:1: remark:     ScratchSize [bytes/lane]: 272 [-Rpass]\n")
     b._check_no_scratch(ok, ())                                                  # the hipcc-scheduled 128-row kernels may spill
     bad = ok.replace("ScratchSize [bytes/lane]: 0", "ScratchSize [bytes/lane]: 48")

@@ -185,3 +185,56 @@ def test_fp8_packed_batch_below_head_dim_128_keeps_descales_and_returns_bf16(D):
     with pytest.raises(RuntimeError, match="bf16 for fp8"):
         mha_fwd(cat8(qs).to(DEV), cat8(ks).to(DEV), cat8(vs).to(DEV), out=torch.empty(sum(lens_q), H, D, dtype=F8, device=DEV).view(F8),
                 cu_seqlens_q=cu(lens_q), cu_seqlens_k=cu(lens_k), max_seqlen_q=max(lens_q), max_seqlen_k=max(lens_k))
+
+
+# ------------------------------------------------------------------------------ small parity fills
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_config0_golden_through_the_head_dim_64_kernel(dtype):
+    """BASELINE.json configs[0] (dense, 1 head, S = 2048, D = 64, fp32 eager on the CPU): the reference-generated ``out_ref`` of that
+    case against the head_dim-64 kernel on the inputs cast to bf16 / fp16, under the reference's own rule
+    (2 x the error of the same-dtype eager pass + fwd_atol, hopper/tests/test_flash_attn.py:266-296). The fixture's pt_maxerr is that of
+    an fp32 pass; the same-dtype pass is recomputed here from the cast inputs."""
+    from tests.helpers import load_dense_case
+    c = load_dense_case("cfg0_fp32_s2048_d64")
+    q, k, v = [x.to(dtype) for x in (c["q"], c["k"], c["v"])]
+    out, lse = L.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), return_softmax_lse=True)
+    assert out.dtype == dtype and tuple(out.shape) == (1, 2048, 1, 64)
+    o_pt, _ = orc.attention_dense_ref(q, k, v, upcast=False, reorder_ops=True)
+    o_up, lse_up = orc.attention_dense_ref(q, k, v)                  # fp32 math on the CAST inputs: what the kernel is asked to compute
+    tol = 2 * (o_pt.float() - o_up.float()).abs().max().item() + 2 * (c["out_ref"] + 0.3 - 0.3 - c["out_ref"]).abs().max().item()
+    assert (out.float().cpu() - o_up.float()).abs().max().item() <= tol
+    # and against the fp32 fixture itself: the input cast is the only extra error (same bound with the cast pass measured vs the fixture)
+    tol_fix = 2 * (o_pt.float() - c["out_ref"]).abs().max().item() + 2 * (c["out_ref"] + 0.3 - 0.3 - c["out_ref"]).abs().max().item()
+    assert (out.float().cpu() - c["out_ref"]).abs().max().item() <= tol_fix
+    assert (lse.cpu() - lse_up).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("D", [32, 64, 96, 128, 192, 256])
+def test_reference_script_known_answers_at_every_head_dim(D):
+    """/root/reference/test_lite_attention.py:7-93 loops over head dims 32 / 64 / 96 / 128 / 192 / 256 (32 runs zero-padded on the 64
+    kernel here): K1 thr = +inf -> every write row is [2, Kt-1, Kt-2]; K2 + must_do over everything -> write == read; K3 thr = -inf ->
+    write == read; K4 thr = 0: LSE against logsumexp (the script accepts 0.1; 1e-3 here). Fewer heads than the script's 32 (time)."""
+    import math
+    torch.manual_seed(0)
+    q, k, v = [torch.randn(2, 5000, 4, D, device=DEV, dtype=torch.bfloat16) for _ in range(3)]
+    bm, bn = L.LiteAttention.get_MN(D, 2)
+    Kt = math.ceil(5000 / bn)
+    attn = L.LiteAttention()
+    attn.threshold = float("inf")
+    attn(q, k, v)
+    assert (attn._skip_list[1, :2, ..., 0] == 2).all()
+    assert (attn._skip_list[1, :2, ..., 1] == Kt - 1).all() and (attn._skip_list[1, :2, ..., 2] == Kt - 2).all()
+    attn = L.LiteAttention()
+    attn.threshold = float("inf")
+    attn(q, k, v, must_do_list=[k.shape[1] - 1, 0])
+    assert (attn._skip_list[1] == attn._skip_list[0]).all()
+    attn = L.LiteAttention()
+    attn.threshold = float("-inf")
+    attn(q, k, v)
+    assert (attn._skip_list[1] == attn._skip_list[0]).all()
+    attn = L.LiteAttention()
+    attn.threshold = 0.0
+    out, lse = attn(q, k, v, return_softmax_lse=True)
+    qr, kr = q.permute(0, 2, 1, 3).float(), k.permute(0, 2, 1, 3).float()
+    lse_ref = torch.logsumexp(torch.matmul(qr, kr.transpose(-2, -1)) / D ** 0.5, dim=-1)
+    assert (lse_ref - lse).abs().max().item() < 1e-3
