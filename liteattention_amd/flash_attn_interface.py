@@ -17,14 +17,16 @@ missing HIP library fails at import of the native binding.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
+import threading
 from typing import Optional, Tuple
 
 import torch
 
 from . import _cabi
 
-__all__ = ["flash_attn_func", "FlashAttnFunc", "flash_attn_combine", "mha_combine", "get_tile_sizes", "skip_list_stats"]
+__all__ = ["flash_attn_func", "FlashAttnFunc", "flash_attn_combine", "mha_combine", "fwd_flags", "get_tile_sizes", "skip_list_stats"]
 
 _FWD_SCHEMA = (
     "fwd("
@@ -113,6 +115,29 @@ def _check_list(t: Optional[torch.Tensor], name: str, q: torch.Tensor) -> Option
     return t.data_ptr()
 
 
+_tls = threading.local()
+
+
+def _scoped_flags() -> int:
+    return getattr(_tls, "flags", 0)
+
+
+@contextlib.contextmanager
+def fwd_flags(flags: int):
+    """Every forward call made by this thread inside the block carries these extra ``la_fwd_args.flags`` (LA_FLAG_EXACT_RESCALE,
+    LA_FLAG_EXACT_ROWSUM, LA_FLAG_EXACT_EXP) - whichever surface it goes through (``LiteAttention.__call__``, ``flash_attn_func``, the
+    registered op, the varlen adapters): the reference's signatures have no argument for them. ``SeqParallelLiteAttention`` uses it to
+    get the reference's fp32-exact LSE for e4m3 inputs whose partial results are merged by LSE."""
+    if flags & ~(_cabi.LA_FLAG_EXACT_RESCALE | _cabi.LA_FLAG_EXACT_ROWSUM | _cabi.LA_FLAG_EXACT_EXP):
+        raise ValueError("fwd_flags accepts LA_FLAG_EXACT_RESCALE, LA_FLAG_EXACT_ROWSUM and LA_FLAG_EXACT_EXP only")
+    prev = _scoped_flags()
+    _tls.flags = prev | flags
+    try:
+        yield
+    finally:
+        _tls.flags = prev
+
+
 def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=None, cu_seqlens_k=None,
             cu_seqlens_k_new=None, seqused_q=None, seqused_k=None, max_seqlen_q=None, max_seqlen_k=None,
             page_table=None, kv_batch_idx=None, leftpad_k=None, rotary_cos=None, rotary_sin=None,
@@ -132,6 +157,7 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     collective running beside the launch gets CUs as items retire); "after_first" sets it on every window but the first
     (no collective is in flight beside window 0). ``_flags``: extra ``LA_FLAG_*`` bits ORed into ``la_fwd_args.flags`` (tests / A/B:
     LA_FLAG_EXACT_RESCALE, LA_FLAG_EXACT_ROWSUM, LA_FLAG_EXACT_EXP); kernel-selection bits that change the tile geometry are not accepted here."""
+    _flags |= _scoped_flags()
     if _flags & ~(_cabi.LA_FLAG_EXACT_RESCALE | _cabi.LA_FLAG_EXACT_ROWSUM | _cabi.LA_FLAG_EXACT_EXP):
         raise ValueError("_flags accepts LA_FLAG_EXACT_RESCALE, LA_FLAG_EXACT_ROWSUM and LA_FLAG_EXACT_EXP only")
     if not q.is_cuda:
@@ -440,6 +466,7 @@ def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
     a.num_heads, a.num_heads_k, a.head_dim, a.head_dim_v = H, Hk, D, D
     a.softmax_scale = float(softmax_scale)
     a.block_m, a.block_n = block_m, block_n
+    flags |= _scoped_flags()
     a.flags = flags & ((_cabi.LA_FLAG_EXACT_ROWSUM | _cabi.LA_FLAG_EXACT_EXP | _cabi.LA_FLAG_STATIC_SCHED) if is_fp8 else
                        (_cabi.LA_FLAG_KERNEL_128ROW | _cabi.LA_FLAG_EXACT_RESCALE | _cabi.LA_FLAG_STATIC_SCHED))
     a.cu_seqlens_q, a.cu_seqlens_k, a.total_q = cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), Tq

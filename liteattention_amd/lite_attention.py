@@ -269,11 +269,24 @@ class SeqParallelLiteAttention:
         self.num_nodes = num_nodes
         self.lite_attention = [LiteAttention(enable_skipping, threshold, max_batch_size) for _ in range(num_nodes)]
         self.set_threshold(threshold)
+        # e4m3 inputs with return_softmax_lse=True: the caller merges partial results by that LSE (README.md:222-250), so the split
+        # runs with the reference's row sums (LA_FLAG_EXACT_ROWSUM: fp32 sums of the un-rounded P, softmax.h:275-296; fp32-exact LSE)
+        # instead of the faster default whose LSE carries the 8-bit encoding of P. Set False to keep the default form.
+        self.exact_fp8_lse = True
 
     def __call__(self, query: Tensor, key: Tensor, value: Tensor, split_idx: int, scale: Optional[float] = None,
-                 return_softmax_lse: bool = False) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+                 return_softmax_lse: bool = False, *, q_descale: Optional[Tensor] = None, k_descale: Optional[Tensor] = None,
+                 v_descale: Optional[Tensor] = None) -> Union[Tensor, Tuple[Tensor, Tensor]]:
         assert split_idx < self.num_nodes, "split_idx must be less than num_nodes"
-        return self.lite_attention[split_idx](query, key, value, scale, return_softmax_lse)
+        kw = {}
+        if q_descale is not None or k_descale is not None or v_descale is not None:       # keyword-only extension, as LiteAttention.__call__
+            kw = dict(q_descale=q_descale, k_descale=k_descale, v_descale=v_descale)
+        if return_softmax_lse and self.exact_fp8_lse and query.dtype == torch.float8_e4m3fn:
+            from .flash_attn_interface import fwd_flags
+            from ._cabi import LA_FLAG_EXACT_ROWSUM
+            with fwd_flags(LA_FLAG_EXACT_ROWSUM):
+                return self.lite_attention[split_idx](query, key, value, scale, return_softmax_lse, **kw)
+        return self.lite_attention[split_idx](query, key, value, scale, return_softmax_lse, **kw)
 
     def reset_skip_state(self):
         for la in self.lite_attention:

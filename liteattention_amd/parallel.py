@@ -16,8 +16,8 @@ attention itself takes at every G in {2, 4, 8} (shard and work both shrink with 
 link), so a gather that starts after the kernel costs ~20 % of the step. The attention is therefore issued as
 several launches over q-tile WINDOWS of the same problem (C-ABI ``q_tile_begin/q_tile_count``): rows of window
 i are final when its launch completes, and their all-gather runs on RCCL's stream while window i+1 computes;
-only the last window's gather is exposed. Windows are whole numbers of workgroup ROUNDS (256 CUs x workgroups
-per CU), so splitting the launch adds no partially filled round. The result is then a list of per-window
+only the last window's gather is exposed. Windows are whole numbers of workgroup ROUNDS (compute units x workgroups
+per CU, asked from the library: ``la_device_slots``), so splitting the launch adds no partially filled round. The result is then a list of per-window
 gathered blocks ``[(G, B, rows_i, H/G, D), ...]`` (row-chunked, which is what a row-wise consumer such as the
 output projection wants); ``to_bshd`` accepts it too.
 """
@@ -65,7 +65,7 @@ class HeadShardedLiteAttention:
                  max_batch_size: int = 4, process_group=None,
                  attention_fn: Optional[Callable[..., torch.Tensor]] = None, overlap_windows: int = 1,
                  windowed_attention_fn: Optional[Callable[..., torch.Tensor]] = None,
-                 q_tile_rows: Optional[int] = None, _collective_at_world_1: bool = False):
+                 q_tile_rows: Optional[int] = None, _collective_at_world_1: bool = False, slots: Optional[int] = None):
         self.group = process_group
         if process_group is not None:
             import torch.distributed as dist
@@ -88,6 +88,7 @@ class HeadShardedLiteAttention:
                                                                                  static_sched="after_first", **kw)))
         self.overlap_windows = int(overlap_windows)
         self._q_tile_rows = q_tile_rows                # test seam (CPU stand-ins have no kernel tile); None = ask the library
+        self._slots = slots                            # with q_tile_rows: resident workgroups to plan windows for (default 256)
         # test seam: run the collective path on a 1-rank group too (an RCCL all-gather of one rank is a copy on RCCL's
         # stream), so a 1-GPU box exercises the real async-collective / stream-ordering code with the real kernels
         self._gather_min_world = 1 if _collective_at_world_1 else 2
@@ -99,13 +100,23 @@ class HeadShardedLiteAttention:
 
     def q_windows(self, q: torch.Tensor) -> List[Tuple[int, int]]:
         """The q-tile windows ``__call__`` uses for this query shape when ``overlap_windows`` > 1."""
-        if self._q_tile_rows is not None:
-            bm = self._q_tile_rows
+        if self._q_tile_rows is not None:              # test seam (CPU stand-in): no kernel, no device
+            bm, slots = self._q_tile_rows, self._slots if self._slots is not None else 256
         else:
+            from . import _cabi
             from .flash_attn_interface import get_tile_sizes
             bm, _ = get_tile_sizes(q.shape[-1], q.element_size())
-        slots = 256 if bm == 256 else 512              # x64: one workgroup per CU; 128-row kernels: two
+            cus, per_cu = _cabi.device_slots(q.shape[-1], q.element_size())   # the library knows the device and the kernel it would run
+            slots = cus * per_cu
         return plan_q_windows(-(-q.shape[1] // bm), q.shape[0] * q.shape[2], self.overlap_windows, slots)
+
+    def preflight_overlapped(self, q, k, v, scale: Optional[float] = None, **kw) -> None:
+        """The windowed launches of the overlapped form WITHOUT their collectives: what a rank can check on its own before all ranks
+        commit to the overlapped step (a rank that fails once its peers are inside a collective leaves them waiting there). Advances
+        the skip state by one call, like any call."""
+        if self._windowed is None:
+            raise RuntimeError("no windowed attention available (attention_fn stand-in without windowed_attention_fn)")
+        self._windowed(q, k, v, self.q_windows(q), lambda i, out, r0, r1: None, scale, **kw)
 
     def _call_overlapped(self, q, k, v, scale, _kernel_events, **kw) -> List[torch.Tensor]:
         import torch.distributed as dist
@@ -254,8 +265,10 @@ class RingSeqParallelLiteAttention:
             self.world, self.rank = 1, 0
         self.states = SeqParallelLiteAttention(self.world, enable_skipping, threshold, max_batch_size)
         # test seams (CPU/gloo): attention_fn(q, k, v, split_idx, scale) -> (out, lse); combine_fn(outs, lses) -> out
+        # e4m3 inputs: SeqParallelLiteAttention asks the library for the reference's row sums when the LSE is returned
+        # (LA_FLAG_EXACT_ROWSUM): the partial results are merged by it
         self._attention = attention_fn if attention_fn is not None else (
-            lambda q, k, v, j, scale: self.states(q, k, v, j, scale, return_softmax_lse=True))
+            lambda q, k, v, j, scale, **kw: self.states(q, k, v, j, scale, return_softmax_lse=True, **kw))
         if combine_fn is None:
             from .flash_attn_interface import flash_attn_combine
             combine_fn = lambda outs, lses: flash_attn_combine(outs, lses, return_lse=False)   # noqa: E731

@@ -235,19 +235,51 @@ def vote_writer_check(q: torch.Tensor, k: torch.Tensor, read_list: torch.Tensor,
 
 
 # ----------------------------------------------------------------------------------------- 50-step denoising workload
+# Constant thresholds (log2 units) at which the list the LAST of the 50 steps reads has 21 / 42 / 57 / 77 % +- 1 % sparsity with this
+# build's 256 x 64 tile on DenoiseWorkload(40 heads): bisected on all 40 heads by tools/calibrate_denoise.py, trace and result in
+# profiles/r04_denoise50_calibration.json (round 1's constants, bisected on 4 heads, gave 24.5 / 44.0 / 61.1 / 77.9 %).
+DENOISE_THRESHOLDS = (("21%", -5.157), ("42%", -4.220), ("57%", -3.399), ("77%", -2.462))
+REFERENCE_T_OVER_T0 = {"21%": 0.824, "42%": 0.601, "57%": 0.443, "77%": 0.235}     # /root/reference/README.md:81-87
+
+
 class DenoiseWorkload:
     """BASELINE.json configs[2]: synthetic, slowly varying, STRUCTURED q/k/v of a 50-step denoising loop at the Wan2.1 video shape
-    (iid randn gives ~0 % sparsity at any negative threshold). S = 21 frames x 3600 tokens; per head the frame centroids follow an
-    AR(1) walk (scores decay smoothly with frame distance); the last `sink` tokens are global anchor keys (QK-Skip walks keys in
-    descending order and can only drop tiles met after a row's dominant keys); step t: x_t = sqrt(1 - s_t^2) x0 + s_t n_t, s_t linear
-    0.5 -> 0.05, noise seed 10^6 + t. Generator and settings of tools/denoise_bench.py --alpha 6 --sink-gain 0.5, the settings of the
-    committed 50-step runs (profiles/r01e_denoise50.json)."""
+    (iid randn gives ~0 % sparsity at any negative threshold). S = 21 frames x 3600 tokens; step t: x_t = sqrt(1 - s_t^2) x0 + s_t n_t,
+    s_t linear 0.5 -> 0.05, noise seed 10^6 + t. Two generators of x0:
+
+    ``generator="anchored"`` (default; the committed 50-step runs since round 1, tools/denoise_bench.py --alpha 6 --sink-gain 0.5): per
+    head the frame centroids follow an AR(1) walk (scores decay smoothly with frame distance), alpha = 6, and the last `sink` tokens are
+    global anchor keys (QK-Skip walks keys in descending order and can only drop tiles met after a row's dominant keys).
+
+    ``generator="survey"``: the generator SURVEY.md 8(d) pins - per head h (seed 1234 + h) centroids = normalised randn smoothed over the
+    frames with [0.25, 0.5, 0.25], q0 = alpha u_f(i) + randn, k0 likewise, v0 = randn, alpha = 4, no anchor keys. Its structure is
+    weak (a same-frame score is 0.5 nat above a cross-frame one against a per-tile maximum of 4 sigma of noise): at the thresholds of the
+    anchored runs it skips almost nothing, which is why round 1 left it; profiles/r04_denoise50_calibration.json holds both side by side."""
     FRAMES, PER, D = 21, 3600, 128
 
-    def __init__(self, heads: int, device, steps: int = 50, alpha: float = 6.0, rho: float = 0.85, sink: int = 640,
-                 sink_gain: float = 0.5, seed: int = 1234):
-        self.steps, self.device = steps, device
+    def __init__(self, heads: int, device, steps: int = 50, alpha: Optional[float] = None, rho: float = 0.85, sink: int = 640,
+                 sink_gain: float = 0.5, seed: int = 1234, generator: str = "anchored"):
+        self.steps, self.device, self.generator = steps, device, generator
         S = self.S = self.FRAMES * self.PER
+        frame = torch.arange(S, device=device) // self.PER
+        if generator == "survey":
+            alpha = 4.0 if alpha is None else alpha
+            q0 = torch.empty(S, heads, self.D, device=device)
+            k0, v0 = torch.empty_like(q0), torch.empty_like(q0)
+            for h in range(heads):
+                g = torch.Generator(device=device).manual_seed(seed + h)
+                u = torch.randn(self.FRAMES, self.D, device=device, generator=g)
+                u = u / u.norm(dim=-1, keepdim=True)
+                pad = torch.cat([u[:1], u, u[-1:]])                                   # edge frames: replicate
+                u = 0.25 * pad[:-2] + 0.5 * pad[1:-1] + 0.25 * pad[2:]
+                q0[:, h] = alpha * u[frame] + torch.randn(S, self.D, device=device, generator=g)
+                k0[:, h] = alpha * u[frame] + torch.randn(S, self.D, device=device, generator=g)
+                v0[:, h] = torch.randn(S, self.D, device=device, generator=g)
+            self.base = (q0[None], k0[None], v0[None])
+            return
+        if generator != "anchored":
+            raise ValueError("generator must be 'anchored' or 'survey'")
+        alpha = 6.0 if alpha is None else alpha
         g = torch.Generator(device=device).manual_seed(seed)
         z = torch.randn(self.FRAMES, heads, self.D, device=device, generator=g)
         u = torch.empty_like(z)
@@ -255,7 +287,7 @@ class DenoiseWorkload:
         for f in range(1, self.FRAMES):
             u[f] = rho * u[f - 1] + (1 - rho ** 2) ** 0.5 * z[f]
         u = u / u.norm(dim=-1, keepdim=True)
-        cen = u[torch.arange(S, device=device) // self.PER]
+        cen = u[frame]
         q0 = alpha * cen + torch.randn(S, heads, self.D, device=device, generator=g)
         k0 = alpha * cen + torch.randn(S, heads, self.D, device=device, generator=g)
         anchor = u.mean(0)

@@ -114,3 +114,87 @@ def test_head_sharded_all_gather_world2(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+# ------------------------------------------------------------------------------------------ bench.py's N > 1 control flow, 4 ranks
+def _bench_worker(rank, world, port, tmpdir):
+    """the trial step of the overlapped all-gather, the agreement all-reduce, the fallback path (one rank is
+    made to fail) and the multi_gpu record - the module-level functions bench.py's main() calls - with MORE than two ranks. The
+    attention is a stand-in (the device op has no CPU form); heads 40 -> 10 per rank as SURVEY.md 8(e) partitions them."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from liteattention_amd.parallel import HeadShardedLiteAttention
+        from oracle import oracle as orc
+        dev = torch.device("cpu")
+        H, B, S, D = 40, 1, 64, 16
+        g = torch.Generator().manual_seed(0)
+        q, k, v = [torch.randn(B, S, H, D, generator=g) for _ in range(3)]
+        fail_on = {"rank": 2, "armed": True}
+        windowed_calls, plain_calls = [], []
+
+        def windowed_stand_in(qq, kk, vv, windows, hook, scale=None, **kw):
+            windowed_calls.append(len(windows))
+            if fail_on["armed"] and rank == fail_on["rank"]:
+                raise RuntimeError("injected: this rank cannot run the overlapped form")
+            out = orc.attention_dense_ref(qq, kk, vv, softmax_scale=scale)[0]
+            for i, (t0, n) in enumerate(windows):
+                hook(i, out, t0 * 16, min(qq.shape[1], (t0 + n) * 16))
+            return out
+
+        def stand_in(qq, kk, vv, scale=None, **kw):
+            plain_calls.append(tuple(qq.shape))
+            return orc.attention_dense_ref(qq, kk, vv, softmax_scale=scale)[0]
+
+        def make(overlap):
+            a = HeadShardedLiteAttention(num_heads=H, max_batch_size=B, process_group=dist.group.WORLD, overlap_windows=overlap,
+                                         attention_fn=stand_in, windowed_attention_fn=windowed_stand_in, q_tile_rows=16, slots=20)
+            return a, (a.shard(q), a.shard(k), a.shard(v))
+
+        assert bench.require_world(dist, 4) == 4
+        with pytest.raises(SystemExit):
+            bench.require_world(dist, 8)                      # the launcher made 4 ranks: a line for 8 would be a lie
+        with pytest.raises(SystemExit):
+            bench.require_world(None, 2)
+        barrier = dist.barrier
+
+        # 1) a rank fails the trial step -> EVERY rank falls back; the fallback (kernel, then one all-gather) is what gets timed
+        att, qkv = make(3)
+        assert (att.h0, att.h1) == (10 * rank, 10 * rank + 10) and len(att.q_windows(qkv[0])) >= 2
+        note = bench.agree_on_overlapped_form(att, qkv, dist, dev, lambda: None)
+        assert att.overlap_windows == 1 and note is not None
+        assert ("injected" in note) == (rank == 2) and ("another rank" in note) == (rank != 2)
+        n_plain = len(plain_calls)
+        step_s, kern_s = bench.timed_steps(att, qkv, 3, 1, barrier, dist, dev, bench.HostEvent)
+        assert len(plain_calls) - n_plain == 4 and step_s > 0 and kern_s > 0 and kern_s <= step_s * 1.5
+        rec = bench.multi_gpu_record(dist, dev, kern_s, att, qkv[0])
+        assert rec["rccl_world_size"] == 4 and rec["backend"] == "gloo" and len(rec["kernel_ms_per_rank"]) == 4
+        assert rec["heads_per_rank"] == [[0, 10], [10, 20], [20, 30], [30, 40]]
+        assert rec["output_shard_bytes"] == B * S * 10 * D * 2 and rec["bytes_received_per_rank_per_step"] == 3 * rec["output_shard_bytes"]
+        assert rec["overlapped_form_kept"] is False and rec["overlap_windows"] == 1
+        full = HeadShardedLiteAttention.to_bshd(att(*qkv))
+        ref = orc.attention_dense_ref(q, k, v)[0]
+        assert torch.allclose(full, ref, atol=1e-6)
+
+        # 2) nobody fails -> the overlapped form is kept and timed; same numbers
+        fail_on["armed"] = False
+        att, qkv = make(3)
+        assert bench.agree_on_overlapped_form(att, qkv, dist, dev, lambda: None) is None and att.overlap_windows == 3
+        n_w = len(windowed_calls)
+        step_s, kern_s = bench.timed_steps(att, qkv, 2, 1, barrier, dist, dev, bench.HostEvent)
+        assert len(windowed_calls) - n_w == 3 and n_w == 3      # before the timed loop: rank 2's failed preflight, this preflight, the trial step
+        rec = bench.multi_gpu_record(dist, dev, kern_s, att, qkv[0])
+        assert rec["overlapped_form_kept"] is True and rec["overlap_windows"] == len(att.q_windows(qkv[0])) >= 2
+        assert torch.allclose(HeadShardedLiteAttention.to_bshd(att(*qkv)), ref, atol=1e-6)
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_multi_gpu_control_flow_world4(tmp_path):
+    world = 4
+    port = _free_port()
+    mp.spawn(_bench_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1", "ok2", "ok3"]

@@ -238,3 +238,54 @@ def test_reference_script_known_answers_at_every_head_dim(D):
     qr, kr = q.permute(0, 2, 1, 3).float(), k.permute(0, 2, 1, 3).float()
     lse_ref = torch.logsumexp(torch.matmul(qr, kr.transpose(-2, -1)) / D ** 0.5, dim=-1)
     assert (lse_ref - lse).abs().max().item() < 1e-3
+
+
+# ------------------------------------------------------------------------------ fp8 partial results merged by LSE
+@pytest.mark.parametrize("form", ["seq_parallel_default", "encoded", "exact_exp", "exact_rowsum"])
+def test_fp8_four_split_merge_against_the_fp8_oracle_on_the_full_keys(form, monkeypatch):
+    """A ring-style / sequence-parallel caller: K/V in 4 shards, one fp8 forward per shard (SeqParallelLiteAttention, one skip state
+    each), partial results merged by their LSE (flash_attn_combine; oracle hopper/tests/test_flash_attn.py:1178-1187) - against the
+    fp8 oracle (the reference's arithmetic, p_round='fp8', softmax.h:85-87,275-296) on the FULL K/V, under the stated fp8 bound
+    (0.05 max|O| + 2e-2), in all three forms of P. `seq_parallel_default` is what the class does by itself for e4m3 inputs with
+    return_softmax_lse=True: LA_FLAG_EXACT_ROWSUM, so the merged LSE is fp32-exact (1e-3); the two forms whose row sums are those of the
+    8-bit P carry that noise into the merge weights: their merged LSE is held to the per-form bound of tests/helpers.py and their
+    merged O to the same fp8 bound."""
+    from liteattention_amd import _cabi as C
+    from liteattention_amd.flash_attn_interface import fwd_flags
+    for v_ in ("LA_FP8_EXP", "LA_FP8_ROWSUM"):
+        monkeypatch.delenv(v_, raising=False)
+    F8 = torch.float8_e4m3fn
+    B, Sq, Sk, H, Hk, D, G = 1, 700, 2048, 4, 2, 128, 4
+    g = torch.Generator().manual_seed(33)
+    q = torch.randn(B, Sq, H, D, generator=g).to(F8)
+    k = torch.randn(B, Sk, Hk, D, generator=g).to(F8)
+    v = torch.randn(B, Sk, Hk, D, generator=g).to(F8)
+    qd, kd, vd = [(0.5 + torch.rand(B, Hk, generator=g)) for _ in range(3)]
+    sp = L.SeqParallelLiteAttention(G, threshold=-30.0, max_batch_size=B)
+    flags = {"seq_parallel_default": 0, "encoded": 0, "exact_exp": C.LA_FLAG_EXACT_EXP, "exact_rowsum": C.LA_FLAG_EXACT_ROWSUM}[form]
+    sp.exact_fp8_lse = form == "seq_parallel_default"
+    outs, lses = [], []
+    Sl = Sk // G
+    for j in range(G):
+        with fwd_flags(flags):
+            o, lse = sp(q.to(DEV), k[:, j * Sl:(j + 1) * Sl].to(DEV), v[:, j * Sl:(j + 1) * Sl].to(DEV), j, return_softmax_lse=True,
+                        q_descale=qd.to(DEV), k_descale=kd.to(DEV), v_descale=vd.to(DEV))
+        outs.append(o)
+        lses.append(lse)
+    out, lse = L.flash_attn_combine(torch.stack(outs), torch.stack(lses))
+    assert out.dtype == torch.bfloat16 and tuple(lse.shape) == (B, H, Sq)
+    rep = H // Hk
+    bm, bn = L.get_tile_sizes(D, 1)
+    o_ref, lse_ref, _ = orc.qkskip_fwd(q.float(), k.float(), v.float(), block_m=bm, block_n=bn, p_round="fp8",
+                                       q_descale=qd, k_descale=kd, v_descale=vd)
+    err = (out.float().cpu() - o_ref).abs().max().item()
+    assert err <= 0.05 * o_ref.abs().max().item() + 2e-2, (form, err)
+    lse_tol = {"seq_parallel_default": 1e-3, "exact_rowsum": 1e-3, "exact_exp": 0.0606, "encoded": 0.083}[form]
+    lse_err = (lse.cpu() - lse_ref).abs().max().item()
+    assert lse_err <= lse_tol, (form, lse_err)
+    # the merge itself against the merge oracle on the SAME partials (attention_combine_ref)
+    m_ref, ml_ref = orc.attention_combine_ref(torch.stack(outs).float().cpu(), torch.stack(lses).cpu().transpose(-1, -2))
+    assert (out.float().cpu() - m_ref).abs().max().item() <= 2.0 ** -7 * m_ref.abs().max().item() + 1e-5
+    assert torch.allclose(lse.cpu(), ml_ref.transpose(1, 2), atol=1e-5, rtol=1e-5)
+    if form == "seq_parallel_default":        # and the long-row statistics: exact row sums leave no bias in the merged LSE
+        assert (lse.cpu() - lse_ref).mean().abs().item() <= 1e-4
