@@ -130,7 +130,8 @@ S_TB, S_VB, S_EXEC, S_T64, S_T64B = 42, 44, 46, 48, 50   # 64-bit temps
 (S_KRS, S_VRS, S_LASTROW, S_NTILES, S_C, S_THR, S_TAILVALID, S_FIRSTLAST, S_TAB, S_DOFLAGS, S_WAVE, S_I, S_DOMASK,
  S_FREE0, S_FREE1, S_FREE2, S_LDS, S_T0, S_T1, S_T2, S_T3, S_NM1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_PARAM, S_DOWORD, S_NEGC,
  S_FREE3, S_DMAW, S_FREE4, S_TAU, S_RESC, S_FREE5) = range(52, 87)
-S_FREE6, S_TB2, S_VB2, S_BIT = 87, 88, 90, 92    # second set of DMA bases (the loop is unrolled by two); the rotating vote bit
+S_FREE6, S_TB2, S_VB2, S_BIT = 87, 88, 90, 92
+S_ONES = S_FREE0                                 # packed (1.0, 1.0) of the element type: src0 of the row-sum dot (dotsum)    # second set of DMA bases (the loop is unrolled by two); the rotating vote bit
 S_CC = 94                                        # s[94:95] = (c, c): scalar operand of v_pk_fma_f32
 TBS, VBS = [S_TB, S_TB2], [S_VB, S_VB2]
 
@@ -216,9 +217,19 @@ def v_read(slot, vbuf_imm, m):
             ("LDS", f"ds_read_b64_tr_b16 {vr(VF[slot] + 2, 2)}, {v(VADDR[db & 3])} offset:{off + 8 * ROW}", ("v", m, 1))]
 
 
+# PRICING ONLY (wrong results; profiles/r04_power_ceiling.md): every 32x32x16 MFMA replaced by TWO 16x16x32 MFMAs on the same operand
+# registers (the same FLOPs, 4-register accumulators taken round-robin from the 16 of the original) - what the matrix pipe costs in the
+# other shape, inside the real loop with its real operand data. `mfma16:qk` / `mfma16:pv` / `mfma16:both`.
+MFMA16 = opt_val("mfma16", "")
+MFMA16_OP = {"bf16": "v_mfma_f32_16x16x32_bf16", "f16": "v_mfma_f32_16x16x32_f16"}[DTYPE]
+
+
 def mfma_qk(sset, j, qb):
     kb, ks = j // KS, j % KS
     d = S_(sset, kb, qb)
+    if MFMA16 in ("qk", "both"):
+        quads = [(2 * ks) % 4, (2 * ks + 1) % 4]
+        return "\n".join(f"    {MFMA16_OP} {vr(d + 4 * qd, 4)}, {KFRAG(j)}, {ar(QA(qb, ks), 4)}, {'0' if ks < 2 else vr(d + 4 * qd, 4)}" for qd in quads)
     c = "0" if ks == 0 else vr(d, 16)
     return f"    {MFMA_OP} {vr(d, 16)}, {KFRAG(j)}, {ar(QA(qb, ks), 4)}, {c}"
 
@@ -226,9 +237,20 @@ def mfma_qk(sset, j, qb):
 def mfma_pv(sset, slot, m, qb):
     db, kk = m >> 2, m & 3
     pf = S_(sset, kk >> 1, qb) + 8 * (kk & 1)
+    if MFMA16 in ("pv", "both"):
+        o = O_(qb, db)
+        return "\n".join(f"    {MFMA16_OP} {ar(o + 4 * qd, 4)}, {vr(VF[slot], 4)}, {vr(pf, 4)}, {ar(o + 4 * qd, 4)}" for qd in ((2 * kk) % 4, (2 * kk + 1) % 4))
     return f"    {MFMA_OP} {ar(O_(qb, db), 16)}, {vr(VF[slot], 4)}, {vr(pf, 4)}, {ar(O_(qb, db), 16)}"
 
 
+# Row sums of the ROUNDED P by v_dot2c_f32_<type> (l += p0 * 1 + p1 * 1 on the packed 16-bit pair, fp32 accumulate): ONE instruction per
+# pair of scores behind the pack instead of two v_add_f32 in front of it - 32 of the step's VALU instructions fewer. l is then the sum
+# of exactly the weights the PV MFMA uses (O = sum P~ V / sum P~ is self-normalised); the LSE carries the rounding of P~ (RNE: unbiased,
+# |LSE - exact| <= 2^-9 for bf16, 2^-12 for fp16, on a row of one dominant key; 2^-9 / sqrt(n) on n comparable keys). The reference
+# sums the un-rounded fp32 P (softmax.h:275-296): this form is LA_FLAG_FAST_ROWSUM, never the default of the head_dim-128 body.
+DOTSUM = "dotsum" in OPT
+DOT_OP = {"bf16": "v_dot2c_f32_bf16", "f16": "v_dot2c_f32_f16"}[DTYPE]
+ONES_BITS = {"bf16": "0x3f803f80", "f16": "0x3c003c00"}[DTYPE]
 PK = "pk" in OPT           # packed-fp32 VALU (v_pk_fma_f32 / v_pk_add_f32). MEASURED ANTI-LEVER beside MFMAs: -64 issue slots
                            # per step but +300 quad-cycles of issue stall (1163 vs 1316 TFLOP/s); kept for A/B only
 
@@ -251,7 +273,12 @@ def softmax_parts(sset, p):
             A.append([f"    v_pk_add_f32 {vr(L0[qb], 2)}, {vr(L0[qb], 2)}, {vr(r0, 2)}"])
         else:
             F.append([f"    v_fma_f32 {v(ta)}, {v(r0)}, {s(S_C)}, {v(NMS[qb])}", f"    v_fma_f32 {v(tb)}, {v(r1)}, {s(S_C)}, {v(NMS[qb])}"])
-            A.append([f"    v_add_f32 {v(L0[qb])}, {v(L0[qb])}, {v(r0)}", f"    v_add_f32 {v(L1[qb])}, {v(L1[qb])}, {v(r1)}"])
+            if "mfmasum" in OPT:     # pricing only (wrong results): row sums from the matrix pipe, see step()
+                A.append([])
+            elif DOTSUM:       # behind the pack (emitted after C by the stream): alternate the two accumulators to keep the chains short
+                A.append([f"    {DOT_OP} {v(L0[qb] if (p & 1) == 0 else L1[qb])}, {s(S_ONES)}, {v(dst)}"])
+            else:
+                A.append([f"    v_add_f32 {v(L0[qb])}, {v(L0[qb])}, {v(r0)}", f"    v_add_f32 {v(L1[qb])}, {v(L1[qb])}, {v(r1)}"])
         E.append([f"    v_exp_f32 {v(r0)}, {v(ta)}", f"    v_exp_f32 {v(r1)}, {v(tb)}"])
         C.append([f"    {CVT_OP} {v(dst)}, {v(r0)}, {v(r1)}"])
     return F, E, A, C
@@ -261,7 +288,7 @@ def softmax_group(sset, p):
     if "nosoftmax" in OPT:
         return []
     F, E, A, C = softmax_parts(sset, p)
-    return [op for part in (F, E, A, C) for per_qb in part for op in per_qb]
+    return [op for part in ((F, E, C, A) if DOTSUM else (F, E, A, C)) for per_qb in part for op in per_qb]
 
 
 def softmax_stream(sset, groups):
@@ -282,16 +309,19 @@ def softmax_stream(sset, groups):
         for qb in range(NQB):
             # between / after the two exps of a q-block: the add(s) and the cvt of group g-1 (the cvt after BOTH of its
             # adds: it may overwrite r0 in place), and the fma(s) of group g+1 (their temporaries were just consumed)
-            fill0 = list(Ap[qb][:1]) if Ap else []
-            fill1 = (list(Ap[qb][1:]) if Ap else []) + (list(Fn[qb]) if Fn else []) + (list(Cp[qb]) if Cp else [])
+            if DOTSUM:                                      # the dot reads the packed pair: behind the cvt of its group
+                fill0 = []
+                fill1 = (list(Fn[qb]) if Fn else []) + (list(Cp[qb]) if Cp else []) + (list(Ap[qb]) if Ap else [])
+            else:
+                fill0 = list(Ap[qb][:1]) if Ap else []
+                fill1 = (list(Ap[qb][1:]) if Ap else []) + (list(Fn[qb]) if Fn else []) + (list(Cp[qb]) if Cp else [])
             if Fn and not PK:                               # scalar form: fma of temp a right after exp a
                 fill0 = [Fn[qb][0]] + fill0
                 fill1 = [x for x in fill1 if x is not Fn[qb][0]]
             o += [E[qb][0]] + fill0 + [E[qb][1]] + fill1
-    for qb in range(NQB):
-        o += parts[-1][2][qb]
-    for qb in range(NQB):
-        o += parts[-1][3][qb]
+    for part in ((3, 2) if DOTSUM else (2, 3)):
+        for qb in range(NQB):
+            o += parts[-1][part][qb]
     return o
 
 
@@ -491,7 +521,22 @@ def distribute(queue, post, start, cap):
 deferred = []     # out-of-line blocks emitted after the loop: callables
 
 
-def step(variant):
+HALFSKIP = int(opt_val("halfskip", "0"))     # PRICING ONLY: every wave sits out one step in HALFSKIP (no MFMA, no softmax, no fragment reads)
+
+
+def step(variant, light=False):
+    if light:                             # the step of a wave whose 128-row half does not list this tile: it still stages its DMA pieces,
+        saved = set(OPT)                  # follows the tile-address table and meets the barrier
+        OPT.update({"nomfma1", "nomfma2", "nosoftmax", "norowmax", "novread", "nokread", "nowaitv"})
+        try:
+            return _step(variant)
+        finally:
+            OPT.clear()
+            OPT.update(saved)
+    return _step(variant)
+
+
+def _step(variant):
     """One pipeline step; variant = parity of i: S_cur = S set `variant`, K(i+2)/V(i) in LDS buffer `variant`, DMA bases
     in SGPR set `variant` (computed during the previous step). Nothing but the drain, the barrier and the loop test sits
     between the last MFMA of a step and the first of the next."""
@@ -538,6 +583,14 @@ def step(variant):
             post[t] += v_read(f % 8, vbuf_cur, ord2[f + 8])
         if "nokread" not in OPT and not K_EARLY and (t < NKF if "klate" not in OPT else (t & 1) == 0):
             post[t].append(k_read(kbuf_read, ord1[t if "klate" not in OPT else f]))
+    if "mfmasum" in OPT:
+        # PRICING ONLY: the 64 v_add_f32 of the row sums are gone and one more MFMA per (q-block, 16-key group)
+        # stands for "ones x P^T" - 8 per step. No 32 accumulator registers are free in this register map, so the stand-in
+        # accumulates into O^T (finite garbage) with a Q fragment as its A operand (real data: prices the energy conservatively).
+        for kk in range(4):
+            for qb in range(NQB):
+                pf = S_(cur, kk >> 1, qb) + 8 * (kk & 1)
+                post[4 * kk + 2 * qb + 17].append(f"    {MFMA_OP} {ar(O_(qb, 0), 16)}, {ar(QA(qb, 0), 4)}, {vr(pf, 4)}, {ar(O_(qb, 0), 16)}")
     rare, back = new_label("rare"), new_label("rare_back")
     fl, flback = new_label("flush"), new_label("flush_back")
     # next step (i+1) stages K(i+4) and V(i+2): their global addresses come from the tile-address table the C++ shell built in
@@ -611,6 +664,8 @@ def prologue():
     emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, {ROW_SHIFT + 4}")      # a wave stages 16 rows = 2 / 4 / 8 KiB of a tile
     emit(f"s_add_u32 {s(S_DMAW)}, {s(S_DMAW)}, {s(S_LDS)}")
     emit(f"s_mov_b32 {s(S_I)}, 0")
+    if DOTSUM:
+        emit(f"s_mov_b32 {s(S_ONES)}, {ONES_BITS}")
     emit(f"s_mov_b32 {s(S_RESC)}, 0")
     emit(f"v_mov_b32 {v(NEGINF)}, 0xff800000")
 
@@ -824,12 +879,23 @@ def main():
     for _ in range(int(opt_val("pad4", "0"))):
         emit("s_nop 0")
     label(loop)
-    emit(f"s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}")
-    emit(f"s_cbranch_scc0 {done}")
-    step(0)
-    emit(f"s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}")
-    emit(f"s_cbranch_scc0 {done}")
-    step(1)
+    for variant in (0, 1):
+        emit(f"s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}")
+        emit(f"s_cbranch_scc0 {done}")
+        if HALFSKIP:
+            # waves 0-1 sit out the steps with i % HALFSKIP == 0, waves 2-3 those with i % HALFSKIP == HALFSKIP / 2: what a workgroup
+            # walking the union of two per-128-row lists would do on the tiles only one half lists (DESIGN.md section 8.6 a)
+            lbl, after = new_label("light"), new_label("after_light")
+            emit(f"s_lshr_b32 {s(S_T0)}, {s(S_WAVE)}, 1")
+            emit(f"s_mul_i32 {s(S_T0)}, {s(S_T0)}, {HALFSKIP // 2}")
+            emit(f"s_and_b32 {s(S_T1)}, {s(S_I)}, {HALFSKIP - 1}")
+            emit(f"s_cmp_eq_u32 {s(S_T0)}, {s(S_T1)}")
+            emit(f"s_cbranch_scc1 {lbl}")
+            step(variant)
+            label(after)
+            deferred.append(lambda lbl=lbl, after=after, variant=variant: (label(lbl), step(variant, light=True), emit(f"s_branch {after}")))
+        else:
+            step(variant)
     emit(f"s_branch {loop}")
     for blk in deferred:
         blk()

@@ -250,6 +250,40 @@ struct SchedGeom {
     }
 };
 
+#ifdef LA_SCHED_GANG
+// A/B variant (never the default build): GANG scheduling of the chunks. The C = 32 items of a chunk are taken by the
+// 32 workgroups of an XCD within a few microseconds of each other; an item of chunk c of queue x may START only when every item of
+// the chunks before c in that queue has FINISHED (eight more counters behind the ticket counters, one per queue: items finished). The
+// co-resident workgroups of an XCD then always work on one chunk - q-tiles [32 j, 32 j + 32) of one head, whose real lists overlap
+// most - instead of drifting over several chunks; the price is the wait for the slowest of 32 lists per chunk.
+// item -> (home queue, chunk index in that queue): the inverse of SchedGeom::item.
+__device__ __forceinline__ void gang_home(const FwdParams& p, int chunk, int vid, int* queue, int* chunk_in_queue) {
+    const SchedGeom geo(p, chunk);
+    constexpr int G = LA_SCHED_G;
+    const int bh = vid / geo.cnt, qi = (vid % geo.cnt + 1) % geo.cnt;        // item() stores (qi + cnt - 1) % cnt
+    const int grp = bh / G, g = min(G, geo.nbh - grp * G);
+    const int J = grp * G * geo.nch + (qi / geo.C) * g + (bh - grp * G);
+    *queue = J % kSchedQueues;
+    *chunk_in_queue = J / kSchedQueues;
+}
+// Bounded wait (a scheduling hint must never be able to hang the device): ~50 ms at most, then the item starts anyway.
+__device__ __forceinline__ void gang_wait(const FwdParams& p, int chunk, int vid) {
+    int x, c;
+    gang_home(p, chunk, vid, &x, &c);
+    const unsigned need = static_cast<unsigned>(c) * static_cast<unsigned>(chunk);
+    unsigned* const done = &p.work_counter[(kSchedQueues + x) * kSchedCounterStride];
+    for (int spin = 0; spin < (1 << 16); ++spin) {
+        if (atomicAdd(done, 0u) >= need) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+__device__ __forceinline__ void gang_done(const FwdParams& p, int chunk, int vid) {
+    int x, c;
+    gang_home(p, chunk, vid, &x, &c);
+    atomicAdd(&p.work_counter[(kSchedQueues + x) * kSchedCounterStride], 1u);
+}
+#endif
+
 // Returns the next item for this workgroup (bh * cnt + q-tile offset) or -1 when all queues are empty.
 // *own_empty (workgroup state, kept in LDS by the caller) remembers that the XCD's own queue has run dry.
 __device__ __forceinline__ int next_work_item(const FwdParams& p, int chunk, int* own_empty) {
@@ -263,6 +297,9 @@ __device__ __forceinline__ int next_work_item(const FwdParams& p, int chunk, int
             if (t >= static_cast<unsigned>(n)) return -1;
             const int it = geo.item(x, t);
             if (it >= 0) return it;          // -2: padding slot, take the next ticket
+#ifdef LA_SCHED_GANG
+            atomicAdd(&ctr[(kSchedQueues + x) * kSchedCounterStride], 1u);     // a padding slot counts as a finished item of its chunk
+#endif
         }
     };
     if (!*own_empty) {
@@ -324,7 +361,7 @@ __device__ __forceinline__ int expand_read_list(const int* __restrict__ row, int
         cnt = min(cnt, room);
         // short ranges (the common case of real lists: hundreds of ranges of a few tiles): the lane writes its own tiles;
         // the rest of a LONG range (imposed bands, early denoising steps: 1-2 ranges of hundreds of tiles, which one lane
-        // would write one LDS store at a time: 16 k cycles per item, tools/phase_profile.py) is filled by the whole wave
+        // would write one LDS store at a time: 16 k cycles per item, tools/phase_profile_real.py) is filled by the whole wave
         // (all loops here have wave-uniform trip counts with predicated bodies: la_fwd_kernel_x64.hip, "COMPILER HAZARD")
         constexpr int kOwn = 4;
 #pragma unroll

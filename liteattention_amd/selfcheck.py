@@ -237,8 +237,8 @@ def vote_writer_check(q: torch.Tensor, k: torch.Tensor, read_list: torch.Tensor,
 # ----------------------------------------------------------------------------------------- 50-step denoising workload
 # Constant thresholds (log2 units) at which the list the LAST of the 50 steps reads has 21 / 42 / 57 / 77 % +- 1 % sparsity with this
 # build's 256 x 64 tile on DenoiseWorkload(40 heads): bisected on all 40 heads by tools/calibrate_denoise.py, trace and result in
-# profiles/r04_denoise50_calibration.json (round 1's constants, bisected on 4 heads, gave 24.5 / 44.0 / 61.1 / 77.9 %).
-DENOISE_THRESHOLDS = (("21%", -5.157), ("42%", -4.220), ("57%", -3.399), ("77%", -2.462))
+# profiles/r04_denoise50_calibration.json (they give 21.0 / 42.2 / 57.1 / 77.3 %; round 1's constants -5.157 / -4.22 / -3.399 / -2.462, bisected on 4 heads, gave 24.5 / 44.0 / 61.1 / 77.9 %).
+DENOISE_THRESHOLDS = (("21%", -5.3438), ("42%", -4.3), ("57%", -3.6), ("77%", -2.5))
 REFERENCE_T_OVER_T0 = {"21%": 0.824, "42%": 0.601, "57%": 0.443, "77%": 0.235}     # /root/reference/README.md:81-87
 
 

@@ -29,3 +29,16 @@ def test_committed_traffic_figure_belongs_to_the_committed_kernel_sources():
     sha = bench.kernel_source_hash()
     for fn in ("pmc_summary.json", "pmc_summary_fp8.json"):
         assert json.load(open(os.path.join(ROOT, "profiles", fn)))["kernel_source_sha16"] == sha, fn
+
+
+def test_tools_readme_indexes_exactly_the_scripts_that_exist():
+    """tools/ had grown to 45 scripts with overlapping purposes. Every script in tools/ (and tools/debug/) is named
+    in tools/README.md, and every script the README names exists."""
+    import re
+    tools = os.path.join(ROOT, "tools")
+    readme = open(os.path.join(tools, "README.md")).read()
+    have = {f for f in os.listdir(tools) if f.endswith((".py", ".sh", ".hip"))} | \
+           {"debug/" + f for f in os.listdir(os.path.join(tools, "debug")) if f.endswith((".py", ".sh", ".hip"))}
+    named = set(re.findall(r"`((?:debug/)?[a-z0-9_]+\.(?:py|sh|hip))", readme))
+    assert have - named == set(), f"scripts tools/README.md does not index: {sorted(have - named)}"
+    assert named - have == set(), f"tools/README.md names scripts that do not exist: {sorted(named - have)}"

@@ -3,7 +3,7 @@
     python tools/asm_variants.py x_base=x64: x_nodma=x64:nodma f8_base=x64f8: ...
       name=x64:<opts>    gen_fwd_x64.py with LA_X64_OPT=<opts>
       name=x64f8:<opts>  gen_fwd_x64_fp8.py with LA_X64F8_OPT=<opts>
-      name=x64d<D>:<opts> gen_fwd_x64.py with LA_X64_D=<D> (96, 192, 256) LA_X64_OPT=<opts>
+      name=x64d<D>:<opts> gen_fwd_x64.py with LA_X64_D=<D> (64, 96, 192, 256) LA_X64_OPT=<opts>
     (GPU box)  LITEATTENTION_AMD_LIB=$PWD/build_variants/<name>.so python tools/abl_bench.py
 Ablation variants compute wrong results; they only price a component.
 """
@@ -23,7 +23,7 @@ def build_one(spec):
         opt, gen, env_key, macro = opt[6:], "gen_fwd_x64_fp8.py", "LA_X64F8_OPT", "LA_X64F8_BODY_INC"
     elif opt.startswith("x64:"):
         opt, gen, env_key, macro = opt[4:], "gen_fwd_x64.py", "LA_X64_OPT", "LA_X64_BODY_INC"
-    elif opt.startswith(("x64d96:", "x64d192:", "x64d256:")):      # the other head dims of the bf16 generator (bench with tools/d256_bench.py <D>)
+    elif opt.startswith(("x64d64:", "x64d96:", "x64d192:", "x64d256:")):      # the other head dims of the bf16 generator (bench with tools/d64_bench.py / tools/d256_bench.py <D>)
         dim = opt[4:opt.index(":")]
         opt, gen, env_key, macro = opt[opt.index(":") + 1:], "gen_fwd_x64.py", "LA_X64_OPT", f"LA_X64_D{dim}_BODY_INC"
         extra_env["LA_X64_D"] = dim
