@@ -518,6 +518,21 @@ def distribute(queue, post, start, cap):
     post[NG - 1] += q
 
 
+def emit_gaps(pre, mf, post):
+    """One phase: per gap the pre items, the MFMA, the fillers. Pricing variant mfma16 (two 16x16x32 MFMAs per gap): with `spread` the
+    second MFMA of a gap sits behind the first half of the gap's fillers instead of right behind the first (a 16x16x32 MFMA holds the
+    matrix pipe ~17 cycles: back to back, the second one stalls at issue)."""
+    for t in range(NG):
+        if MFMA16 and "spread" in OPT and "\n" in mf[t]:
+            a, b = mf[t].split("\n")
+            h = (len(post[t]) + 1) // 2
+            for it in pre[t] + [a] + post[t][:h] + [b] + post[t][h:]:
+                out.append(it)
+        else:
+            for it in pre[t] + [mf[t]] + post[t]:
+                out.append(it)
+
+
 deferred = []     # out-of-line blocks emitted after the loop: callables
 
 
@@ -565,9 +580,7 @@ def _step(variant):
             post[NG // 2 + f * (NG // 2) // 8] += v_read(f, vbuf_cur, ord2[f])
     vq = softmax_stream(cur, list(range(XPAIRS, 16)))
     distribute(vq, post, 0, CAP1)
-    for t in range(NG):
-        for it in pre[t] + [mf[t]] + post[t]:
-            out.append(it)
+    emit_gaps(pre, mf, post)
 
     # ---- phase 2: PV(i) || K(i+2) fragments -> AGPRs, rest of the V^T fragments, next step's DMA bases,
     #               stats(i+1), first part of softmax(i+1)
@@ -627,9 +640,7 @@ def _step(variant):
     # the first two gaps may only hold ops that do not read S_nxt (MFMA -> VALU read hazard): the SALU / seq part
     distribute(vq[:n_head], post, 0, CAP2 if CAP2 > 0 else 6)
     distribute(vq[n_head:], post, 2, CAP2)
-    for t in range(NG):
-        for it in pre[t] + [mf[t]] + post[t]:
-            out.append(it)
+    emit_gaps(pre, mf, post)
 
     # ---- tail: the rare O rescale, drain, barrier
     resc, resc_back = new_label("resc"), new_label("resc_back")
