@@ -61,6 +61,8 @@ def _compile(lib_path: str, defines, verbose: bool) -> str:
         env = dict(os.environ, LA_X64_D=str(head_dim), LA_X64_DTYPE=dtype)
         if head_dim != 128:                        # LA_X64_OPT tunes the head_dim-128 body (tools/asm_variants.py); the others have their own knob
             env["LA_X64_OPT"] = os.environ.get(f"LA_X64_D{head_dim}_OPT", "")
+            if head_dim == 64 and any(d.replace(" ", "") == "LA_D64_W2=1" for d in defines):
+                env["LA_X64_OPT"] = os.environ.get("LA_X64_D64_OPT", "w2")       # -DLA_D64_W2=1 (A/B build): the two-waves-per-SIMD body
         subprocess.run([sys.executable, os.path.join(CSRC, X64_GEN), os.path.join(CSRC, inc)], check=True, stdout=quiet, env=env)
     subprocess.run([sys.executable, os.path.join(CSRC, X64F8_GEN), os.path.join(CSRC, X64F8_INC)], check=True, stdout=quiet)
     for variant, inc in (("exp", X64F8_EXP_INC), ("lvalu", X64F8_LVALU_INC)):       # LA_X64F8_<VARIANT>_OPT tunes that body alone

@@ -60,10 +60,23 @@ CVT_OP = {"bf16": "v_cvt_pk_bf16_f32", "f16": "v_cvt_pk_f16_f32"}[DTYPE]        
 # 8 KiB, 2 DMA pieces per wave and tensor), K chunks swizzled by (row >> 1) & 7 and V 64-byte segments by (row >> 1) & 1 - the
 # conflict-free forms for a 128-byte pitch (16 consecutive rows of one chunk column / 4 rows x 64 bytes of a transpose read cover
 # all 64 banks once).
+# W2 (LA_X64_OPT=w2, head_dim 64 only; round 4): TWO waves per SIMD - a workgroup of EIGHT waves of 32 query rows (q-tile 256, as before).
+# At head_dim 64 a step has half the MFMAs of head_dim 128 under the same softmax, and a lone wave issues one instruction per ~4-5
+# cycles whatever it is: the one-wave body is issue-bound (MFMA busy 46 % at 2.1 GHz, waves issuing 78 % of the time). A second wave
+# per SIMD doubles the issue bandwidth, and one wave's softmax runs under the other's MFMAs. Two waves share the SIMD's 512 registers,
+# so a wave owns ONE 32-row q-block (as at head dims 192 / 256): O^T 32 + Q 16 + K fragments 32 AGPRs, S 32 + a 4-deep V^T ring + state
+# in 90 VGPRs, which leaves the C++ shell the registers it keeps across the body. Every K / V^T fragment then feeds ONE MFMA instead of
+# two: LDS reads double to 1 KiB per MFMA - 128 KiB per step and CU, half of what the LDS delivers in the 1024 cycles the step's MFMAs
+# take (256 B/clk/CU), and the second wave hides their latency. The intra-wave software pipeline of the one-wave body (two S buffers) is
+# gone: a step is QK -> row max / vote -> softmax -> PV in program order (step_w2), with the LDS reads and the DMA issue inside the two
+# MFMA runs; K and V are staged ONE tile ahead.
+W2 = "w2" in OPT
 D = int(os.environ.get("LA_X64_D", "128"))
 assert D in (64, 96, 128, 192, 256)
+assert not W2 or D == 64
 DL = 64 if D == 64 else (128 if D <= 128 else 256)   # layout head dim: LDS row pitch, q-blocks per wave, DMA pieces
-NQB = 2 if DL <= 128 else 1               # 32-row q-blocks per wave
+NQB = 1 if W2 else (2 if DL <= 128 else 1)   # 32-row q-blocks per wave
+NW = 8 if W2 else 4                       # waves per workgroup
 ROW_SHIFT = {64: 7, 128: 8, 256: 9}[DL]   # log2 of the LDS row pitch in bytes
 KS = D // 16                              # k-steps of S^T = K Q^T
 DB = D // 32                              # 32-wide d-blocks of O^T
@@ -71,7 +84,7 @@ ROW = 2 * DL                              # bytes per K / V row in LDS
 NKF, NVF = 2 * KS, 4 * DB                 # K fragments (A operands of QK) / V^T fragments (A operands of PV) per tile
 NG = NKF * NQB                            # MFMAs (= gaps for the other pipes) per phase: 32, or 24 for head dims 96 / 192
 assert NG == NVF * NQB
-PW = 16 * ROW // 1024                     # 1-KiB DMA pieces per wave per tile (a wave stages 16 of the 64 rows)
+PW = (64 // NW) * ROW // 1024             # 1-KiB DMA pieces per wave per tile (a wave stages 64 / NW of the 64 rows)
 # Where the K fragments of tile i+2 are read from LDS. Two q-blocks per wave: during phase 2 of step i (the LDS pipe has room there).
 # One q-block per wave (head dims 192 / 256): a phase moves the same 32 MFMAs over half the rows, so LDS bytes per MFMA double and
 # phase 2 (24 V^T + 32 K fragments = 56 KiB per wave, 85 % of the CU's LDS read rate) stalls the MFMAs; there every K fragment
@@ -85,7 +98,10 @@ CAP1 = int(opt_val("cap1", "0"))          # fillers per MFMA gap the distributor
 CAP2 = int(opt_val("cap2", "0"))
 DMA_GAPS = [int(x) for x in opt_val("dmagaps", {128: "1,2,4,6,8,10,11,13,15,17", 96: "0,1,3,4,6,7,8,9,11,12", 64: "1,2,4,8,9,11"}[D] if DL <= 128 else
                                     "1,2,3,4,5,7,8,9,10,11,13,14,15,16,17,19,20,21,22,23").replace(".", ",").split(",")]   # m0K,K0..3,m0V,V0..3 (phase 1)
-assert max(DMA_GAPS) < NG
+assert W2 or max(DMA_GAPS) < NG          # (step_w2 places its DMA pieces itself)
+
+Q_A0, K_A0 = (32, 48) if W2 else (128, 192)     # first AGPR of the Q fragments / of the K fragments
+
 
 # ---------------------------------------------------------------- AGPR map
 def O_(qb, db):
@@ -93,13 +109,13 @@ def O_(qb, db):
 
 
 def QA(qb, ks):
-    return 128 + 4 * KS * qb + 4 * ks
+    return Q_A0 + 4 * KS * qb + 4 * ks
 
 
 def KFRAG(j):
     """Operand of K fragment j = kb * KS + ks. head_dim 128: a[192:255]. head_dim 256: 32 fragments; key block 0 in a[192:255],
     key block 1 in v[64:127] (the S buffers are half the size there; an MFMA A operand may be either file)."""
-    return f"a[{192 + 4 * j}:{192 + 4 * j + 3}]" if j < 16 else f"v[{64 + 4 * (j - 16)}:{64 + 4 * (j - 16) + 3}]"
+    return f"a[{K_A0 + 4 * j}:{K_A0 + 4 * j + 3}]" if j < 16 else f"v[{64 + 4 * (j - 16)}:{64 + 4 * (j - 16) + 3}]"
 
 
 # ---------------------------------------------------------------- VGPR map
@@ -123,6 +139,16 @@ QROW = [216, 217]
 RAGK, RAGV = 218, 219                     # ragged-path swizzled chunk offsets (constants)
 MTHR = [220, 221]                         # m_ref + tau/c: the lazy-rescale trigger level
 TABV = 222                                # LDS address of tab[i + 2], the tile-address table entry step i reads from
+if W2:                                    # 90 VGPRs: S v[0:31] (one buffer), V^T ring v[32:47] (4 slots), addresses / state / temporaries
+    VF = [32 + 4 * i for i in range(4)]
+    KADDR = list(range(48, 52)) + [0] * 4
+    VADDR = [52, 53, 0, 0]
+    LK, LV = [54], [55]
+    MTRUE, MREF, NMS, MLOC, L0, L1, MTHR, QROW = [56], [57], [58], [59], [60], [61], [62], [63]
+    NEGINF, HH4, TABV = 64, 65, 66
+    T = list(range(68, 84))               # (T[4], T[5]) an even-aligned pair
+    ALPHA, MLOC2 = [84], [85]
+    LANE, RIPROW, RAGK, RAGV = 86, 87, 88, 89
 
 # ---------------------------------------------------------------- SGPR map (s32-s34 are ABI-reserved: unused)
 S_KBASE, S_VBASE, S_QBASE = 36, 38, 40    # 64-bit
@@ -326,6 +352,8 @@ def softmax_stream(sset, groups):
 
 
 def row_max_ops(sset):
+    if "norowmax" in OPT and W2:
+        return []
     """In-lane max of the 32 scores of each q-block into MLOC[qb] (two max3 chains each), interleaved over q-blocks."""
     per = []
     for qb in range(NQB):
@@ -654,6 +682,220 @@ def _step(variant):
     emit(f"s_add_u32 {s(S_I)}, {s(S_I)}, 1")
 
 
+def mask_first_tile_ops():
+    """seqlen-k mask of the first walked tile (mask.h:44-78; mainloop...:1626): columns >= tail_valid -> -inf."""
+    for kb in range(2):
+        for r in range(16):
+            key = 32 * kb + (r & 3) + 8 * (r >> 2)
+            emit(f"v_add_u32 {v(T[0])}, {key}, {v(HH4)}")
+            emit(f"v_cmp_gt_i32 vcc, {s(S_TAILVALID)}, {v(T[0])}")            # key < tail_valid -> keep
+            for qb in range(NQB):
+                emit(f"v_cndmask_b32 {v(S_(0, kb, qb) + r)}, {v(NEGINF)}, {v(S_(0, kb, qb) + r)}, vcc")
+
+
+def w2_top_fillers(p):
+    """What every step does first, as (slot, item) pairs to be interleaved with the step's first run of instructions: this step's DMA
+    addresses from the tile-address table -> SGPRs, K(i+2) -> K buffer p, V(i+1) -> V buffer 1-p (both buffers were last read in step
+    i-1, behind its barrier), the first V^T fragments of tile i, TABV -> tab[i+2]."""
+    kbuf_stage, vbuf_cur, vbuf_stage = p * KV_TILE, p * KV_TILE, (p ^ 1) * KV_TILE
+    ord2 = [(f % DB) * 4 + (f // DB) for f in range(NVF)]
+    f = [(0, ("LDS", f"ds_read_b64 {vr(T[4], 2)}, {v(TABV)} offset:8", "tabv")),
+         (0, ("LDS", f"ds_read_b64 {vr(T[6], 2)}, {v(TABV)} offset:16", "tabk")),
+         (2, ("WAIT", "tabk")),
+         (2, f"    v_readfirstlane_b32 {s(VBS[0])}, {v(T[4])}"), (2, f"    v_readfirstlane_b32 {s(VBS[0] + 1)}, {v(T[5])}"),
+         (2, f"    v_readfirstlane_b32 {s(TBS[0])}, {v(T[6])}"), (2, f"    v_readfirstlane_b32 {s(TBS[0] + 1)}, {v(T[7])}"),
+         (2, f"    v_add_u32 {v(TABV)}, 16, {v(TABV)}")]
+    for g_, op in zip(range(3, 64), dma_ops(kbuf_stage, vbuf_stage, st=0)):     # >= 5 wait states behind the v_readfirstlane of their bases
+        f.append((g_, op))
+    if "novread" not in OPT:
+        for k in range(len(VF)):
+            for it in v_read(k, vbuf_cur, ord2[k]):
+                f.append((4 + k, it))
+    return f
+
+
+def w2_interleave(main, fillers, per_slot=1):
+    """main: instruction list; fillers: (slot, item) pairs; slot k = behind the (k * per_slot)-th main instruction (slot 0: in front)."""
+    by = {}
+    for slot, it in fillers:
+        by.setdefault(slot, []).append(it)
+    for it in by.pop(0, []):
+        out.append(it)
+    n_slots = max(by) if by else 0
+    if n_slots * per_slot > len(main):              # ablation variants (no softmax): pad with no-ops
+        main = list(main) + ["    s_nop 0"] * (n_slots * per_slot - len(main))
+    for i, op in enumerate(main):
+        out.append(op)
+        if (i + 1) % per_slot == 0:
+            for it in by.pop((i + 1) // per_slot, []):
+                out.append(it)
+    assert not by
+
+
+def w2_qk(fillers=()):
+    ord1 = [(f & 1) * KS + (f >> 1) for f in range(NKF)]
+    w2_interleave([mfma_qk(0, ord1[t // NQB], t % NQB) for t in range(NG)], fillers)
+    emit("s_nop 15")                                 # the MFMA results are readable 18 wait states after the last MFMA issued
+    emit("s_nop 7")
+
+
+def w2_stats(first_tile, can_be_first):
+    """Row max, vote (position S_I, or S_I + 1 for the waves that run one QK ahead: the bit bookkeeping only counts calls), running
+    max, lazy-rescale decision. first_tile: this IS the first walked tile (no test); can_be_first: test S_I == 0 at run time."""
+    first, first_back = new_label("w2first"), new_label("w2first_back")
+    rare, back = new_label("w2rare"), new_label("w2rare_back")
+    fl, flback = new_label("w2flush"), new_label("w2flush_back")
+
+    def mask_block(msk, msk_back):
+        label(msk)
+        emit(f"s_cmp_eq_u32 {s(S_FIRSTLAST)}, 1")             # the first walked tile is tile k_tiles - 1 (C++ shell)
+        emit(f"s_cbranch_scc0 {msk_back}")
+        emit(f"s_cmp_lt_i32 {s(S_TAILVALID)}, 64")
+        emit(f"s_cbranch_scc0 {msk_back}")
+        mask_first_tile_ops()
+        emit(f"s_branch {msk_back}")
+    if first_tile or can_be_first:
+        msk, msk_back = new_label("w2mask"), new_label("w2mask_back")
+        if can_be_first:
+            emit(f"s_cmp_eq_u32 {s(S_I)}, 0")
+            emit(f"s_cbranch_scc1 {msk}")
+        else:
+            emit(f"s_branch {msk}")
+        label(msk_back)
+        deferred.append(lambda msk=msk, msk_back=msk_back: mask_block(msk, msk_back))
+    for op in row_max_ops(0):
+        out.append(op)
+    for qb in range(NQB):
+        emit(f"v_mov_b32 {v(T[qb])}, {v(MLOC[qb])}")
+    emit("s_nop 1")
+    for qb in range(NQB):
+        emit(f"v_permlane32_swap_b32 {v(MLOC[qb])}, {v(T[qb])}")
+    emit("s_nop 0")
+    for qb in range(NQB):
+        emit(f"v_max_f32 {v(MLOC[qb])}, {v(MLOC[qb])}, {v(T[qb])}")
+
+    def first_ops():
+        # first walked tile: m_true = m_ref = its row max; position 0 is never flagged (softmax.h:153)
+        for qb in range(NQB):
+            emit(f"v_mov_b32 {v(MTRUE[qb])}, {v(MLOC[qb])}")
+            emit(f"v_mov_b32 {v(MREF[qb])}, {v(MLOC[qb])}")
+            emit(f"v_mul_f32 {v(NMS[qb])}, {s(S_NEGC)}, {v(MLOC[qb])}")
+            emit(f"v_add_f32 {v(MTHR[qb])}, {s(S_TAU)}, {v(MLOC[qb])}")
+        emit(f"s_or_b32 {s(S_DOMASK)}, {s(S_DOMASK)}, {s(S_BIT)}")
+    if first_tile:
+        first_ops()
+    else:
+        if can_be_first:
+            emit(f"s_cmp_eq_u32 {s(S_I)}, 0")
+            emit(f"s_cbranch_scc1 {first}")
+            deferred.append(lambda: (label(first), first_ops(), emit(f"s_branch {first_back}")))
+        # vote: (m_loc - m_prev) * c > thr   (softmax.h:194), m_prev = the running max BEFORE this tile
+        for qb in range(NQB):
+            emit(f"v_sub_f32 {v(T[2 + qb])}, {v(MLOC[qb])}, {v(MTRUE[qb])}")
+        for qb in range(NQB):
+            emit(f"v_max_f32 {v(MTRUE[qb])}, {v(MTRUE[qb])}, {v(MLOC[qb])}")
+        for qb in range(NQB):
+            emit(f"v_mul_f32 {v(T[2 + qb])}, {s(S_C)}, {v(T[2 + qb])}")
+        assert NQB == 1
+        emit(f"v_cmp_gt_f32 vcc, {v(T[2])}, {s(S_THR)}")
+        emit("s_cmp_lg_u64 vcc, 0")                                  # SCC = some row of the wave voted "do"
+        emit(f"s_cselect_b32 {s(S_T0)}, {s(S_BIT)}, 0")
+        emit(f"s_or_b32 {s(S_DOMASK)}, {s(S_DOMASK)}, {s(S_T0)}")
+        emit(f"v_cmp_gt_f32 vcc, {v(MTRUE[0])}, {v(MTHR[0])}")       # lazy rescale: m_true > m_ref + tau / c on some lane
+        emit(f"s_cbranch_vccnz {rare}")
+        label(back)
+        if can_be_first:
+            label(first_back)
+
+        def rare_block(rare=rare, back=back):
+            # m_ref follows m_true; alpha = exp2((m_ref_old - m_true) c); l and O^T (the tiles before this one) *= alpha, here and now:
+            # this tile's PV comes later in program order, and the PV MFMAs of the previous tile have long drained
+            label(rare)
+            emit("s_nop 15")
+            emit("s_nop 15")
+            for qb in range(NQB):
+                emit(f"v_sub_f32 {v(T[2 + qb])}, {v(MREF[qb])}, {v(MTRUE[qb])}")
+            for qb in range(NQB):
+                emit(f"v_mul_f32 {v(T[2 + qb])}, {s(S_C)}, {v(T[2 + qb])}")
+            for qb in range(NQB):
+                emit(f"v_exp_f32 {v(ALPHA[qb])}, {v(T[2 + qb])}")
+            for qb in range(NQB):
+                emit(f"v_mov_b32 {v(MREF[qb])}, {v(MTRUE[qb])}")
+            for qb in range(NQB):
+                emit(f"v_mul_f32 {v(NMS[qb])}, {s(S_NEGC)}, {v(MREF[qb])}")
+                emit(f"v_add_f32 {v(MTHR[qb])}, {s(S_TAU)}, {v(MREF[qb])}")
+            for qb in range(NQB):
+                emit(f"v_mul_f32 {v(L0[qb])}, {v(L0[qb])}, {v(ALPHA[qb])}")
+                emit(f"v_mul_f32 {v(L1[qb])}, {v(L1[qb])}, {v(ALPHA[qb])}")
+            for qb in range(NQB):
+                for base in range(0, 16 * DB, 8):
+                    for k in range(8):
+                        emit(f"v_accvgpr_read_b32 {v(T[k])}, a{O_(qb, 0) + base + k}")
+                    for k in range(8):
+                        emit(f"v_mul_f32 {v(T[k])}, {v(T[k])}, {v(ALPHA[qb])}")
+                    for k in range(8):
+                        emit(f"v_accvgpr_write_b32 a{O_(qb, 0) + base + k}, {v(T[k])}")
+            emit("s_nop 7")
+            emit(f"s_branch {back}")
+        deferred.append(rare_block)
+    emit(f"s_lshl_b32 {s(S_BIT)}, {s(S_BIT)}, 1")
+    emit(f"s_cbranch_scc0 {fl}")
+    label(flback)
+    deferred.append(lambda: flush_block(fl, flback))
+
+
+def w2_pv(p):
+    """O^T += V(i)^T P^T; beside the MFMAs: the K(i+1) fragments -> AGPRs (the QK of tile i has consumed K(i)'s), the rest of V^T."""
+    kbuf_next, vbuf_cur = (p ^ 1) * KV_TILE, p * KV_TILE
+    ord1 = [(f & 1) * KS + (f >> 1) for f in range(NKF)]
+    ord2 = [(f % DB) * 4 + (f // DB) for f in range(NVF)]
+    NS = len(VF)
+    emit("s_nop 4")                                  # the last pack of P -> its first MFMA read
+    for t in range(NG):
+        f, qb = t // NQB, t % NQB
+        if qb == 0 and "novread" not in OPT:
+            out.append(("WAIT", ("v", ord2[f], 1)))
+        out.append(mfma_pv(0, f % NS, ord2[f], qb) if "nomfma2" not in OPT else "    s_nop 0")
+        if qb == NQB - 1 and f + NS < NVF and "novread" not in OPT:
+            for it in v_read(f % NS, vbuf_cur, ord2[f + NS]):
+                out.append(it)
+        if t < NKF and "nokread" not in OPT:
+            out.append(k_read(kbuf_next, ord1[t]))
+
+
+def w2_tail():
+    emit(("DRAIN",))
+    if "nobarrier" not in OPT:
+        emit("s_barrier")
+    emit(f"s_add_u32 {s(S_I)}, {s(S_I)}, 1")
+
+
+def step_w2(p, group):
+    """W2: one step. p = parity of i = S_I: K(i) came from K buffer p, V(i) is in V buffer p, K(i+1) in K buffer 1-p.
+    Waves 0-3 (group "a") run tile i in program order: QK(i) -> statistics(i) -> softmax(i) -> PV(i). Waves 4-7 (group "b") share their
+    SIMDs with waves 0-3 and the ONE barrier of the workgroup, so in the same rotation both waves of a SIMD would want the matrix pipe,
+    then the vector unit, then the matrix pipe at the same moments; they run the rotation softmax(i) -> PV(i) -> QK(i+1) ->
+    statistics(i+1) instead (QK(0) and its statistics in front of their loop), so that one wave's vector work lies under the other's
+    MFMAs. The LDS buffer protocol is the same for both groups."""
+    if group == "a" or "norot" in OPT:          # norot (A/B): both groups in the same rotation
+        w2_qk(w2_top_fillers(p))
+        w2_stats(first_tile=False, can_be_first=(p == 0))       # i == 0 is even: only this copy of the step can be the first one
+        for op in softmax_stream(0, list(range(16))):
+            out.append(op)
+        w2_pv(p)
+    else:
+        w2_interleave(softmax_stream(0, list(range(16))), w2_top_fillers(p), per_slot=6)
+        w2_pv(p)
+        skip = new_label("w2lastqk")
+        emit(f"s_cmp_eq_u32 {s(S_I)}, {s(S_NM1)}")             # the last tile has no successor
+        emit(f"s_cbranch_scc1 {skip}")
+        emit("s_waitcnt lgkmcnt(0)")                         # the K(i+1) fragments
+        w2_qk()
+        w2_stats(first_tile=False, can_be_first=False)
+        label(skip)
+    w2_tail()
+
+
 def prologue():
     emit("; ---- lane id, parameter block -> SGPRs")
     emit(f"v_mbcnt_lo_u32_b32 {v(LANE)}, -1, 0")
@@ -672,7 +914,7 @@ def prologue():
     emit(f"s_mov_b32 {s(S_CC)}, {s(S_C)}")
     emit(f"s_mov_b32 {s(S_CC + 1)}, {s(S_C)}")
     emit(f"s_sub_u32 {s(S_NM1)}, {s(S_NTILES)}, 1")
-    emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, {ROW_SHIFT + 4}")      # a wave stages 16 rows = 2 / 4 / 8 KiB of a tile
+    emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, {ROW_SHIFT + (3 if W2 else 4)}")      # a wave stages 16 rows = 2 / 4 / 8 KiB of a tile (w2: 8 rows)
     emit(f"s_add_u32 {s(S_DMAW)}, {s(S_DMAW)}, {s(S_LDS)}")
     emit(f"s_mov_b32 {s(S_I)}, 0")
     if DOTSUM:
@@ -710,7 +952,7 @@ def prologue():
     for db in range(2 if DL == 64 else 4):
         emit(f"v_xor_b32 {v(T[7])}, {db}, {v(T[4])}")
         emit(f"v_lshl_add_u32 {v(VADDR[db])}, {v(T[7])}, 6, {v(T[5])}")
-    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 4")
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, {3 if W2 else 4}")
     if DL == 64:
         # DMA image: a 1-KiB piece = 8 rows of 128 bytes; lane -> (rip = lane >> 3, cpos = lane & 7). Row = 16 w + 8 j + rip: the K
         # swizzle XORs the chunk with (row >> 1) & 7 = (4 j + (rip >> 1)) & 7, the V swizzle with ((row >> 1) & 1) << 2 = ((rip >> 1) & 1) << 2
@@ -720,6 +962,10 @@ def prologue():
         emit(f"v_lshrrev_b32 {v(T[8])}, 1, {v(T[6])}")            # rip >> 1
         emit(f"v_xor_b32 {v(RAGK)}, {v(T[7])}, {v(T[8])}")
         emit(f"v_lshlrev_b32 {v(RAGK)}, 4, {v(RAGK)}")            # (cpos ^ (rip >> 1)) << 4
+        if W2:                                                     # rows 8 w + rip: (row >> 1) & 7 has the term 4 (w & 1) as well
+            emit(f"s_and_b32 {s(S_T2)}, {s(S_WAVE)}, 1")
+            emit(f"s_lshl_b32 {s(S_T2)}, {s(S_T2)}, 6")
+            emit(f"v_xor_b32 {v(RAGK)}, {s(S_T2)}, {v(RAGK)}")
         emit(f"v_and_b32 {v(T[8])}, 1, {v(T[8])}")
         emit(f"v_lshlrev_b32 {v(T[8])}, 2, {v(T[8])}")
         emit(f"v_xor_b32 {v(RAGV)}, {v(T[7])}, {v(T[8])}")
@@ -742,7 +988,7 @@ def prologue():
         emit(f"v_xor_b32 {v(RAGV)}, {v(T[1])}, {v(RAGV)}")
         emit(f"v_lshlrev_b32 {v(RAGV)}, 4, {v(RAGV)}")            # (cpos ^ (rip<<2)) << 4
     emit(f"s_mov_b32 {s(S_T1)}, {s(S_LASTROW)}")              # seqlen_k < 64: rows of the only tile stay inside the tensor
-    RSTEP = 16 // PW                                           # rows per piece
+    RSTEP = (64 // NW) // PW                                   # rows per piece
     for j in range(PW):
         # LK[j] = (16w + RSTEP j + rip)*k_rs + (RAGK ^ ((RSTEP j) << 4)) + 3072 - 1024 (j & 3); LV[j] likewise with the V swizzle
         bias = DMA_BIAS - 1024 * (j & 3)
@@ -794,7 +1040,7 @@ def prologue():
         for r in range(4 * KS):
             emit(f"v_cndmask_b32 {v(4 * KS * qb + r)}, 0, {v(4 * KS * qb + r)}, vcc")
     for r in range(4 * KS * NQB):
-        emit(f"v_accvgpr_write_b32 a{128 + r}, {v(r)}")
+        emit(f"v_accvgpr_write_b32 a{Q_A0 + r}, {v(r)}")
     emit("; ---- state")
     for r in range(16 * DB * NQB):
         emit(f"v_accvgpr_write_b32 a{r}, 0")
@@ -804,6 +1050,20 @@ def prologue():
         emit(f"v_mov_b32 {v(L1[qb])}, 0")
         emit(f"v_mov_b32 {v(ALPHA[qb])}, 1.0")
 
+    if W2:
+        # step i reads tab[i + 1].v (V(i+1)) and tab[i + 2].k (K(i+2)): TABV = &tab[1]. K(0) fragments -> AGPRs; once every wave has
+        # them, K buffer 0 is free for K(2), which step 0 stages. The first tile's mask / statistics are step 0's (out-of-line blocks).
+        emit("; ---- w2: K(0) fragments -> AGPRs")
+        emit(f"v_mov_b32 {v(TABV)}, {s(S_TAB)}")
+        emit(f"v_add_u32 {v(TABV)}, 16, {v(TABV)}")
+        for j in range(NKF):
+            emit(k_read(0, j))
+        emit(f"s_mov_b32 {s(S_DOMASK)}, 0")
+        emit(f"s_mov_b32 {s(S_BIT)}, 1")
+        emit(f"s_mov_b32 {s(S_DOWORD)}, {s(S_DOFLAGS)}")
+        emit(("DRAIN",))
+        emit("s_barrier")
+        return
     emit("; ---- tile addresses of positions 1..3 from the table; K(0) fragments -> AGPRs, S(0) = K(0) Q^T, then K(1) fragments")
     emit(f"v_mov_b32 {v(T[6])}, {s(S_TAB)}")
     emit(f"ds_read_b64 {vr(T[8], 2)}, {v(T[6])} offset:32")          # tab[2].k : K(2), staged below
@@ -884,6 +1144,31 @@ def epilogue():
 
 def main():
     prologue()
+    if W2:
+        # two loops: waves 0-3 (group a) and waves 4-7 (group b, one QK ahead: see step_w2); every wave meets the same barriers
+        done = new_label("done")
+        loop_b_entry = new_label("w2groupb")
+        emit(f"s_cmp_ge_u32 {s(S_WAVE)}, 4")
+        emit(f"s_cbranch_scc1 {loop_b_entry}")
+        for group in ("a", "b"):
+            loop = new_label("loop" + group)
+            if group == "b":
+                label(loop_b_entry)
+                if "norot" not in OPT:
+                    w2_qk()                                    # tile 0 (its K fragments are in the AGPRs)
+                    w2_stats(first_tile=True, can_be_first=False)
+            label(loop)
+            for variant in (0, 1):
+                emit(f"s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}")
+                emit(f"s_cbranch_scc0 {done}")
+                step_w2(variant, group)
+            emit(f"s_branch {loop}")
+        for blk in deferred:
+            blk()
+        label(done)
+        epilogue()
+        write_out()
+        return
     loop, done = new_label("loop"), new_label("done")
     if opt_val("align", ""):                                   # code-placement experiments: see DESIGN.md section 4.2
         out.append(f".p2align {opt_val('align', '')}")
@@ -896,6 +1181,7 @@ def main():
         if HALFSKIP:
             # waves 0-1 sit out the steps with i % HALFSKIP == 0, waves 2-3 those with i % HALFSKIP == HALFSKIP / 2: what a workgroup
             # walking the union of two per-128-row lists would do on the tiles only one half lists (DESIGN.md section 8.6 a)
+            assert not W2
             lbl, after = new_label("light"), new_label("after_light")
             emit(f"s_lshr_b32 {s(S_T0)}, {s(S_WAVE)}, 1")
             emit(f"s_mul_i32 {s(S_T0)}, {s(S_T0)}, {HALFSKIP // 2}")
@@ -905,6 +1191,8 @@ def main():
             step(variant)
             label(after)
             deferred.append(lambda lbl=lbl, after=after, variant=variant: (label(lbl), step(variant, light=True), emit(f"s_branch {after}")))
+        elif W2:
+            step_w2(variant)
         else:
             step(variant)
     emit(f"s_branch {loop}")
@@ -912,6 +1200,10 @@ def main():
         blk()
     label(done)
     epilogue()
+    write_out()
+
+
+def write_out():
     lines = finalize(out)
     text = "\n".join(lines)
     path = sys.argv[1] if len(sys.argv) > 1 else "la_fwd_x64_body.inc"

@@ -69,3 +69,23 @@ def test_fp16_body_differs_only_in_the_type_dependent_opcodes(tmp_path):
     la, lb = norm(a).splitlines(), norm(b).splitlines()
     assert len(la) == len(lb)
     assert [x for x, y in zip(la, lb) if x != y and not x.lstrip().startswith(("//", ";"))] == []
+
+
+def test_two_waves_per_simd_body_of_head_dim_64_fits_two_waves(tmp_path):
+    """The A/B body of round 4 (gen_fwd_x64.py LA_X64_OPT=w2, -DLA_D64_W2=1; profiles/r04_head_dim_64.md): an 8-wave workgroup with two
+    waves per SIMD needs <= 256 registers per wave INCLUDING what the C++ shell keeps across the body: the body stays inside v0-v89 +
+    a0-a79 (LA_X64W2_CLOBBERS), has 8 + 8 MFMAs per step and two loops (waves 0-3 / waves 4-7, the latter one QK ahead)."""
+    out = tmp_path / "w2.inc"
+    e = dict(os.environ, LA_X64_D="64", LA_X64_OPT="w2")
+    subprocess.run([sys.executable, os.path.join(CSRC, "gen_fwd_x64.py"), str(out)], check=True, stdout=subprocess.DEVNULL, env=e)
+    text = out.read_text()
+    body = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith((";", "//")))
+    vmax, amax, sgprs = _registers(body)
+    assert 0 <= vmax <= 89 and 0 <= amax <= 79, (vmax, amax)
+    assert min(sgprs) >= 35 and max(sgprs) <= 95
+    # group a: 2 steps x 16; group b: QK of tile 0 (8) + 2 steps x 16
+    assert body.count("v_mfma_f32_32x32x16_bf16") == 2 * 16 + 8 + 2 * 16
+    assert body.count("s_barrier") == 1 + 2 + 2          # prologue + one per step copy, both groups: every wave meets the same barriers
+    shell = open(os.path.join(CSRC, "la_fwd_kernel_x64.hip")).read()
+    clob = shell.split("#define LA_X64W2_CLOBBERS")[1].split("namespace la")[0]
+    assert '"v89"' in clob and '"v90"' not in clob and '"a79"' in clob and '"a80"' not in clob
