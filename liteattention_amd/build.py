@@ -64,7 +64,8 @@ def _compile(lib_path: str, defines, verbose: bool) -> str:
             if head_dim == 64 and any(d.replace(" ", "") == "LA_D64_W2=1" for d in defines):
                 env["LA_X64_OPT"] = os.environ.get("LA_X64_D64_OPT", "w2")       # -DLA_D64_W2=1 (A/B build): the two-waves-per-SIMD body
         subprocess.run([sys.executable, os.path.join(CSRC, X64_GEN), os.path.join(CSRC, inc)], check=True, stdout=quiet, env=env)
-    subprocess.run([sys.executable, os.path.join(CSRC, X64F8_GEN), os.path.join(CSRC, X64F8_INC)], check=True, stdout=quiet)
+    env_f8 = dict(os.environ, LA_X64F8_OPT=os.environ.get("LA_X64F8_DEFAULT_OPT", ""))      # a global LA_X64F8_OPT must not leak into the default body
+    subprocess.run([sys.executable, os.path.join(CSRC, X64F8_GEN), os.path.join(CSRC, X64F8_INC)], check=True, stdout=quiet, env=env_f8)
     for variant, inc in (("exp", X64F8_EXP_INC), ("lvalu", X64F8_LVALU_INC)):       # LA_X64F8_<VARIANT>_OPT tunes that body alone
         f8_opt = ",".join(x for x in (os.environ.get(f"LA_X64F8_{variant.upper()}_OPT", ""), variant) if x)
         subprocess.run([sys.executable, os.path.join(CSRC, X64F8_GEN), os.path.join(CSRC, inc)], check=True, stdout=quiet,

@@ -811,6 +811,12 @@ def main():
     text = "\n".join(lines)
     path = sys.argv[1] if len(sys.argv) > 1 else "la_fwd_x64_fp8_body.inc"
     mode = 2 if not LMFMA else (0 if LIN else 1)               # PMODE of the shell (la_fwd_kernel_x64_fp8.hip)
+    # the three bodies of the build are told apart by their FILE NAME in the shell's includes: a body generated under options that belong to
+    # another name (e.g. a global LA_X64F8_OPT in the environment of a default build) must fail here, not at link time
+    by_name = 1 if path.endswith("_exp_body.inc") else (2 if path.endswith("_lvalu_body.inc") else (0 if path.endswith("la_fwd_x64_fp8_body.inc") else mode))
+    if by_name != mode:
+        raise SystemExit(f"{path}: generated with the options of P mode {mode} (LA_X64F8_OPT={os.environ.get('LA_X64F8_OPT', '')!r}) "
+                         f"but named like the body of P mode {by_name}")
     with open(path.replace("_body.inc", "_consts.h"), "w") as f:
         f.write("// GENERATED by gen_fwd_x64_fp8.py together with the body of the same name — do not edit.\n")
         f.write(f"#define LA_X64F8_TAU_{mode} {TAU!r}f\n#define LA_X64F8_OFFSET_{mode} {P_OFFSET!r}f\n")

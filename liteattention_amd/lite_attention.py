@@ -115,12 +115,33 @@ class LiteAttention:
             if _verbose():
                 print("[Warning]: reinitialized skip list during the forward pass")
         elif query.shape[0] > self._skip_list.shape[1]:
+            # growth replaces the tensor: a HIP graph captured earlier keeps pointers into the OLD lists and would ping-pong on freed
+            # memory. It cannot be allowed inside a capture, and graphs captured before it must be re-captured (or avoid it: preallocate()).
+            if query.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("the skip lists would have to grow (a larger batch than any seen so far) inside a HIP-graph capture: "
+                                   "call preallocate(batch) before capturing")
             grown = self._init_skip_list(query, value, must_skip_list)
             grown[:, : self._skip_list.shape[1]] = self._skip_list
             self._skip_list = grown
         rd = self._phase
         self._phase = 1 - rd
         return self._skip_list[rd], self._skip_list[1 - rd]
+
+    def preallocate(self, query: Tensor, value: Tensor, batch: Optional[int] = None, must_skip_list: list = None):
+        """Size the lists for ``batch`` sequences (default ``max_batch_size``) of this shape NOW, so that no later call has to grow them:
+        what a caller does before capturing calls into a HIP graph (a graph keeps the list pointers of its capture; growth replaces the
+        tensor). The state of sequences already tracked is kept; (re)initialises like any shape change otherwise."""
+        batch = self.max_batch_size if batch is None else batch
+        assert batch <= self.max_batch_size, "batch size must be less than or equal to max_batch_size (modify max_batch_size in LiteAttention constructor)"
+        key = (query.shape[1], value.shape[1], query.shape[2], query.shape[3], query.dtype, query.device,
+               get_tile_sizes(query.shape[3], query.dtype.itemsize))
+        if self._skip_list is None or key != self._shape_key:
+            self._skip_list = self._init_skip_list(query, value, must_skip_list, batch=batch)
+            self._shape_key, self._phase = key, 0
+        elif batch > self._skip_list.shape[1]:
+            grown = self._init_skip_list(query, value, must_skip_list, batch=batch)
+            grown[:, : self._skip_list.shape[1]] = self._skip_list
+            self._skip_list = grown
 
     _MUST_DO_ROWS_MAX = 8          # distinct must_do_list values whose device rows are kept (least recently used go first)
 

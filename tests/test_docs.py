@@ -1,5 +1,5 @@
 """CPU: the measured tables of DESIGN.md are the ones tools/gen_design_tables.py writes from the committed evidence of ONE run
-(profiles/r03_*): prose may interpret the numbers, it may not drift from them."""
+(profiles/r04_*): prose may interpret the numbers, it may not drift from them."""
 import os
 import subprocess
 import sys
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_design_tables_are_generated_from_the_committed_profiles():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_design_tables.py"), "r03", "--check"], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_design_tables.py"), "r04", "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     text = open(os.path.join(ROOT, "DESIGN.md")).read()
     for name in ("headline", "rocprof_bf16", "rocprof_fp8", "traffic", "real_gap", "fp8_forms", "sched_sweep", "denoise50"):

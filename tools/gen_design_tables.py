@@ -2,7 +2,7 @@
 """Rewrites the measured tables of DESIGN.md from the committed evidence of ONE run (profiles/<tag>_*; tools/evidence.sh ->
 tools/summarize_evidence.py): every block between `<!-- GEN:name -->` and `<!-- /GEN:name -->` is regenerated, nothing else is touched.
 
-    python tools/gen_design_tables.py [tag]            rewrite DESIGN.md in place (default tag r03)
+    python tools/gen_design_tables.py [tag]            rewrite DESIGN.md in place (default tag r04)
     python tools/gen_design_tables.py [tag] --check    exit 1 if DESIGN.md is not what the profiles say (tests/test_docs.py)
 
 The prose around the blocks may interpret the numbers; it must not restate them from memory."""
@@ -29,6 +29,9 @@ def blocks(tag):
     rp, rp8 = load(f"{tag}_rocprof_summary.json"), load(f"{tag}_fp8_rocprof_summary.json")
     tr = load(f"{tag}_traffic_vs_sparsity.json")
     ss = load("r03_sched_sweep.json")
+    ss4 = load("r04_sched_sweep.json")
+    if ss and ss4:                                    # round 4 added the gang-scheduled A/B build (another box: compare it with ITS tree row)
+        ss = {"rows": ss["rows"] + [dict(x, variant=x["variant"] + " (r04 session)") for x in ss4["rows"] if x["variant"] in ("gang", "tree")]}
     out = {}
     if b:
         r, pw = b["roofline"], b.get("power") or {}
@@ -50,6 +53,9 @@ def blocks(tag):
             note = f"{p8.get('socket_w', 'n/a')} W at {f((p8.get('sclk_mhz') or 0) / 1000, 2)} GHz; verified {f8.get('verified', {}).get('ok')} (max err {f8.get('verified', {}).get('max_err')})"
             if f8.get("exact_exp"):
                 note += f"; LA_FLAG_EXACT_EXP on the same box: {f(f8['exact_exp']['value'])} TFLOP/s"
+            if f8.get("exact_rowsum"):
+                note += (f"; **LA_FLAG_EXACT_ROWSUM (the reference's arithmetic): {f(f8['exact_rowsum']['value'])} TFLOP/s = {f(f8['exact_rowsum']['frac'], 3)}**, "
+                         f"verified {(f8['exact_rowsum'].get('verified') or {}).get('ok')}")
             rows.append(f"| **fp8 C3 imposed 42 %** (default block-scaled encoding of P) | {f8['ms_per_step']} | **{f(f8['value'])}** | **{f(f8['roofline']['frac'], 3)}** of 5 PF | {note} |")
         for run in (b.get("other_head_dims") or {}).get("runs", []):
             rows.append(f"| bf16 head_dim {run['head_dim']}, dense S = 16 384 H = 40, tiles {run['tiles'][0]} x {run['tiles'][1]} | {run['ms']} | {f(run['tflops'])} | "
@@ -61,15 +67,19 @@ def blocks(tag):
         out["headline"] = rows
         dn = b.get("denoise50")
         if dn and "runs" in dn:
-            rows = [f"Dense kernel on the same tensors: {dn['dense_ms_per_step']} ms per step.", "",
-                    "| target | thr (log2) | last-step sparsity | last step ms | t / t_dense | ideal (1 - s) | 50 steps ms | speed-up vs 50 dense calls | "
-                    "step-49 check (rows, max err / tol, LSE, write rows checked / bad, max ranges per row) | mean / max abs error vs dense output |",
-                    "|---|---|---|---|---|---|---|---|---|---|"]
+            dv0 = dn.get("dense_vs_sweep0") or {}
+            rows = [f"Dense kernel on the same tensors: {dn['dense_ms_per_step']} ms per step ({dn.get('dense_how', 'median of three launches')}; min / max "
+                    f"{dn.get('dense_ms_min_max')}); against the dense point of the imposed-list sweep of the same run ({dv0.get('sweep0_kernel_ms')} ms, random q / k / v): "
+                    f"ratio {dv0.get('ratio')}, within 2 %: {dv0.get('within_2pct')}.", "",
+                    "| target | thr (log2) | last-step sparsity (within 1 % of target) | last step ms | dense ms, this run | t / t_dense | ideal (1 - s) | reference t / t0 at the target | "
+                    "50 steps ms | speed-up vs 50 dense calls | step-49 check (rows, max err / tol, LSE, write rows checked / bad, max ranges per row) | mean / max abs error vs dense output |",
+                    "|---|---|---|---|---|---|---|---|---|---|---|---|"]
             for x in dn["runs"]:
                 v = x.get("verified") or {}
                 chk = (f"ok={v.get('ok')}: {v.get('rows')} rows, {v.get('max_err')} / {v.get('tol')}, {v.get('max_err_lse')}, {v.get('write_rows_checked')} / "
                        f"{v.get('write_rows_bad')}, {v.get('max_ranges_per_row')}") if v else "n/a"
-                rows.append(f"| {x['target']} | {x['thr']} | {100 * x['sparsity_last_step']:.1f} % | {x['ms_last_step']} | {x['t_last_over_dense']} | {x['ideal_1_minus_s']} | "
+                rows.append(f"| {x['target']} | {x['thr']} | {100 * x['sparsity_last_step']:.1f} % ({x.get('within_1pct_of_target')}) | {x['ms_last_step']} | {x.get('dense_ms_this_run')} | "
+                            f"{x['t_last_over_dense']} | {x['ideal_1_minus_s']} | {x.get('reference_t_over_t0_at_target')} | "
                             f"{x['total_ms_50_steps']} | {x['speedup_vs_dense_50_steps']}x | {chk} | {x['mean_abs_err_vs_dense']} / {x['max_abs_err_vs_dense']} |")
             out["denoise50"] = rows
     for name, d in (("rocprof_bf16", rp), ("rocprof_fp8", rp8)):
@@ -125,7 +135,7 @@ def blocks(tag):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    tag = args[0] if args else "r03"
+    tag = args[0] if args else "r04"
     path = os.path.join(ROOT, "DESIGN.md")
     text = open(path).read()
     new = text

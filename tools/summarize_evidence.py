@@ -106,7 +106,7 @@ with open(os.path.join(PROF, f"{tag}_kernel_stats.csv"), "w") as f:
         f.write(f"\"{r['name']}\",{r['calls']},{r['avg_ms']:.4f},{r['min_ms']:.4f},{r['max_ms']:.4f},{r['pct']:.2f}\n")
 
 for dt in ("bf16", "fp8"):
-    kname = "la_fwd_fp8" if dt == "fp8" else "la_fwd_bf16"
+    kname = "la_fwd_x64_fp8" if dt == "fp8" else "la_fwd_x64_kernel"
     # fp8: the bench line also times the LA_FLAG_EXACT_EXP body (template argument 1); the PMC passes and this summary are the default body (0)
     stat_name = "la_fwd_x64_fp8_kernel<true, 0>" if dt == "fp8" else kname
     avg_ms = next((r["avg_ms"] for r in ks if stat_name in r["name"]), None)
@@ -157,7 +157,7 @@ for mode, arg in (("imposed", "0.0"), ("imposed", "0.42"), ("imposed", "0.77"), 
     n = f"traffic_{mode}_{arg}"
     pmc = {}
     for pas in ("fetch", "write", "busy"):
-        c, _, cnt = counters(f"{n}_{pas}", last=3, kernel="la_fwd_bf16")
+        c, _, cnt = counters(f"{n}_{pas}", last=3, kernel="la_fwd_x64_kernel")
         pmc.update(c)
     probe = None
     logf = os.path.join(src, f"{n}_fetch.log")
