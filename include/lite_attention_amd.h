@@ -86,7 +86,8 @@ typedef enum la_status {
                                   *    P cannot overflow, so O is practically never rescaled.
                                   * Measured on the reference-generated fp8 outputs the error of O is 1.0-1.3 x that of the exact form (rms) and well
                                   * inside the reference's own fp8 rule; |LSE - exact| <= 0.084 (rows of one or two comparable keys), about 3e-4 of
-                                  * bias on long rows. +22 % throughput at the headline shape. Implied by LA_FLAG_EXACT_ROWSUM. Ignored for bf16 / fp16. */
+                                  * bias on long rows. +15 ... +22 % throughput at the headline shape over the reference's form, by box and session (the same-session table is
+                                  * generated into DESIGN.md section 3.4; bench.py reports all three forms in one line). Implied by LA_FLAG_EXACT_ROWSUM. Ignored for bf16 / fp16. */
 #define LA_FLAG_STATIC_SCHED 2u  /* keep one workgroup per item (static XCD map) even when a workspace is given. For
                                   * launches that must share the GPU with another kernel while they run — e.g. an RCCL
                                   * collective on another stream: persistent workgroups would hold every CU until the
@@ -103,7 +104,7 @@ typedef enum la_dtype {
 } la_dtype;
 
 /*
- * Forward arguments. Strides are in ELEMENTS (as Flash_fwd_params, flash_api.cpp:84-103).
+ * Forward arguments (dense and QK-Skip launches, fixed-length and packed batches, bf16 / fp16 / fp8: every path of la_fwd). Strides are in ELEMENTS (as Flash_fwd_params, flash_api.cpp:84-103).
  * Tensors: q (B,Sq,H,D)  k (B,Sk,Hk,D)  v (B,Sk,Hk,Dv)  o (B,Sq,H,Dv)  lse (B,H,Sq) fp32 contiguous.
  * GQA / MQA: H % Hk == 0, query head h reads K/V head h / (H/Hk) (flash_api.cpp:777; the reference's
  * non-packed GQA path); fp8 descales are per (batch, K/V head) for q, k AND v (flash_api.cpp:689-691).
