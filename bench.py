@@ -352,11 +352,9 @@ def denoise50(L, dev, thresholds=None, sweep0_ms=None, dense_steps=(5, 15, 25, 3
                      "ms_last_step": round(ms[-1], 3), "dense_ms_this_run": round(dense, 3), "dense_samples_this_run": len(dense_ms),
                      "t_last_over_dense": round(ms[-1] / dense, 3), "ideal_1_minus_s": round(1 - last_sparsity, 3),
                      "reference_t_over_t0_at_target": REFERENCE_T_OVER_T0.get(name),
-                     "mean_sparsity_over_steps": None,
                      "total_ms_50_steps": round(sum(ms), 1), "speedup_vs_dense_50_steps": round(dense * wl.steps / sum(ms), 3),
                      "max_abs_err_vs_dense": float(f"{d.max().item():.3e}"), "mean_abs_err_vs_dense": float(f"{d.mean().item():.3e}"),
                      "mean_abs_dense_output": float(f"{ref.float().abs().mean().item():.3e}"), "verified": verified})
-        runs[-1].pop("mean_sparsity_over_steps")
         del att, out, d, ref
     dense_all = sorted(all_dense)[len(all_dense) // 2]
     res = {"what": "50 synthetic denoising steps, B=1 S=75600 H=40 D=128 bf16, real skip lists at fixed thresholds "

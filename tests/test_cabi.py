@@ -258,3 +258,24 @@ def test_every_exported_symbol_is_declared_bound_and_documented():
     integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for name in exports:
         assert re.search(r"\b" + name + r"\b", integration), f"INTEGRATION.md never mentions {name}"
+
+
+def test_round4_entry_points_validate_without_a_device():
+    """la_blockmask_to_lists / la_device_slots (ABI 6): the argument checks fail before any HIP call (safe without a GPU); the slot query
+    answers from the tile table + the device attribute (256 compute units when there is no device to ask)."""
+    lib = _cabi.load()
+    buf = (ctypes.c_int32 * 16)()
+    m = (ctypes.c_uint8 * 16)()
+    assert lib.la_blockmask_to_lists(None, 0, 0, 1, 1, 1, 1, None, None, buf, None, None) == _cabi.LA_ERR_NULL_ARG
+    assert lib.la_blockmask_to_lists(m, 0, 0, 1, 1, 1, 1, None, None, None, None, None) == _cabi.LA_ERR_NULL_ARG
+    assert lib.la_blockmask_to_lists(m, 0, 0, 0, 1, 1, 1, None, None, buf, None, None) == _cabi.LA_ERR_SHAPE
+    assert lib.la_blockmask_to_lists(m, 0, 0, 1, 1, 1, 0, None, None, buf, None, None) == _cabi.LA_ERR_SHAPE
+    assert lib.la_blockmask_to_lists(m, 0, -4, 1, 1, 1, 1, None, None, buf, None, None) == _cabi.LA_ERR_STRIDE
+    cu, per = ctypes.c_int(0), ctypes.c_int(0)
+    assert lib.la_device_slots(128, 2, 0, ctypes.byref(cu), ctypes.byref(per)) == _cabi.LA_OK and cu.value > 0 and per.value == 1
+    assert lib.la_device_slots(64, 2, 0, ctypes.byref(cu), ctypes.byref(per)) == _cabi.LA_OK and per.value == 1       # the one-wave body is the default at head_dim 64
+    assert lib.la_device_slots(128, 2, _cabi.LA_FLAG_KERNEL_128ROW, ctypes.byref(cu), ctypes.byref(per)) == _cabi.LA_OK and per.value == 2
+    assert lib.la_device_slots(256, 2, _cabi.LA_FLAG_KERNEL_128ROW, ctypes.byref(cu), ctypes.byref(per)) == _cabi.LA_OK and per.value == 1
+    assert lib.la_device_slots(48, 2, 0, ctypes.byref(cu), ctypes.byref(per)) == _cabi.LA_ERR_HEAD_DIM
+    assert lib.la_device_slots(128, 1, _cabi.LA_FLAG_KERNEL_128ROW, None, None) == _cabi.LA_ERR_UNSUPPORTED
+    assert _cabi.device_slots(128, 2)[1] == 1
