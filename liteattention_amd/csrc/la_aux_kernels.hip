@@ -55,13 +55,22 @@ hipError_t launch_skip_list_stats(const int32_t* list, int rows, int k_tiles, in
 
 // One wave per (batch, head, q-tile) row. Position j of the descending walk is tile kt-1-j; a kept run [start .. end] (start >= end)
 // becomes the pair (start, end) of the row, runs in descending order: row = [2 * runs, start0, end0, start1, end1, ..., 0 ...].
-// HBM-bound byte work: kt mask bytes in (three cached loads per lane: the tile and its two neighbours), kt+1 ints out.
+// HBM-bound byte work: kt mask bytes in, kt+1 ints out. A lane's position starts a run when it is kept and position j-1 is not, ends
+// one when position j+1 is not: both neighbours come out of the BALLOT of the chunk (and of the chunks beside it), so every mask byte
+// is loaded once; the loads of 8 chunks (512 positions) are issued together before the first ballot - a row of 1 182 tiles is 3
+// memory latencies, not 19. STAGED (rows of up to ~4 000 tiles): the pairs are scattered into an LDS copy of the row and the row leaves in
+// coalesced 256-byte wave stores, zero padding included; otherwise they go straight to global memory (partial, scattered stores).
+// Round 4 at the Wan2.1 geometry (11 840 rows x 1 183 ints, 56-70 MB): first form 35-44 us, one load per byte 29-32 us, staged: tools/blockmask_bench.py.
+template <bool STAGED>
 __global__ void __launch_bounds__(256) blockmask_to_lists_kernel(const uint8_t* __restrict__ mask, int64_t mask_batch_stride,
                                                                   int64_t mask_head_stride, int batch, int num_heads, int q_tiles,
                                                                   int k_tiles, const int32_t* __restrict__ q_tiles_valid,
                                                                   const int32_t* __restrict__ k_tiles_valid,
                                                                   int32_t* __restrict__ lists, int32_t* __restrict__ empty_rows) {
+    constexpr int G = 8;                         // chunks of 64 positions whose loads are in flight together
+    extern __shared__ int32_t bm_rows[];         // STAGED: 4 waves x (k_tiles + 2) ints
     const int lane = threadIdx.x & 63;
+    int32_t* const stage = bm_rows + (threadIdx.x >> 6) * (k_tiles + 2);
     const int64_t rows = static_cast<int64_t>(batch) * num_heads * q_tiles;
     const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
@@ -75,24 +84,39 @@ __global__ void __launch_bounds__(256) blockmask_to_lists_kernel(const uint8_t* 
         kv = kv < 0 ? 0 : (kv > k_tiles ? k_tiles : kv);
         const bool all = q_tiles_valid != nullptr && m >= q_tiles_valid[b];   // a q-tile past the sequence's end: never read; full corner
         int runs = 0;                                                  // kept runs that START at positions before this chunk
-        for (int j0 = 0; j0 < k_tiles; j0 += 64) {
-            const int j = j0 + lane, t = k_tiles - 1 - j;
-            const bool in = j < k_tiles;
-            const bool keep = in && t < kv && (all || mrow[t] != 0);
-            const bool prev = in && t + 1 < kv && (all || mrow[t + 1] != 0);          // t + 1 < kv <= k_tiles: in bounds
-            const bool next = in && t >= 1 && t - 1 < kv && (all || mrow[t - 1] != 0);
-            const bool is_start = keep && !prev, is_end = keep && !next;
-            const unsigned long long sb = __ballot(is_start);
-            const int ridx = runs + __popcll(sb & ((2ull << lane) - 1ull)) - 1;       // the run this position belongs to
-            if (is_start && 1 + 2 * ridx <= k_tiles) out[1 + 2 * ridx] = t;
-            if (is_end && 2 + 2 * ridx <= k_tiles) out[2 + 2 * ridx] = t;              // a last end behind the row is counted, not stored
-            runs += __popcll(sb);
+        unsigned long long before = 0ull;                              // bit 63: is the position in front of this chunk kept?
+        for (int j0 = 0; j0 < k_tiles; j0 += 64 * G) {
+            unsigned long long kb[G + 1];
+#pragma unroll
+            for (int c = 0; c <= G; ++c) {                             // G chunks + the first position behind them (one more ballot)
+                const int j = j0 + 64 * c + lane, t = k_tiles - 1 - j;
+                const bool keep = j < k_tiles && t < kv && (all || mrow[t] != 0);
+                kb[c] = __ballot(keep);
+            }
+#pragma unroll
+            for (int c = 0; c < G; ++c) {
+                if (j0 + 64 * c >= k_tiles) break;                     // wave-uniform
+                const int t = k_tiles - 1 - (j0 + 64 * c + lane);
+                const bool keep = (kb[c] >> lane) & 1ull;
+                const bool prev = lane == 0 ? (before >> 63) & 1ull : (kb[c] >> (lane - 1)) & 1ull;
+                const bool next = lane == 63 ? kb[c + 1] & 1ull : (kb[c] >> (lane + 1)) & 1ull;
+                const bool is_start = keep && !prev, is_end = keep && !next;
+                const unsigned long long sb = __ballot(is_start);
+                const int ridx = runs + __popcll(sb & ((2ull << lane) - 1ull)) - 1;       // the run this position belongs to
+                int32_t* const dst = STAGED ? stage : out;
+                if (is_start && 1 + 2 * ridx <= k_tiles) dst[1 + 2 * ridx] = t;
+                if (is_end && 2 + 2 * ridx <= k_tiles) dst[2 + 2 * ridx] = t;              // a last end behind the row is counted, not stored
+                runs += __popcll(sb);
+                before = kb[c];
+            }
         }
-        for (int i = 2 * runs + 1 + lane; i <= k_tiles; i += 64) out[i] = 0;
-        if (lane == 0) {
-            out[0] = 2 * runs;
-            if (runs == 0 && empty_rows != nullptr) atomicAdd(empty_rows, 1);
+        if (STAGED) {                                                  // LDS accesses of one wave are ordered: no barrier between the phases
+            for (int i = lane; i <= k_tiles; i += 64) out[i] = i == 0 ? 2 * runs : (i <= 2 * runs ? stage[i] : 0);
+        } else {
+            for (int i = 2 * runs + 1 + lane; i <= k_tiles; i += 64) out[i] = 0;
+            if (lane == 0) out[0] = 2 * runs;
         }
+        if (lane == 0 && runs == 0 && empty_rows != nullptr) atomicAdd(empty_rows, 1);
     }
 }
 
@@ -107,8 +131,13 @@ hipError_t launch_blockmask_to_lists(const uint8_t* mask, int64_t mask_batch_str
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 16384) blocks = 16384;      // >> 256 CUs; rows beyond are taken by the grid-stride loop
     (void)hipGetLastError();
-    hipLaunchKernelGGL(blockmask_to_lists_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, mask, mask_batch_stride,
-                       mask_head_stride, batch, num_heads, q_tiles, k_tiles, q_tiles_valid, k_tiles_valid, lists, empty_rows);
+    const size_t lds = 4 * (static_cast<size_t>(k_tiles) + 2) * sizeof(int32_t);
+    if (lds <= 64 * 1024)
+        hipLaunchKernelGGL(blockmask_to_lists_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), lds, stream, mask, mask_batch_stride,
+                           mask_head_stride, batch, num_heads, q_tiles, k_tiles, q_tiles_valid, k_tiles_valid, lists, empty_rows);
+    else
+        hipLaunchKernelGGL(blockmask_to_lists_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, mask, mask_batch_stride,
+                           mask_head_stride, batch, num_heads, q_tiles, k_tiles, q_tiles_valid, k_tiles_valid, lists, empty_rows);
     return hipGetLastError();
 }
 

@@ -29,7 +29,7 @@ def _rows_ref(mask2d, kv=None):
 
 
 @pytest.mark.parametrize("qt,kt,p", [(5, 1, 0.5), (7, 2, 0.5), (9, 3, 0.6), (33, 63, 0.5), (17, 64, 0.3), (12, 65, 0.7), (40, 130, 0.5),
-                                     (296, 1182, 0.56), (3, 257, 1.0), (4, 200, 0.02)])
+                                     (296, 1182, 0.56), (3, 257, 1.0), (4, 200, 0.02), (2, 4200, 0.5)])     # 4200: past the LDS-staged form
 def test_blockmask_kernel_rows_equal_the_python_rows_bit_for_bit(qt, kt, p):
     g = torch.Generator().manual_seed(qt * 1000 + kt)
     mask = torch.rand(qt, kt, generator=g) < p
