@@ -93,7 +93,8 @@ PW = (64 // NW) * ROW // 1024             # 1-KiB DMA pieces per wave per tile (
 # (+1.4 %), head_dim 192 1111 -> 1107 (24 + 24 KiB there: nothing to balance) - small, because these forms sit at the power limit
 # too (1.8-1.9 GHz). Default: 256 only; `kearly` / `klate2` force it on / off for A/B.
 K_EARLY = NQB == 1 and (D == 256 or "kearly" in OPT) and "klate2" not in OPT
-XPAIRS = int(opt_val("x", "8" if D == 64 else "5"))   # pair-groups (of 16; one group = the same pair of both q-blocks) done in phase 2
+XPAIRS = int(opt_val("x", {64: "4", 256: "6"}.get(D, "5")))   # pair-groups (of 16; one group = the same pair of both q-blocks) done in phase 2 (head_dim 64: 4 since round 4,
+                                                      # +1.8-2.2 % over round 3's 8 on two boxes; 1 / 2 / 3 / 6 / 10 / 12 lose to it; head_dim 256: 6, +1 % over 5; 96 / 192: 5 stays)
 CAP1 = int(opt_val("cap1", "0"))          # fillers per MFMA gap the distributor may place (0 = balance evenly)
 CAP2 = int(opt_val("cap2", "0"))
 DMA_GAPS = [int(x) for x in opt_val("dmagaps", {128: "1,2,4,6,8,10,11,13,15,17", 96: "0,1,3,4,6,7,8,9,11,12", 64: "1,2,4,8,9,11"}[D] if DL <= 128 else
