@@ -250,6 +250,31 @@ def expand_must_do_ref(must_do_list: Sequence[int], k_tile: int, width: int) -> 
     return row
 
 
+def blockmask_rows_ref(mask2d, k_tiles_valid: Optional[int] = None) -> torch.Tensor:
+    """Checker of ``la_blockmask_to_lists``: a 0/1 block mask [q_tiles, k_tiles] -> int32 rows [q_tiles, k_tiles + 1] in the list format the
+    reader walks (row = [L, start0, end0, ...], ranges descending, both ends inclusive: mainloop_fwd_sm90_tma_gmma_ws.hpp:47-115),
+    zero padded; an entry that would lie behind the row is counted in L and not stored (the reader takes a missing end as 0); a row that
+    keeps nothing is [0, 0, ...]. Pure Python, one tile at a time; the inverse is ``walk_tiles``."""
+    qt, kt = int(mask2d.shape[0]), int(mask2d.shape[1])
+    kv = kt if k_tiles_valid is None else max(0, min(int(k_tiles_valid), kt))
+    out = torch.zeros(qt, kt + 1, dtype=torch.int32)
+    for m in range(qt):
+        keep = [bool(mask2d[m, t]) and t < kv for t in range(kt)]
+        row, t = [], kt - 1
+        while t >= 0:
+            if keep[t]:
+                start = t
+                while t - 1 >= 0 and keep[t - 1]:
+                    t -= 1
+                row += [start, t]
+            t -= 1
+        out[m, 0] = len(row)
+        for i, x in enumerate(row):
+            if 1 + i <= kt:
+                out[m, 1 + i] = x
+    return out
+
+
 def walk_tiles(row: Sequence[int]) -> List[int]:
     """Tile indices the reader visits for one list row, in visiting order
     (mainloop...:1804-1827; both range ends inclusive)."""

@@ -14,18 +14,18 @@ DEV = "cuda"
 
 
 def _rows_ref(mask2d, kv=None):
-    """Pure-Python reference (compat.blockmask_to_rows) with the row padded / cut to k_tiles + 1 entries like the kernel's rows."""
-    kt = mask2d.shape[1]
-    m = mask2d.clone().bool()
+    """The oracle's rows (oracle.blockmask_rows_ref: pure Python, one tile at a time), cross-checked against the product's own pure-Python
+    ``compat.blockmask_to_rows`` wherever that one is defined (rows that keep a tile)."""
+    ref = orc.blockmask_rows_ref(mask2d != 0, kv)
+    m = (mask2d != 0).clone()
     if kv is not None:
         m[:, kv:] = False
-    out = torch.zeros(m.shape[0], kt + 1, dtype=torch.int32)
+    kt = m.shape[1]
     for i in range(m.shape[0]):
-        if not bool(m[i].any()):
-            continue                                           # row[0] = 0: counted in empty_rows
-        r = compat.blockmask_to_rows(m[i:i + 1])[0]
-        out[i, : min(len(r), kt + 1)] = torch.tensor(r[: kt + 1], dtype=torch.int32)
-    return out
+        if bool(m[i].any()):
+            r = compat.blockmask_to_rows(m[i:i + 1])[0][: kt + 1]
+            assert ref[i, : len(r)].tolist() == r and r[0] == int(ref[i, 0])
+    return ref
 
 
 @pytest.mark.parametrize("qt,kt,p", [(5, 1, 0.5), (7, 2, 0.5), (9, 3, 0.6), (33, 63, 0.5), (17, 64, 0.3), (12, 65, 0.7), (40, 130, 0.5),

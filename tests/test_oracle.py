@@ -274,3 +274,22 @@ def test_p_roundings_match_torch_casts():
     assert torch.equal(orc.round_like_p(x, True), x.bfloat16().float())
     x8 = x.clamp_max(448.0)
     assert torch.equal(orc.round_like_p(x8, "fp8"), x8.to(torch.float8_e4m3fn).float())
+
+
+def test_blockmask_rows_restatement_round_trips_through_the_reader():
+    """oracle.blockmask_rows_ref (the checker of la_blockmask_to_lists): walking the row it builds with the reader's rules (walk_tiles:
+    descending, both ends inclusive) visits exactly the kept tiles, in descending order; SURVEY A.1's initial row is the all-ones mask."""
+    import torch
+    from oracle import oracle as orc
+    g = torch.Generator().manual_seed(3)
+    for kt in (1, 2, 3, 10, 64, 65, 200):
+        mask = torch.rand(7, kt, generator=g) < 0.5
+        mask[0] = True
+        mask[1] = False
+        rows = orc.blockmask_rows_ref(mask)
+        assert rows[0].tolist()[:3] == ([2, kt - 1, 0] if kt >= 2 else [2, 0]) and int(rows[1, 0]) == 0
+        for m in range(2, 7):
+            kept = [t for t in range(kt - 1, -1, -1) if bool(mask[m, t])]
+            r = rows[m].tolist()
+            full = r[: r[0] + 1] + [0] * max(0, r[0] + 1 - len(r))           # an end behind the row reads as 0
+            assert (not kept and r[0] == 0) or orc.walk_tiles(full) == kept, (kt, m)
