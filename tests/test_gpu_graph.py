@@ -46,3 +46,35 @@ def test_two_steps_per_replay_equal_the_eager_loop(dtype):
     live = torch.arange(n + 1, device="cuda") <= att_e._skip_list[..., 0:1]
     assert bool(((att_g._skip_list[..., : n + 1] == att_e._skip_list[..., : n + 1]) | ~live).all())     # same skip state after 8 steps
     assert att_g.get_skip_fraction() == att_e.get_skip_fraction() > 0.05
+
+
+def test_list_growth_cannot_happen_inside_a_capture_and_preallocate_avoids_it():
+    """the lists grow on demand when a larger batch appears - which replaces the tensor a captured graph points into. Growth
+    inside a capture raises; ``preallocate`` sizes the lists for the largest batch first, and then a graph captured at batch 2 replays
+    bit-identically to eager calls while batch-1 calls in between keep using the same (unmoved) lists."""
+    import liteattention_amd as L
+    S, H, D, thr = 1024, 2, 128, -3.0
+    q1, k1, v1 = [x.cuda() for x in structured_qkv(1, S, H, D, seed=500, alpha=8.0)]
+    q2, k2, v2 = [x.cuda() for x in structured_qkv(2, S, H, D, seed=501, alpha=8.0)]
+    att = L.LiteAttention(threshold=thr, max_batch_size=2)
+    att(q1, k1, v1); att(q1, k1, v1)                       # lists sized for batch 1
+    assert att._skip_list.shape[1] == 1
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="preallocate"):
+        with torch.cuda.graph(g):
+            att(q2, k2, v2)                                # would have to grow inside the capture
+    torch.cuda.synchronize()
+    att = L.LiteAttention(threshold=thr, max_batch_size=2)
+    att.preallocate(q1, v1)                                # max_batch_size sequences, before anything is captured
+    assert att._skip_list.shape[1] == 2
+    ptr = att._skip_list.data_ptr()
+    ref = L.LiteAttention(threshold=thr, max_batch_size=2)
+    e = [ref(q2, k2, v2), ref(q2, k2, v2), ref(q2, k2, v2), ref(q2, k2, v2)]
+    att(q2, k2, v2); att(q2, k2, v2)                       # eager warm-up (must-do row), phases 0 and 1
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        o0 = att(q2, k2, v2)
+        o1 = att(q2, k2, v2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert att._skip_list.data_ptr() == ptr and torch.equal(o0, e[2]) and torch.equal(o1, e[3])
