@@ -97,8 +97,10 @@ for r in rows:
     p = r.get("pmc_pass")
     md.append(f"| {r['instr']} | {r['waves_per_simd']} | {r['operands']} | {r['tflops']} | {r['frac_of_2500']} | {r['socket_w']} | {r['sclk_mhz']} | {r['pj_per_flop_socket']} | "
               + (f"{p['clock_ghz']}, {100 * p['mfma_busy']:.1f} %" if p else "") + " |")
-md += ["", "Reading: with all-zero operands the pipe runs at the nameplate (2.39 GHz, 0.99 of 2.5 PF) at two thirds of the power cap; with N(0,1) bf16 operands the",
-       "SAME instruction stream is throttled to 1.84 GHz = 0.71 of the nameplate. The ceiling of ANY bf16 kernel on random data on this part is therefore ~0.71-0.79,",
+r_rand = next(r for r in rows if r["case"] == "32x32x16_w1_rand")
+r_zero = next(r for r in rows if r["case"] == "32x32x16_w1_zero")
+md += ["", f"Reading: with all-zero operands the pipe runs at the nameplate ({r_zero['sclk_mhz'] / 1000:.2f} GHz, {r_zero['frac_of_2500']:.2f} of 2.5 PF) at two thirds of the power cap; with N(0,1) bf16 operands the",
+       f"SAME instruction stream is throttled to {r_rand['sclk_mhz'] / 1000:.2f} GHz = {r_rand['frac_of_2500']:.2f} of the nameplate. The ceiling of ANY bf16 kernel on random data on this part is therefore ~0.71-0.79,",
        "set by operand toggling, not by the instruction stream; the guide's 2495 TF figure is the zero-toggle case. `16x16x32` costs 8 % less energy per FLOP than",
        "`32x32x16` on random data (half the accumulator traffic per FLOP) and reaches 0.79.", "",
        "## (iii) Ablations and priced levers on the current body", "", res["variants_what"], "",
