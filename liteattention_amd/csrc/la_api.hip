@@ -256,8 +256,8 @@ int la_device_slots(int head_dim, int element_size, uint32_t flags, int* compute
     int bm = 0, bn = 0;
     const int rc = la_get_tile_sizes_ex(head_dim, element_size, flags, &bm, &bn);
     if (rc != LA_OK) return rc;
-    // the hand-scheduled kernels fill a CU with one workgroup (512 registers x 4 waves, 64-130 KiB of LDS) - two at head_dim 64, whose
-    // body is built for two waves per SIMD; the hipcc-scheduled 128-row template runs two per CU at head_dim <= 128 (la_fwd_kernel_v2.hip)
+    // the hand-scheduled kernels fill a CU with ONE workgroup (512 registers x 4 waves, 64-130 KiB of LDS; the two-waves-per-SIMD A/B body
+    // of head_dim 64 is one 8-wave workgroup too); the hipcc-scheduled 128-row template runs two per CU at head_dim <= 128 (la_fwd_kernel_v2.hip)
     const bool v2 = element_size == 2 && (flags & LA_FLAG_KERNEL_128ROW) != 0;
     if (compute_units) *compute_units = la::compute_units();
     if (workgroups_per_cu) *workgroups_per_cu = v2 ? (head_dim <= 128 ? 2 : 1) : (element_size == 2 ? la::x64_workgroups_per_cu(head_dim) : 1);

@@ -81,7 +81,7 @@ inline hipError_t prepare_work_queue(FwdParams& p, bool skipable, int total, int
 size_t fwd_lds_bytes_v2(int head_dim, int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, bool f16, hipStream_t stream);   // 128-row hipcc-scheduled template: head_dim 64; 128 / 256 as the A/B kernels (LA_FLAG_KERNEL_128ROW)
 size_t fwd_lds_bytes_x64(int k_tiles, int* seq_cap_out, int head_dim, int* walk_buffers_out = nullptr);
-int x64_workgroups_per_cu(int head_dim);      // resident workgroups per CU of the hand-scheduled kernel: 2 at head_dim 64 (two waves per SIMD), else 1
+int x64_workgroups_per_cu(int head_dim);      // resident workgroups per CU of the hand-scheduled kernels: 1
 hipError_t launch_fwd_x64(const FwdParams& p, int head_dim, bool skipable, bool f16, hipStream_t stream);  // 1 wave/SIMD; head_dim 128: 64 rows/wave, q-tile 256; 256: 32 rows/wave, q-tile 128
 size_t fwd_lds_bytes_x64_fp8(int k_tiles, int* seq_cap_out, int* walk_buffers_out = nullptr);
 hipError_t launch_fwd_x64_fp8(const FwdParams& p, bool skipable, int p_mode, hipStream_t stream);   // 1 wave/SIMD, 64 rows/wave; p.v = V^T workspace
