@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1: started WITHOUT a launcher (no RANK / WORLD_SIZE in the environment), ``python bench.py --gpus N``
+creates its N ranks itself (`self_launch`: it re-executes this file under torch.distributed.run on 127.0.0.1 with a free port,
+one rank per GPU, relays rank 0's JSON line and exits non-zero if any rank failed).
+
 Workload (BASELINE.json metric: "self-attn TFLOPS + ms/step @ seq=75k d=128 bf16, sparsity 0->77%"):
 one self-attention call of Wan2.1-14B's video shape — B=1, S=75600, H=40, D=128, bf16 — through
 ``LiteAttention.__call__`` with an IMPOSED 42 % sparse read list (SURVEY.md §8d "imposed sparsity":
@@ -149,6 +153,42 @@ def power_sample(launch, n_launches, device_index=0):
             "how": f"rocm-smi, 2 samples while {n_launches} queued launches of the timed configuration run (outside the timed region)"}
 
 
+# ------------------------------------------------------------------------------------------ creating the ranks
+def launched_by_a_launcher(env=None) -> bool:
+    """True when a launcher (torch.distributed.run, the driver's N > 1 command) has already created this process as one rank."""
+    env = os.environ if env is None else env
+    return "RANK" in env and "WORLD_SIZE" in env
+
+
+def self_launch(argv, n_gpus) -> int:
+    """``python bench.py --gpus N`` without a launcher: re-execute this file as N ranks under torch.distributed.run (one process per
+    GPU, rendezvous on 127.0.0.1 at a free port). The children's stdout / stderr are this process's own, so rank 0's ONE JSON line
+    comes out here; the return code is torchrun's (non-zero when any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, LA_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC: RCCL between processes fails without it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, n_gpus))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def load_stand_in():
+    """Test seam (tests/test_bench_main_cpu.py): ``LA_BENCH_STANDIN=<module>`` names a module under tests/ whose ``StandIn`` class
+    replaces the device (cpu), the collective backend (gloo) and the attention op (a torch restatement that honours the read lists),
+    so that THIS file's main() - argument parsing, self-launch, seeding, head partition, agreement, timing, JSON merge, exit codes -
+    runs end to end with more than one rank where there is no GPU. The line it prints says so in `data` and is not a measurement."""
+    name = os.environ.get("LA_BENCH_STANDIN")
+    if not name:
+        return None
+    import importlib
+    return importlib.import_module(name).StandIn()
+
+
 # ------------------------------------------------------------------------------------------ N > 1 control flow
 # Module-level so that a CPU test drives exactly this code with > 2 gloo ranks and a stand-in attention
 # (tests/test_distributed_cpu.py::test_bench_multi_gpu_control_flow_world4): no 8-GPU node is available to the builder.
@@ -283,7 +323,8 @@ def config1_dense(L, dev, S=32768, H=40, D=128, reps=5):
             "verified": {"rows": ver["rows"], "max_err": ver["max_err"], "max_err_lse": ver["max_err_lse"], "ok": ver["ok"]}}
 
 
-def denoise50(L, dev, thresholds=None, sweep0_ms=None, dense_steps=(5, 15, 25, 35, 45, 49), random_qkv=None):
+def denoise50(L, dev, thresholds=None, sweep0_ms=None, dense_steps=(5, 15, 25, 35, 45, 49), random_qkv=None, headline_launch=None,
+              headline_ms=None):
     """BASELINE.json configs[2]. Per threshold: 50 calls of LiteAttention.__call__ on the slowly varying workload; kernel time per
     step by HIP events on the launch stream. Reports the sparsity of the list the LAST step read, its time against the DENSE kernel on
     the same tensors, the 50-step total, and the error the skipping itself introduces at the last step (sparse vs dense kernel
@@ -298,12 +339,16 @@ def denoise50(L, dev, thresholds=None, sweep0_ms=None, dense_steps=(5, 15, 25, 3
     against sweep[0] is the like-with-like check of the launch context, the structured-vs-random ratio is the data effect. Measured
     (profiles/r04_bench_line.json): the data does nothing (ratio 0.999) and the CONTEXT does - inside the loop every launch follows
     ~30 ms of memory-bound tensor generation and a host sync, and the same dense launch runs 1.5-5 % slower there than in the
-    back-to-back sweep, by box. Sparse and dense are both timed in that context, which is what t / t_dense needs."""
+    back-to-back sweep, by box. Sparse and dense are both timed in that context, which is what t / t_dense needs.
+
+    `headline_launch`: the HEADLINE launch itself - the imposed 42 % list on the sweep's random tensors - is timed
+    in the same context, one launch per sampled step, and reported as `headline_in_loop` beside the back-to-back `headline_ms`: the
+    top-level `ms_per_step` is the cool number, this is the same work inside a pipeline-like loop."""
     from liteattention_amd.selfcheck import DENOISE_THRESHOLDS, REFERENCE_T_OVER_T0, DenoiseWorkload, lists_to_bitmap, vote_writer_check
     thresholds = DENOISE_THRESHOLDS if thresholds is None else thresholds
     wl = DenoiseWorkload(40, dev)
     ev = lambda: torch.cuda.Event(enable_timing=True)                                           # noqa: E731
-    all_dense, all_dense_random = [], []
+    all_dense, all_dense_random, all_headline = [], [], []
 
     def dense_samples(q, k, v, n=3):
         ref = L.flash_attn_func(q, k, v)                      # untimed: the first launch after another kernel
@@ -330,6 +375,11 @@ def denoise50(L, dev, thresholds=None, sweep0_ms=None, dense_steps=(5, 15, 25, 3
                 nonlocal ref, dense_ms
                 if random_qkv is not None:
                     all_dense_random.extend(dense_samples(*random_qkv, n=1)[0])
+                if headline_launch is not None:
+                    headline_launch()                              # untimed: the first launch after another kernel
+                    e0, e1 = ev(), ev()
+                    e0.record(); headline_launch(); e1.record(); torch.cuda.synchronize()
+                    all_headline.append(e0.elapsed_time(e1))
                 d_ms, ref = dense_samples(q, k, v)            # at t = 49 `ref` is the dense output the sparse one is compared with
                 dense_ms += d_ms
             if dense_first:
@@ -380,6 +430,12 @@ def denoise50(L, dev, thresholds=None, sweep0_ms=None, dense_steps=(5, 15, 25, 3
            "dense_how": f"median of {len(all_dense)} warmed dense launches interleaved with the sparse runs (steps {list(dense_steps)} of each "
                         "threshold's loop, 1 untimed + 3 timed each)",
            "dense_ms_min_max": [round(min(all_dense), 3), round(max(all_dense), 3)], "runs": runs}
+    if all_headline:
+        hl = sorted(all_headline)[len(all_headline) // 2]
+        res["headline_in_loop"] = {"ms": round(hl, 3), "samples": len(all_headline), "min_max": [round(min(all_headline), 3), round(max(all_headline), 3)],
+                                   "back_to_back_kernel_ms": headline_ms, "ratio": None if not headline_ms else round(hl / headline_ms, 4),
+                                   "what": "the headline launch (imposed 42 % list, the timed loop's random q / k / v) timed inside the 50-step loop: "
+                                           "1 untimed + 1 timed launch at each sampled step, median"}
     if sweep0_ms:
         res["dense_vs_sweep0"] = {"sweep0_kernel_ms": round(sweep0_ms, 3), "ratio": round(dense_all / sweep0_ms, 4),
                                   "note": "sweep[0] = the dense point of the imposed-list sweep (random q, k, v) in this same bench run"}
@@ -416,25 +472,37 @@ def main():
                     help="bf16 = headline (BASELINE.json configs[2,3]); fp8 = configs[4] (e4m3 Q/K/V, bf16 out)")
     args = ap.parse_args()
 
+    # LA_BENCH_FORCE_DIST=1: run the N > 1 code path (process group, trial step, overlapped all-gather, agreement
+    # all-reduce) on ONE rank too - a 1-rank RCCL all-gather is a copy on RCCL's stream. For exercising this file on a 1-GPU box.
+    want_dist = args.gpus > 1 or os.environ.get("LA_BENCH_FORCE_DIST") == "1"
+    if want_dist and not launched_by_a_launcher():
+        sys.exit(self_launch(sys.argv[1:], args.gpus))           # the N ranks are created here; each of them re-enters main()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N "
-                         "for --gpus N > 1 (no line is printed for a world the launcher did not create)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher created WORLD_SIZE={world} rank(s): no line is printed for a "
+                         "world other than --gpus (start it as `python bench.py --gpus N`, or under torch.distributed.run "
+                         "--nproc-per-node N)")
+    seam = load_stand_in()
+    if seam is None:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        backend, device_sync, new_event = "nccl", torch.cuda.synchronize, (lambda: torch.cuda.Event(enable_timing=True))
+    else:
+        dev, backend, device_sync, new_event = torch.device("cpu"), "gloo", (lambda: None), HostEvent
     dist = None
-    # LA_BENCH_FORCE_DIST=1: run the N > 1 code path (process group, trial step, overlapped all-gather, agreement
-    # all-reduce) on ONE rank too — a 1-rank RCCL all-gather is a copy on RCCL's stream. For exercising this file on a 1-GPU box.
     force_dist = os.environ.get("LA_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ
     if world > 1 or force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if seam is None:
+            dist.init_process_group(backend=backend, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     require_world(dist, args.gpus)
 
     import liteattention_amd as L
@@ -444,13 +512,13 @@ def main():
     assert H % world == 0, "heads must divide over ranks"
     Hl = H // world
 
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)         # every rank draws ITS heads: no broadcast, no shared tensor
     qkv_bf16 = [torch.randn(B, S, Hl, D, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16) for _ in range(3)]
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     def run_dtype(dtype_name, steps, warmup, sweep, distributed):
         """Headline measurement (+ optional sparsity sweep, + verification) for one input dtype on this rank's heads."""
@@ -463,8 +531,11 @@ def main():
         att = HeadShardedLiteAttention(num_heads=H, threshold=-10.0, max_batch_size=B,
                                        process_group=None if use_dist is None else dist.group.WORLD,
                                        overlap_windows=args.overlap_windows if use_dist is not None else 1,
-                                       _collective_at_world_1=force_dist)
+                                       _collective_at_world_1=force_dist, **({} if seam is None else seam.attention_kwargs()))
         att.local.threshold = float("-inf")     # imposed lists are a fixed point: identical work every step
+        if seam is not None:
+            seam.bind(att, bm, bn)
+        local_call = (lambda: att.local(q, k, v, return_softmax_lse=True)) if seam is None else (lambda: seam.local_call(q, k, v))
 
         def set_sparsity(s):
             rows = banded_rows(q_tiles, k_tiles, bm, bn, s)
@@ -475,13 +546,13 @@ def main():
             return rows
 
         def timed(n_steps, n_warmup):
-            return timed_steps(att, (q, k, v), n_steps, n_warmup, barrier, use_dist, dev, lambda: torch.cuda.Event(enable_timing=True))
+            return timed_steps(att, (q, k, v), n_steps, n_warmup, barrier, use_dist, dev, new_event)
 
         # ---- headline: 42 % imposed sparsity
         rows = set_sparsity(HEADLINE_SPARSITY)
         overlap_note = None
         if use_dist is not None and att.overlap_windows > 1:
-            overlap_note = agree_on_overlapped_form(att, (q, k, v), dist, dev, torch.cuda.synchronize)
+            overlap_note = agree_on_overlapped_form(att, (q, k, v), dist, dev, device_sync)
         flops_rank = executed_flops(rows, Hl, B, S, S, bm, bn, D)
         step_s, kern_s = timed(steps, warmup)
         flops_job = flops_rank * world
@@ -529,7 +600,7 @@ def main():
             try:
                 rows42 = set_sparsity(HEADLINE_SPARSITY)
                 read_list = att.local._skip_list[att.local._phase].clone()
-                out, lse = att.local(q, k, v, return_softmax_lse=True)
+                out, lse = local_call()
                 heads = sorted({0, Hl // 2, Hl - 1})
                 lse8 = 2e-4 if os.environ.get("LA_FP8_ROWSUM", "").startswith("exact") else 2.5e-3      # fp8 LSE by form of P: tests/test_gpu_headline.py
                 tol = dict(o_rtol=0.05, o_atol=1e-3, lse_atol=lse8) if fp8 else dict(o_rtol=2.0 ** -8, o_atol=1e-4)
@@ -578,10 +649,16 @@ def main():
                 e["reference_t_over_t0"] = ref_curve[s_]
             res["sweep"] = sw
         res["_bm_bn_tiles"] = (bm, bn, q_tiles, k_tiles)
+
+        def headline_again():
+            set_sparsity(HEADLINE_SPARSITY)
+            return lambda: att(q, k, v)
+        res["_headline_again"] = headline_again
         return res
 
     main_res = run_dtype(args.dtype, args.steps, args.warmup, sweep=(world == 1 and not args.no_sweep), distributed=True)
     bm, bn, q_tiles, k_tiles = main_res.pop("_bm_bn_tiles")
+    headline_again = main_res.pop("_headline_again")
 
     result = {
         "metric": "self-attn TFLOPS + ms/step @ seq=75k d=128 bf16, sparsity 0->77%; 1/2/4/8 GPU",
@@ -590,11 +667,14 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": main_res["ms_per_step"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic" if seam is None else "STAND-IN attention on the CPU over gloo (test seam): NOT a measurement",
         "config": {"workload": f"QK-Skip self-attention fwd, B={B} S={S} H={H} D={D} {args.dtype}, imposed "
                                f"{HEADLINE_SPARSITY:.0%} sparsity (banded lists, thr=-inf), tiles {bm}x{bn}",
                    "sparsity": main_res["sparsity"],
                    "parallelism": main_res["parallelism"],
+                   "launcher": ("self-launched: python bench.py --gpus N re-executed itself under torch.distributed.run"
+                                if os.environ.get("LA_BENCH_SELF_LAUNCHED") == "1" else
+                                ("external launcher (torch.distributed.run)" if launched_by_a_launcher() else "single process")),
                    "dense_equiv_tflops": main_res["dense_equiv_tflops"]},
         "roofline": main_res["roofline"],
     }
@@ -608,7 +688,7 @@ def main():
     if world == 1 and args.dtype == "bf16" and not args.no_fp8:
         try:
             f8 = run_dtype("fp8", max(5, args.steps // 2), 2, sweep=False, distributed=False)
-            f8.pop("_bm_bn_tiles")
+            f8.pop("_bm_bn_tiles"); f8.pop("_headline_again")
             result["fp8"] = {"value": f8["value"], "unit": result["unit"], "ms_per_step": f8["ms_per_step"], "dtype": "fp8 (e4m3 in, fp32 accumulate, bf16 out)",
                              "steps": max(5, args.steps // 2), "sparsity": f8["sparsity"], "tiles": f8["tiles"],
                              "roofline": f8["roofline"], "verified": f8.get("verified"), "power": f8.get("power"),
@@ -649,7 +729,11 @@ def main():
     if world == 1 and args.dtype == "bf16" and not args.no_denoise and S == 75600 and H == 40:
         try:
             sw0 = result.get("sweep", [{}])[0].get("kernel_ms")
-            result["denoise50"] = denoise50(L, dev, sweep0_ms=sw0, random_qkv=qkv_bf16 if world == 1 else None)
+            result["denoise50"] = denoise50(L, dev, sweep0_ms=sw0, random_qkv=qkv_bf16 if world == 1 else None,
+                                            headline_launch=headline_again(), headline_ms=main_res["roofline"]["kernel_ms"])
+            hil = result["denoise50"].get("headline_in_loop")
+            if hil:                                    # beside the cool number, at the top level
+                result["ms_per_step_in_denoise_loop"] = hil["ms"]
         except Exception as e:  # noqa: BLE001
             result["denoise50"] = {"error": repr(e)}
 

@@ -48,6 +48,24 @@ def test_bench_multi_gpu_branch_on_a_one_rank_rccl_group(windows):
     assert r["roofline"]["bound"] == "mfma" and 0 < r["roofline"]["frac"] < 1
 
 
+def test_bench_self_launches_its_ranks_when_no_launcher_did():
+    """`python bench.py --gpus N` with NO RANK / WORLD_SIZE in the environment creates the ranks itself
+    (torch.distributed.run on 127.0.0.1). On a 1-GPU box N = 1 with LA_BENCH_FORCE_DIST=1 takes exactly that road: the line comes
+    from a rank the self-launcher made, over a real RCCL process group."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LA_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--seqlen", "8192", "--heads", "8", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-denoise", "--no-head-dims", "--no-fp8", "--no-power"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["config"]["launcher"].startswith("self-launched") and r["data"] == "synthetic"
+    assert r["multi_gpu"]["rccl_world_size"] == 1 and r["multi_gpu"]["backend"] == "nccl" and r["multi_gpu"]["overlapped_form_kept"]
+    assert r["verified"]["ok"] and r["verified"]["ok_all_ranks"] and r["n_gpus"] == 1
+
+
 def test_bench_single_process_line_has_the_contract_fields():
     r = _run_bench(["--no-sweep"], {})
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
