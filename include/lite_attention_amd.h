@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LA_ABI_VERSION 6   /* 6 = 5 + la_blockmask_to_lists, la_device_slots (5 = 4 + skip lists and fp8 with cu_seqlens, LA_FLAG_EXACT_ROWSUM /
+#define LA_ABI_VERSION 7   /* 7 = 6 + la_build_info; 6 = 5 + la_blockmask_to_lists, la_device_slots (5 = 4 + skip lists and fp8 with cu_seqlens, LA_FLAG_EXACT_ROWSUM /
                             * LA_FLAG_EXACT_EXP, LA_DTYPE_FP32 for la_combine); la_fwd_args unchanged since 4 */
 
 typedef enum la_status {
@@ -240,6 +240,14 @@ int la_blockmask_to_lists(const uint8_t* blockmask, int64_t mask_batch_stride, i
  * compute units x workgroups per compute unit. A host that splits one attention into q-tile windows (la_fwd_args.q_tile_begin)
  * sizes them in whole rounds of this number. No counterpart in the reference (one launch per call). */
 int la_device_slots(int head_dim, int element_size, uint32_t flags, int* compute_units, int* workgroups_per_cu);
+
+/* What this binary was built from: "abi=7;src=<sha256[:16] of the kernel / API sources, generators and this header>;variant=0|1;
+ * wrong_results=0|1;opts=<generator options and -D defines, empty for the product build>". The product build (variant=0) is generated
+ * with NO generator option and NO define, whatever the environment of the build held; A/B and pricing builds (python -m
+ * liteattention_amd.build --out=...) say variant=1, and wrong_results=1 when an option that changes the arithmetic went in. The Python
+ * binding refuses a library in the default location whose record says variant / wrong_results or whose src differs from the tree
+ * beside it. No counterpart in the reference (its build flags are only visible in setup.py's environment, hopper/setup.py:47-68). */
+const char* la_build_info(void);
 
 const char* la_status_string(int status);
 int         la_abi_version(void);

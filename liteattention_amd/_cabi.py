@@ -13,7 +13,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # LITEATTENTION_AMD_LIB overrides the in-tree location (deployment / tests of the failure path)
 LIB_PATH = os.environ.get("LITEATTENTION_AMD_LIB") or os.path.join(_PKG_DIR, "libliteattention_amd.so")
 
-LA_ABI_VERSION = 6
+LA_ABI_VERSION = 7
 LA_DTYPE_BF16, LA_DTYPE_FP16, LA_DTYPE_FP8_E4M3, LA_DTYPE_FP32 = 0, 1, 2, 3
 
 LA_OK = 0
@@ -25,7 +25,7 @@ LA_ERR_Q_WINDOW = -13
 
 EXPORTED_SYMBOLS = (
     "la_abi_version", "la_get_tile_sizes", "la_get_tile_sizes_ex", "la_fwd", "la_fwd_workspace_bytes", "la_skip_list_stats", "la_combine",
-    "la_status_string", "la_last_hip_error", "la_blockmask_to_lists", "la_device_slots",
+    "la_status_string", "la_last_hip_error", "la_blockmask_to_lists", "la_device_slots", "la_build_info",
 )
 
 
@@ -139,10 +139,35 @@ def load() -> ctypes.CDLL:
     lib.la_status_string.argtypes = [ctypes.c_int]
     lib.la_status_string.restype = ctypes.c_char_p
     lib.la_last_hip_error.restype = ctypes.c_int
+    lib.la_build_info.restype = ctypes.c_char_p
     if lib.la_abi_version() != LA_ABI_VERSION:
         raise NativeLibraryError(f"ABI version mismatch: library {lib.la_abi_version()} vs binding {LA_ABI_VERSION}")
+    _check_build_record(lib)
     _lib = lib
     return lib
+
+
+def build_info() -> dict:
+    """``la_build_info()`` of the loaded library as a dict: abi, src (hash of the sources it was built from), variant, wrong_results, opts."""
+    from . import _buildinfo
+    return _buildinfo.parse(load().la_build_info().decode())
+
+
+def _check_build_record(lib) -> None:
+    """The library in the DEFAULT location must be the product build of the sources beside it: generated with no generator option and
+    no define (variant=0, wrong_results=0) from exactly this tree (src). A/B and pricing variants - whose results may be wrong on
+    purpose - are only reachable by naming them in LITEATTENTION_AMD_LIB, which skips this check (the caller chose the file)."""
+    if os.environ.get("LITEATTENTION_AMD_LIB"):
+        return
+    from . import _buildinfo
+    rec = _buildinfo.parse(lib.la_build_info().decode())
+    if rec.get("variant") != "0" or rec.get("wrong_results") != "0":
+        raise NativeLibraryError(f"{LIB_PATH} is an A/B or pricing variant ({lib.la_build_info().decode()}), not the product build: "
+                                 "rebuild with `python -m liteattention_amd.build --force`")
+    want = _buildinfo.source_hash()
+    if want is not None and rec.get("src") != want:
+        raise NativeLibraryError(f"{LIB_PATH} was built from other sources (library src={rec.get('src')}, tree src={want}): "
+                                 "rebuild with `python -m liteattention_amd.build`")
 
 
 def status_string(code: int) -> str:

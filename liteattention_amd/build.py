@@ -12,14 +12,20 @@ import shutil
 import subprocess
 import sys
 
+try:
+    from . import _buildinfo
+except ImportError:                       # loaded by path (__graft_entry__.build(), before the package can be imported)
+    import importlib.util as _ilu
+    _spec = _ilu.spec_from_file_location("la_buildinfo", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_buildinfo.py"))
+    _buildinfo = _ilu.module_from_spec(_spec)
+    _spec.loader.exec_module(_buildinfo)
+
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_NAME = "libliteattention_amd.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
-SOURCES = ["la_fwd_kernel_v2.hip", "la_fwd_kernel_x64.hip", "la_prep_fp8.hip", "la_fwd_kernel_x64_fp8.hip", "la_aux_kernels.hip",
-           "la_api.hip"]
-HEADERS = ["la_kernel_params.h", "la_tiles.h", "la_fwd_common.h", "gen_fwd_x64.py", "gen_fwd_x64_fp8.py", "gen_epilogue.py"]
+SOURCES, HEADERS = _buildinfo.SOURCES, _buildinfo.HEADERS
 X64_GEN, X64_INC = "gen_fwd_x64.py", "la_fwd_x64_body.inc"      # the hand-scheduled main loop, included by la_fwd_kernel_x64.hip
 X64_F16_INC = "la_fwd_x64_f16_body.inc"                        # the same generator with LA_X64_DTYPE=f16 (fp16 MFMA / conversions)
 X64_BODIES = [(128, "bf16", X64_INC), (128, "f16", X64_F16_INC)] + [
@@ -27,6 +33,11 @@ X64_BODIES = [(128, "bf16", X64_INC), (128, "f16", X64_F16_INC)] + [
 X64F8_GEN, X64F8_INC = "gen_fwd_x64_fp8.py", "la_fwd_x64_fp8_body.inc"     # fp8: the same structure on the block-scaled MFMA
 X64F8_EXP_INC = "la_fwd_x64_fp8_exp_body.inc"                               # LA_X64F8_OPT=exp: P = v_exp_f32 rounded by the hardware convert (LA_FLAG_EXACT_EXP)
 X64F8_LVALU_INC = "la_fwd_x64_fp8_lvalu_body.inc"                           # LA_X64F8_OPT=lvalu: that, and fp32 row sums on the VALU (LA_FLAG_EXACT_ROWSUM)
+
+
+def body_macro(head_dim: int, dtype: str) -> str:
+    """Name of the shell's include macro for a bf16 / fp16 body (la_fwd_kernel_x64.hip)."""
+    return "LA_X64_" + ("" if head_dim == 128 else f"D{head_dim}_") + ("F16_" if dtype == "f16" else "") + "BODY_INC"
 
 
 def _hipcc() -> str:
@@ -37,7 +48,11 @@ def _hipcc() -> str:
 
 
 def is_stale() -> bool:
+    """The product library is missing, older than a build input, or its own record (la_build_info) names other sources / a variant."""
     if not os.path.exists(LIB_PATH):
+        return True
+    rec = _buildinfo.record_in_file(LIB_PATH)
+    if rec is None or rec["variant"] != "0" or rec["wrong_results"] != "0" or rec["src"] != _buildinfo.source_hash():
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(INCLUDE, "lite_attention_amd.h")]
@@ -46,47 +61,124 @@ def is_stale() -> bool:
 
 def build(force: bool = False, verbose: bool = False, defines=(), out: str = None) -> str:
     """Compile every HIP source for gfx950 into one shared library. Returns its path.
-    ``defines``/``out`` build an A/B variant (e.g. defines=["LA_NO_SETPRIO"], out="/path/lib_b.so") that
-    LITEATTENTION_AMD_LIB can select; the default build has neither."""
+
+    The PRODUCT library (``out`` is None -> liteattention_amd/libliteattention_amd.so) is built from the default bodies with no
+    define, whatever the environment holds: every ``LA_X64*`` generator option variable is removed from the generators' environment
+    and ``defines`` is refused (a stray LA_X64_OPT=nosoftmax at build time used to yield a default library that
+    computes garbage). ``defines`` / generator options only go into an A/B or pricing VARIANT, ``out="/path/lib_b.so"``, whose bodies
+    are generated beside it (``<out>.gen/``, the tree's own bodies stay the default ones), whose ``la_build_info()`` says ``variant=1``
+    (+ ``wrong_results=1`` when an option that changes the arithmetic went in) and which only ``LITEATTENTION_AMD_LIB`` can select."""
     if out is not None:
-        return _compile(out, defines, verbose)
+        return _compile(out, defines, verbose, variant=True)
+    if defines:
+        raise ValueError("the product library takes no -D defines: build a variant with out=... (python -m liteattention_amd.build -D... --out=...)")
     if not force and not is_stale():
         return LIB_PATH
-    return _compile(LIB_PATH, (), verbose)
+    return _compile(LIB_PATH, (), verbose, variant=False)
 
 
-def _compile(lib_path: str, defines, verbose: bool) -> str:
-    quiet = None if verbose else subprocess.DEVNULL
+def _generator_env(variant: bool) -> dict:
+    """Environment of the body generators. Product build: no LA_X64* variable survives (LA_X64_OPT, LA_X64_D<D>_OPT, LA_X64F8_OPT,
+    LA_X64F8_<FORM>_OPT, LA_X64F8_DEFAULT_OPT, LA_X64_D, LA_X64_DTYPE - the last two are set per body below)."""
+    if variant:
+        return dict(os.environ)
+    return {k: v for k, v in os.environ.items() if not k.startswith("LA_X64")}
+
+
+def generate_bodies(gen_dir: str, variant: bool, defines=(), quiet=subprocess.DEVNULL):
+    """Run the body generators into ``gen_dir``. Returns (paths of the generated bodies, -D macros that point the shells at them).
+    Product build (``variant`` False): the generators see no LA_X64* option, whatever this process's environment holds."""
+    base_env = _generator_env(variant)
+    generated, macros = [], []
+
+    def generate(gen, inc, env, macro, consts_macro=None):
+        path = os.path.join(gen_dir, inc)
+        subprocess.run([sys.executable, os.path.join(CSRC, gen), path], check=True, stdout=quiet, env=env)
+        generated.append(path)
+        if variant:
+            macros.append(f'-D{macro}="{path}"')
+            if consts_macro:
+                macros.append(f'-D{consts_macro}="{path.replace("_body.inc", "_consts.h")}"')
+
     for head_dim, dtype, inc in X64_BODIES:       # one generated body per (head dim, 16-bit element type)
-        env = dict(os.environ, LA_X64_D=str(head_dim), LA_X64_DTYPE=dtype)
-        if head_dim != 128:                        # LA_X64_OPT tunes the head_dim-128 body (tools/asm_variants.py); the others have their own knob
+        env = dict(base_env, LA_X64_D=str(head_dim), LA_X64_DTYPE=dtype)
+        if variant and head_dim != 128:            # LA_X64_OPT tunes the head_dim-128 body (tools/asm_variants.py); the others have their own knob
             env["LA_X64_OPT"] = os.environ.get(f"LA_X64_D{head_dim}_OPT", "")
             if head_dim == 64 and any(d.replace(" ", "") == "LA_D64_W2=1" for d in defines):
                 env["LA_X64_OPT"] = os.environ.get("LA_X64_D64_OPT", "w2")       # -DLA_D64_W2=1 (A/B build): the two-waves-per-SIMD body
-        subprocess.run([sys.executable, os.path.join(CSRC, X64_GEN), os.path.join(CSRC, inc)], check=True, stdout=quiet, env=env)
-    env_f8 = dict(os.environ, LA_X64F8_OPT=os.environ.get("LA_X64F8_DEFAULT_OPT", ""))      # a global LA_X64F8_OPT must not leak into the default body
-    subprocess.run([sys.executable, os.path.join(CSRC, X64F8_GEN), os.path.join(CSRC, X64F8_INC)], check=True, stdout=quiet, env=env_f8)
-    for variant, inc in (("exp", X64F8_EXP_INC), ("lvalu", X64F8_LVALU_INC)):       # LA_X64F8_<VARIANT>_OPT tunes that body alone
-        f8_opt = ",".join(x for x in (os.environ.get(f"LA_X64F8_{variant.upper()}_OPT", ""), variant) if x)
-        subprocess.run([sys.executable, os.path.join(CSRC, X64F8_GEN), os.path.join(CSRC, inc)], check=True, stdout=quiet,
-                       env=dict(os.environ, LA_X64F8_OPT=f8_opt))
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-I", INCLUDE, "-I", CSRC]
-    cmd += [f"-D{d}" for d in defines]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+        generate(X64_GEN, inc, env, body_macro(head_dim, dtype))
+    f8_default = os.environ.get("LA_X64F8_DEFAULT_OPT", "") if variant else ""      # a global LA_X64F8_OPT never reaches the default body
+    generate(X64F8_GEN, X64F8_INC, dict(base_env, LA_X64F8_OPT=f8_default), "LA_X64F8_BODY_INC", "LA_X64F8_CONSTS_INC")
+    for form, inc in (("exp", X64F8_EXP_INC), ("lvalu", X64F8_LVALU_INC)):       # LA_X64F8_<FORM>_OPT tunes that body alone (variants only)
+        extra = os.environ.get(f"LA_X64F8_{form.upper()}_OPT", "") if variant else ""
+        generate(X64F8_GEN, inc, dict(base_env, LA_X64F8_OPT=",".join(x for x in (extra, form) if x)),
+                 f"LA_X64F8_{form.upper()}_BODY_INC", f"LA_X64F8_{form.upper()}_CONSTS_INC")
+    return generated, macros
+
+
+def _compile(lib_path: str, defines, verbose: bool, variant: bool = False) -> str:
+    gen_dir = CSRC
+    if variant:                                    # a variant's bodies live beside it; the tree keeps the product bodies
+        gen_dir = os.path.abspath(lib_path) + ".gen"
+        os.makedirs(gen_dir, exist_ok=True)
+    generated, macros = generate_bodies(gen_dir, variant, defines, None if verbose else subprocess.DEVNULL)
+    info = _build_record(generated, defines, variant)
+    # one hipcc -c per source, in parallel (the sources share no device code: every kernel is launched from its own file), then one link
+    common = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, f'-DLA_BUILD_INFO="{info}"']
+    common += [f"-D{d}" for d in defines] + macros
+    obj_dir = os.path.abspath(lib_path) + ".obj"
+    os.makedirs(obj_dir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+        cmd = common + ["-c", os.path.join(CSRC, src), "-o", obj, "-Rpass-analysis=kernel-resource-usage"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        return obj, subprocess.run(cmd, check=False, stderr=subprocess.PIPE, text=True)
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        results = list(ex.map(compile_one, SOURCES))
+    remarks = ""
+    for (obj, res), src in zip(results, SOURCES):
+        if res.returncode != 0:
+            sys.stderr.write(res.stderr)                   # the compiler's diagnostics, not just "non-zero exit status"
+            raise RuntimeError(f"hipcc failed on {src} with exit status {res.returncode} (diagnostics above)")
+        if verbose:
+            sys.stderr.write("".join(ln + "\n" for ln in res.stderr.splitlines() if "remark:" not in ln and ln.strip()))
+        remarks += res.stderr
     tmp = lib_path + ".tmp"
-    cmd += ["-o", tmp, "-Rpass-analysis=kernel-resource-usage"]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    res = subprocess.run(cmd, check=False, stderr=subprocess.PIPE, text=True)
-    if res.returncode != 0:
-        sys.stderr.write(res.stderr)                       # the compiler's diagnostics, not just "non-zero exit status"
-        raise RuntimeError(f"hipcc failed with exit status {res.returncode} (diagnostics above)")
-    if verbose:
-        sys.stderr.write("".join(ln + "\n" for ln in res.stderr.splitlines() if "remark:" not in ln and ln.strip()))
-    _check_no_scratch(res.stderr, defines)
+    link = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for obj, _ in results] + ["-o", tmp],
+                          check=False, stderr=subprocess.PIPE, text=True)
+    if link.returncode != 0:
+        sys.stderr.write(link.stderr)
+        raise RuntimeError(f"hipcc failed to link with exit status {link.returncode} (diagnostics above)")
+    shutil.rmtree(obj_dir, ignore_errors=True)
+    _check_no_scratch(remarks, defines)
     os.replace(tmp, lib_path)
     return lib_path
+
+
+def _build_record(generated, defines, variant: bool) -> str:
+    """The text behind la_build_info(): source hash, variant / wrong_results, and the options that went in - read back from the tag
+    line every generator writes at the top of its body (``// la_body_options: ...; wrong_results=N``), so the record says what the
+    bodies ARE, not what the environment asked for."""
+    opts, wrong = [], False
+    for path in generated:
+        with open(path) as f:
+            tag = [ln for ln in (f.readline(), f.readline()) if ln.startswith("// la_body_options:")]
+        if not tag:
+            raise RuntimeError(f"{path}: no la_body_options tag (generator out of date?)")
+        body_opts = tag[0].split(":", 1)[1].split(";")[0].strip()
+        wrong = wrong or "wrong_results=1" in tag[0]
+        name = os.path.basename(path).replace("la_fwd_x64_", "").replace("_body.inc", "").replace("body.inc", "d128")
+        if body_opts not in ("-", "exp", "lvalu") or not name:
+            opts.append(f"{name}[{body_opts}]")
+    opts += [f"-D{d}" for d in defines]
+    if not variant and (opts or wrong):
+        raise RuntimeError(f"the product build must be option-free, got {opts} (wrong_results={wrong}): generator environment not clean?")
+    text = ",".join(opts).replace(";", ",").replace('"', "'").replace(" ", "")
+    return f"src={_buildinfo.source_hash()};variant={1 if variant else 0};wrong_results={1 if wrong else 0};opts={text}"
 
 
 def _check_no_scratch(remarks: str, defines) -> None:

@@ -234,11 +234,16 @@ def blockmask_to_lists(blockmask: torch.Tensor, k_tiles_valid: Optional[torch.Te
     ``[batch, heads, q_tiles, k_tiles]`` -> lists ``[batch, heads, q_tiles, k_tiles + 1]`` when ``batch`` / ``heads`` are given (the mask is
     broadcast through zero strides, not materialised), else lists shaped like the mask's leading dims. ``k_tiles_valid`` /
     ``q_tiles_valid`` (int ``[batch]``): the sequence of batch b has only that many tiles — k-tiles beyond are dropped, q-tile rows beyond
-    (never read by the kernel) get the whole corner. A mask in host memory goes through the tensor-op form (host bookkeeping, like
-    ``init_skip_list``); it has no ``q_tiles_valid``."""
+    (never read by the kernel) get the whole corner. ``k_tiles_valid`` is PER BATCH on both paths: exactly ``batch`` entries (one packed
+    sequence per batch index, which is what ``cu_seqlens`` describes); anything else raises ``ValueError`` whether the mask lives on the
+    host or on the device. ``validate=True`` costs one blocking read of a 4-byte counter on the device path (callers on a hot path, such
+    as ``flash_blocksparse_attn_qkvpacked_func`` with a mask converted once, pass ``validate=False`` after the first conversion). A mask
+    in host memory goes through the tensor-op form (host bookkeeping, like ``init_skip_list``); it has no ``q_tiles_valid``."""
     if not blockmask.is_cuda:
         if q_tiles_valid is not None:
             raise NotImplementedError("q_tiles_valid: device masks only")
+        if k_tiles_valid is not None and blockmask.dim() >= 3 and torch.as_tensor(k_tiles_valid).numel() != blockmask.shape[0]:
+            raise ValueError("k_tiles_valid / q_tiles_valid must hold one entry per batch")       # the device path's rule (ADVICE r4)
         out = _blockmask_to_lists_host(blockmask, k_tiles_valid, validate)
         if batch is not None and heads is not None and out.dim() < 4:
             out = (out[None, None] if out.dim() == 2 else out[:, None]).expand(batch, heads, -1, -1).contiguous()

@@ -44,6 +44,19 @@ def opt_val(key, default):
     return default
 
 
+# Options that only MOVE instructions (placement, split points, cache policy, code alignment): the body computes the same results bit
+# for bit. Every other option drops work or changes the arithmetic - pricing experiments (tools/asm_variants.py). The first line of a
+# generated body says which kind went in; liteattention_amd/build.py refuses the latter for the product library and records both in
+# la_build_info() for A/B builds (--out=).
+SCHEDULE_ONLY = {"x", "cap1", "cap2", "dmagaps", "dmapol", "align", "pad4", "kearly", "klate", "klate2", "expblock", "norot", "w2", "pk"}
+
+
+def option_tag():
+    wrong = sorted(o for o in OPT if o.split(":")[0] not in SCHEDULE_ONLY)
+    return (f"// la_body_options: {','.join(sorted(OPT)) or '-'}; wrong_results={1 if wrong else 0}"
+            + (f" (PRICING ONLY, results are wrong: {','.join(wrong)})" if wrong else ""))
+
+
 # 16-bit element type of Q / K / V / P / O: "bf16" (default) or "f16" (LA_X64_DTYPE; the build generates one body per type). Only the
 # MFMA opcode and the fp32 -> 16-bit pack differ: the fragment layout, the transpose reads and the schedule are type-agnostic.
 DTYPE = os.environ.get("LA_X64_DTYPE", "bf16")
@@ -353,9 +366,9 @@ def softmax_stream(sset, groups):
 
 
 def row_max_ops(sset):
+    """In-lane max of the 32 scores of each q-block into MLOC[qb] (two max3 chains each), interleaved over q-blocks."""
     if "norowmax" in OPT and W2:
         return []
-    """In-lane max of the 32 scores of each q-block into MLOC[qb] (two max3 chains each), interleaved over q-blocks."""
     per = []
     for qb in range(NQB):
         regs = [S_(sset, 0, qb) + r for r in range(16)] + [S_(sset, 1, qb) + r for r in range(16)]
@@ -1192,9 +1205,7 @@ def main():
             step(variant)
             label(after)
             deferred.append(lambda lbl=lbl, after=after, variant=variant: (label(lbl), step(variant, light=True), emit(f"s_branch {after}")))
-        elif W2:
-            step_w2(variant)
-        else:
+        else:                            # (the W2 body has its own loops and returned above)
             step(variant)
     emit(f"s_branch {loop}")
     for blk in deferred:
@@ -1211,6 +1222,7 @@ def write_out():
     with open(path, "w") as f:
         f.write("// GENERATED by gen_fwd_x64.py — do not edit. Inline-asm body of la_fwd_x64_kernel.\n" if D == 128 else
                 f"// GENERATED by gen_fwd_x64.py (LA_X64_D={D}) — do not edit. Inline-asm body of la_fwd_bf16_x64_kernel<.., {D}>.\n")
+        f.write(option_tag() + "\n")
         f.write('R"ASM(\n' + text + '\n)ASM"\n')
     print(f"wrote {path}: {len(lines)} lines, {text.count('v_mfma')} MFMAs")
 

@@ -43,6 +43,18 @@ def opt_val(key, default):
     return default
 
 
+# Options that only move instructions or select one of the three product bodies (exp / lvalu): same results bit for bit as the body of
+# that name. Everything else is a pricing experiment; the first line of a generated body says which kind went in (see gen_fwd_x64.py).
+SCHEDULE_ONLY = {"x", "dmagaps", "align", "pad4", "smstart", "klate", "pk", "exp", "lvalu"}
+
+
+def option_tag():
+    wrong = sorted(o for o in OPT if o.split(":")[0] not in SCHEDULE_ONLY)
+    return (f"// la_body_options: {','.join(sorted(OPT)) or '-'}; wrong_results={1 if wrong else 0}"
+            + (f" (PRICING ONLY, results are wrong: {','.join(wrong)})" if wrong else ""))
+
+
+
 XPAIRS = int(opt_val("x", "8" if ("exp" not in OPT and "lvalu" not in OPT) else "4"))          # pair-groups (of 16) done in phase 2. EVEN: two pair-groups share one packed-e4m3 destination register
                                           # (lo / hi half by op_sel); an odd split leaves a half-written register across the phase boundary
                                           # (measured x = 2 / 4: 2078-2101 TFLOP/s at 42 %, x = 3 / 5 / 6: 2048-2065)
@@ -822,6 +834,7 @@ def main():
         f.write(f"#define LA_X64F8_TAU_{mode} {TAU!r}f\n#define LA_X64F8_OFFSET_{mode} {P_OFFSET!r}f\n")
     with open(path, "w") as f:
         f.write("// GENERATED by gen_fwd_x64_fp8.py — do not edit. Inline-asm body of la_fwd_x64_fp8_kernel.\n")
+        f.write(option_tag() + "\n")
         f.write('R"ASM(\n' + text + '\n)ASM"\n')
     print(f"wrote {path}: {len(lines)} lines, {text.count('v_mfma')} MFMAs")
 

@@ -29,13 +29,20 @@ constexpr uint32_t kKnownFlags = LA_FLAG_V_PREPARED | LA_FLAG_STATIC_SCHED | LA_
 bool uses_128row(int head_dim, int element_size, uint32_t flags) {      // the flag changes the q-tile (256 -> 128 rows) at head dims 64 and 128
     return element_size == 2 && (head_dim == 128 || head_dim == 64) && (flags & LA_FLAG_KERNEL_128ROW) != 0;
 }
-constexpr uint64_t kSchedWorkspaceBytes = 1024;   // 8 ticket counters of 64 bytes (+ slack)
+constexpr uint64_t kSchedWorkspaceBytes = 1024;   // 16 ticket / steal counters of 64 bytes, all of them zeroed by prepare_work_queue (no slack)
 constexpr float kRescaleTauBf16 = 8.0f;           // lazy-rescale slack of the x64 kernel, log2 units
 }  // namespace
 
 extern "C" {
 
 int la_abi_version(void) { return LA_ABI_VERSION; }
+
+#ifndef LA_BUILD_INFO          // liteattention_amd/build.py passes the record; a hand-run hipcc gets an honest "unknown"
+#define LA_BUILD_INFO "src=unknown;variant=1;wrong_results=0;opts=built outside liteattention_amd/build.py"
+#endif
+#define LA_STR2(x) #x
+#define LA_STR(x) LA_STR2(x)
+const char* la_build_info(void) { return "abi=" LA_STR(LA_ABI_VERSION) ";" LA_BUILD_INFO; }
 
 int la_last_hip_error(void) { return g_last_hip_error; }
 

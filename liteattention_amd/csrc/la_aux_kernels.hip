@@ -110,8 +110,16 @@ __global__ void __launch_bounds__(256) blockmask_to_lists_kernel(const uint8_t* 
                 before = kb[c];
             }
         }
-        if (STAGED) {                                                  // LDS accesses of one wave are ordered: no barrier between the phases
+        if (STAGED) {
+            // the pairs were scattered by some lanes and are copied out by others of the SAME wave: the hardware executes one wave's LDS
+            // accesses in order, but nothing in the source language says so - a wave-scope fence + wave barrier keeps the compiler from
+            // moving the loads above the stores (and, at the end, the next row's stores above these loads); no workgroup barrier is needed
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (int i = lane; i <= k_tiles; i += 64) out[i] = i == 0 ? 2 * runs : (i <= 2 * runs ? stage[i] : 0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         } else {
             for (int i = 2 * runs + 1 + lane; i <= k_tiles; i += 64) out[i] = 0;
             if (lane == 0) out[0] = 2 * runs;

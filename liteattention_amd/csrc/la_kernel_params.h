@@ -71,7 +71,9 @@ inline hipError_t prepare_work_queue(FwdParams& p, bool skipable, int total, int
     *grid = total;
     if (!skipable) p.work_counter = nullptr;        // dense: every item costs the same, the static map is balanced
     if (p.work_counter == nullptr) return hipSuccess;
-    const hipError_t err = hipMemsetAsync(p.work_counter, 0, 16 * 64, stream);       // 8 ticket queues, one 64-byte line each (+ 8 lines the LA_SCHED_GANG A/B build counts finished items in)
+    constexpr size_t kWorkQueueBytes = 16 * 64;     // == kSchedWorkspaceBytes of la_api.hip (what la_fwd_workspace_bytes asks the caller for)
+    static_assert(kWorkQueueBytes == 1024, "la_api.hip promises callers a 1024-byte scheduler workspace: change both together");
+    const hipError_t err = hipMemsetAsync(p.work_counter, 0, kWorkQueueBytes, stream);       // 8 ticket queues, one 64-byte line each (+ 8 lines the LA_SCHED_GANG A/B build counts finished items in)
     if (err != hipSuccess) return err;
     const int slots = wg_per_cu * compute_units();
     *grid = total < slots ? total : slots;

@@ -100,6 +100,16 @@ def get_tile_sizes(head_dim: int, element_size: int) -> Tuple[int, int]:
     return _cabi.get_tile_sizes(kernel_head_dim(head_dim, element_size, flags), element_size, flags)
 
 
+def device_slots(head_dim: int, element_size: int) -> Tuple[int, int]:
+    """(compute units, resident workgroups per compute unit) of the kernel that serves this head_dim / element size - mapped exactly
+    as ``get_tile_sizes`` maps them (a head dim between instantiations runs the next size up; e4m3 above head_dim 128 runs the bf16
+    kernel of that head dim), THEN asked from the library (``la_device_slots`` only knows instantiated kernels: 80 -> LA_ERR_HEAD_DIM)."""
+    if element_size == 1 and head_dim > 128:
+        element_size = 2
+    flags = _cabi.default_flags()
+    return _cabi.device_slots(kernel_head_dim(head_dim, element_size, flags), element_size, flags)
+
+
 def _check_list(t: Optional[torch.Tensor], name: str, q: torch.Tensor) -> Optional[int]:
     """flash_api.cpp:919-963: int32, 4-D, contiguous (same messages)."""
     if t is None:

@@ -103,10 +103,11 @@ class HeadShardedLiteAttention:
         if self._q_tile_rows is not None:              # test seam (CPU stand-in): no kernel, no device
             bm, slots = self._q_tile_rows, self._slots if self._slots is not None else 256
         else:
-            from . import _cabi
-            from .flash_attn_interface import get_tile_sizes
+            from .flash_attn_interface import device_slots, get_tile_sizes
             bm, _ = get_tile_sizes(q.shape[-1], q.element_size())
-            cus, per_cu = _cabi.device_slots(q.shape[-1], q.element_size())   # the library knows the device and the kernel it would run
+            # the library knows the device and the kernel it would run; both calls map the head dim / element size the same way
+            # (80 -> the 96 kernel, e4m3 above 128 -> the bf16 kernel of that head dim: ADVICE r4)
+            cus, per_cu = device_slots(q.shape[-1], q.element_size())
             slots = cus * per_cu
         return plan_q_windows(-(-q.shape[1] // bm), q.shape[0] * q.shape[2], self.overlap_windows, slots)
 
@@ -274,30 +275,42 @@ class RingSeqParallelLiteAttention:
             combine_fn = lambda outs, lses: flash_attn_combine(outs, lses, return_lse=False)   # noqa: E731
         self._combine = combine_fn
 
-    def __call__(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None) -> torch.Tensor:
+    def __call__(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None, *,
+                 q_descale: Optional[torch.Tensor] = None, k_descale: Optional[torch.Tensor] = None,
+                 v_descale: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``q/k/v_descale`` (e4m3 inputs; fp32 ``(batch, nheads_k)`` as ``flash_attn_func`` takes them): the K / V descales belong to
+        the K / V SHARD and travel round the ring with it; q's stays with the local rows."""
         G, r = self.world, self.rank
+        def descales(kd, vd):
+            if q_descale is None and kd is None and vd is None:
+                return {}
+            return dict(q_descale=q_descale, k_descale=kd, v_descale=vd)
         if G == 1:
-            out, _ = self._attention(q, k, v, 0, scale)
+            out, _ = self._attention(q, k, v, 0, scale, **descales(k_descale, v_descale))
             return out
         import torch.distributed as dist
         nxt, prv = (r + 1) % G, (r - 1) % G
         k_cur, v_cur = k.contiguous(), v.contiguous()
+        ds_cur = [None if d is None else d.contiguous() for d in (k_descale, v_descale)]
         outs, lses = [], []
         for step in range(G):
             src = (r - step) % G                       # the rank whose K/V shard is in hand = the skip state to use
             reqs = []
             if step + 1 < G:                           # pass the block on while it is being used (read-only here)
                 k_nxt, v_nxt = torch.empty_like(k_cur), torch.empty_like(v_cur)
-                ops = [dist.P2POp(dist.isend, k_cur, nxt, group=self.group), dist.P2POp(dist.isend, v_cur, nxt, group=self.group),
-                       dist.P2POp(dist.irecv, k_nxt, prv, group=self.group), dist.P2POp(dist.irecv, v_nxt, prv, group=self.group)]
+                ds_nxt = [None if d is None else torch.empty_like(d) for d in ds_cur]
+                sends = [k_cur, v_cur] + [d for d in ds_cur if d is not None]
+                recvs = [k_nxt, v_nxt] + [d for d in ds_nxt if d is not None]
+                ops = [dist.P2POp(dist.isend, t, nxt, group=self.group) for t in sends] + \
+                      [dist.P2POp(dist.irecv, t, prv, group=self.group) for t in recvs]
                 reqs = dist.batch_isend_irecv(ops)
-            out, lse = self._attention(q, k_cur, v_cur, src, scale)
+            out, lse = self._attention(q, k_cur, v_cur, src, scale, **descales(*ds_cur))
             outs.append(out)
             lses.append(lse)
             for req in reqs:
                 req.wait()
             if step + 1 < G:
-                k_cur, v_cur = k_nxt, v_nxt
+                k_cur, v_cur, ds_cur = k_nxt, v_nxt, ds_nxt
         return self._combine(torch.stack(outs), torch.stack(lses))
 
     def reset_skip_state(self):

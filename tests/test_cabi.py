@@ -279,3 +279,20 @@ def test_round4_entry_points_validate_without_a_device():
     assert lib.la_device_slots(48, 2, 0, ctypes.byref(cu), ctypes.byref(per)) == _cabi.LA_ERR_HEAD_DIM
     assert lib.la_device_slots(128, 1, _cabi.LA_FLAG_KERNEL_128ROW, None, None) == _cabi.LA_ERR_UNSUPPORTED
     assert _cabi.device_slots(128, 2)[1] == 1
+
+
+def test_window_planning_maps_the_head_dim_before_asking_the_library():
+    """``HeadShardedLiteAttention.q_windows`` asked ``la_device_slots`` with the RAW head dim / element size, which
+    the library only answers for instantiated kernels (80, 72 -> LA_ERR_HEAD_DIM; e4m3 at 256 -> LA_ERR_HEAD_DIM), so every overlapped
+    call at a zero-padded head dim raised. The host maps exactly as ``get_tile_sizes`` does (80 -> 96, e4m3 above 128 -> bf16 kernel)."""
+    from liteattention_amd import flash_attn_interface as fai
+    lib = _cabi.load()
+    cu, per = ctypes.c_int(), ctypes.c_int()
+    for d, e in ((80, 2), (72, 2), (256, 1)):
+        assert lib.la_device_slots(d, e, 0, ctypes.byref(cu), ctypes.byref(per)) == _cabi.LA_ERR_HEAD_DIM      # the raw question fails
+    try:
+        want96, want256 = _cabi.device_slots(96, 2), _cabi.device_slots(256, 2)
+    except RuntimeError:
+        pytest.skip("la_device_slots needs a device for the compute-unit count")
+    assert fai.device_slots(80, 2) == fai.device_slots(72, 2) == want96
+    assert fai.device_slots(256, 1) == want256 and fai.device_slots(160, 1) == _cabi.device_slots(192, 2)

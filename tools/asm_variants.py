@@ -33,9 +33,10 @@ def build_one(spec):
                    stdout=subprocess.DEVNULL)
     # the other generated include must exist too (default options)
     so = os.path.join(OUT, f"{name}.so")
-    from liteattention_amd.build import SOURCES
+    from liteattention_amd.build import SOURCES, _build_record
+    info = _build_record([inc], (), True)          # la_build_info() of the variant: its options, and wrong_results=1 for pricing bodies
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           f'-D{macro}="{inc}"'] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", so]
+           f'-D{macro}="{inc}"', f'-DLA_BUILD_INFO="{info}"'] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", so]
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     return so
 
