@@ -26,6 +26,7 @@ INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_NAME = "libliteattention_amd.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 SOURCES, HEADERS = _buildinfo.SOURCES, _buildinfo.HEADERS
+X64_M16_GEN = "gen_fwd_x64_m16.py"                              # head_dim 128 on the 16x16x32 MFMA (A/B build -DLA_X64_M16=1)
 X64_GEN, X64_INC = "gen_fwd_x64.py", "la_fwd_x64_body.inc"      # the hand-scheduled main loop, included by la_fwd_kernel_x64.hip
 X64_F16_INC = "la_fwd_x64_f16_body.inc"                        # the same generator with LA_X64_DTYPE=f16 (fp16 MFMA / conversions)
 X64_BODIES = [(128, "bf16", X64_INC), (128, "f16", X64_F16_INC)] + [
@@ -106,7 +107,10 @@ def generate_bodies(gen_dir: str, variant: bool, defines=(), quiet=subprocess.DE
             env["LA_X64_OPT"] = os.environ.get(f"LA_X64_D{head_dim}_OPT", "")
             if head_dim == 64 and any(d.replace(" ", "") == "LA_D64_W2=1" for d in defines):
                 env["LA_X64_OPT"] = os.environ.get("LA_X64_D64_OPT", "w2")       # -DLA_D64_W2=1 (A/B build): the two-waves-per-SIMD body
-        generate(X64_GEN, inc, env, body_macro(head_dim, dtype))
+        gen = X64_GEN
+        if variant and head_dim == 128 and any(d.replace(" ", "") == "LA_X64_M16=1" for d in defines):
+            gen = X64_M16_GEN                       # -DLA_X64_M16=1 (A/B build): head_dim 128 on v_mfma_f32_16x16x32 (LA_X64_OPT tunes it)
+        generate(gen, inc, env, body_macro(head_dim, dtype))
     f8_default = os.environ.get("LA_X64F8_DEFAULT_OPT", "") if variant else ""      # a global LA_X64F8_OPT never reaches the default body
     generate(X64F8_GEN, X64F8_INC, dict(base_env, LA_X64F8_OPT=f8_default), "LA_X64F8_BODY_INC", "LA_X64F8_CONSTS_INC")
     for form, inc in (("exp", X64F8_EXP_INC), ("lvalu", X64F8_LVALU_INC)):       # LA_X64F8_<FORM>_OPT tunes that body alone (variants only)
