@@ -450,7 +450,8 @@ def step(variant):
         post[g_].append(op)
     v0 = int(opt_val("vgap0", "36"))
     for f in range(8):                                         # key step 0's fragments, spread over the back of the phase
-        post[v0 + f * ((NG - v0) // 8)] += v_read(f, vbuf_cur, 0, f)
+        if "novread" not in OPT:
+            post[v0 + f * ((NG - v0) // 8)] += v_read(f, vbuf_cur, 0, f)
     distribute(softmax_stream(cur, list(range(XQ, NQUADS))), post, 0)
     emit_gaps(pre, mf, post)
 
@@ -463,12 +464,12 @@ def step(variant):
     kgaps = int(opt_val("kgaps", "2"))                                           # one K fragment read every `kgaps` gaps
     for t, (kk, db, qb) in enumerate(PV_ORDER):
         f = kk * DB + db
-        if qb == 0:
+        if qb == 0 and "novread" not in OPT:
             pre[t].append(("WAIT", ("v", kk, db, 1)))
         mf.append(mfma_pv(cur, f % 8, kk, db, qb) if "nomfma2" not in OPT else "    s_nop 0")
-        if qb == NQB - 1 and kk == 0:                                            # the slot's four MFMAs have issued: refill it for key step 1
+        if qb == NQB - 1 and kk == 0 and "novread" not in OPT:                   # the slot's four MFMAs have issued: refill it for key step 1
             post[t] += v_read(f % 8, vbuf_cur, 1, db)
-        if t % kgaps == 0 and t // kgaps < len(kq):
+        if t % kgaps == 0 and t // kgaps < len(kq) and "nokread" not in OPT:
             post[t].append(k_read(kbuf_read, *kq[t // kgaps]))
     rare, back = new_label("rare"), new_label("rare_back")
     fl, flback = new_label("flush"), new_label("flush_back")
@@ -476,7 +477,7 @@ def step(variant):
     st2 = variant ^ 1
     head = [("LDS", f"ds_read_b64 {vr(T[4], 2)}, {v(TABV)} offset:8", "tabv"),
             ("LDS", f"ds_read_b64 {vr(T[6], 2)}, {v(TABV)} offset:32", "tabk")]
-    rm = row_max_ops(nxt)
+    rm = row_max_ops(nxt) if "norowmax" not in OPT else []
     nb = [f"    v_readfirstlane_b32 {s(VBS[st2])}, {v(T[4])}", f"    v_readfirstlane_b32 {s(VBS[st2] + 1)}, {v(T[5])}",
           f"    v_readfirstlane_b32 {s(TBS[st2])}, {v(T[6])}", f"    v_readfirstlane_b32 {s(TBS[st2] + 1)}, {v(T[7])}"]
     vq = rm[:8] + [("WAIT", "tabk")]
@@ -486,10 +487,11 @@ def step(variant):
         rm = rm[3:]
         if nb:
             vq.append(nb.pop(0))
-    vq += stats_ops(rare, back, fl, flback, inv, invback)
-    deferred.append(lambda: inval_block(inv, invback))
-    deferred.append(lambda: rare_rescale_block(rare, back))
-    deferred.append(lambda: flush_block(fl, flback))
+    if "nostats" not in OPT:
+        vq += stats_ops(rare, back, fl, flback, inv, invback)
+        deferred.append(lambda: inval_block(inv, invback))
+        deferred.append(lambda: rare_rescale_block(rare, back))
+        deferred.append(lambda: flush_block(fl, flback))
     vq += softmax_stream(nxt, list(range(XQ)))
     # the first SAFE_GAPS gaps hold nothing that reads S_nxt (MFMA result -> VALU read hazard: the last QK MFMA has 8 passes)
     distribute(head, post, 0, 4, end=SAFE_GAPS)

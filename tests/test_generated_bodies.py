@@ -89,3 +89,25 @@ def test_two_waves_per_simd_body_of_head_dim_64_fits_two_waves(tmp_path):
     shell = open(os.path.join(CSRC, "la_fwd_kernel_x64.hip")).read()
     clob = shell.split("#define LA_X64W2_CLOBBERS")[1].split("namespace la")[0]
     assert '"v89"' in clob and '"v90"' not in clob and '"a79"' in clob and '"a80"' not in clob
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_m16_body_stays_inside_the_declared_clobbers_and_has_the_16x16x32_counts(tmp_path, dtype):
+    """The head_dim-128 body on v_mfma_f32_16x16x32 (gen_fwd_x64_m16.py, round 5; A/B build -DLA_X64_M16=1): same shell, same clobber
+    set; 64 + 64 MFMAs per step (prologue QK + two unrolled steps = 5 phases of 64), no 32x32x16 MFMA, 64-bit VGPR tuples even-aligned."""
+    out = tmp_path / "m16.inc"
+    e = dict(os.environ, LA_X64_DTYPE=dtype)
+    e.pop("LA_X64_OPT", None)
+    subprocess.run([sys.executable, os.path.join(CSRC, "gen_fwd_x64_m16.py"), str(out)], check=True, stdout=subprocess.DEVNULL, env=e)
+    text = out.read_text()
+    assert "la_body_options: m16; wrong_results=0" in text.splitlines()[1]
+    body = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith((";", "//")))
+    vmax, amax, sgprs = _registers(body)
+    assert 0 <= vmax <= 222 and amax <= 255 and min(sgprs) >= 35 and max(sgprs) <= 95
+    assert max(int(hi) for _, hi in re.findall(r"\ba\[(\d+):(\d+)\]", body)) == 255 and max(int(hi) for _, hi in re.findall(r"\bv\[(\d+):(\d+)\]", body)) <= 222
+    assert body.count(f"v_mfma_f32_16x16x32_{dtype}") == 5 * 64 and "32x32x16" not in body
+    assert body.count("v_permlane16_swap_b32") >= 2 * 2 + 1                     # the transposing row reduction, twice per unrolled loop + prologue
+    for lo in re.findall(r"\bv\[(\d+):(\d+)\]", body):
+        assert int(lo[0]) % 2 == 0, lo                                             # gfx950: VGPR tuples must be 64-bit aligned
+    for lab in re.findall(r"^\s*([.\w%=]+):\s*$", body, flags=re.M):
+        assert lab.endswith("%="), lab
