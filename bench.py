@@ -122,7 +122,7 @@ def cpu_baseline(S, D, bm, bn, rows, target_seconds=15.0):
 
 def power_sample(launch, n_launches, device_index=0):
     """Socket power and shader clock (rocm-smi) read WHILE `n_launches` queued calls of `launch` keep the GPU busy; outside any timed
-    region. The kernels of this path hold the package at its power cap with the clock throttled: this puts
+    region. The kernels of this path hold the package at its power cap with the clock throttled (HISTORY.md section 4.2): this puts
     the two numbers that say so next to the roofline fraction. Returns None if rocm-smi is not there."""
     import json as _json
     import shutil

@@ -87,7 +87,7 @@ typedef enum la_status {
                                   * Measured on the reference-generated fp8 outputs the error of O is 1.0-1.3 x that of the exact form (rms) and well
                                   * inside the reference's own fp8 rule; |LSE - exact| <= 0.084 (rows of one or two comparable keys), about 3e-4 of
                                   * bias on long rows. +15 ... +22 % throughput at the headline shape over the reference's form, by box and session (the same-session table is
-                                  * generated into DESIGN.md section 3.4; bench.py reports all three forms in one line). Implied by LA_FLAG_EXACT_ROWSUM. Ignored for bf16 / fp16. */
+                                  * generated into HISTORY.md section 3.4; bench.py reports all three forms in one line). Implied by LA_FLAG_EXACT_ROWSUM. Ignored for bf16 / fp16. */
 #define LA_FLAG_STATIC_SCHED 2u  /* keep one workgroup per item (static XCD map) even when a workspace is given. For
                                   * launches that must share the GPU with another kernel while they run — e.g. an RCCL
                                   * collective on another stream: persistent workgroups would hold every CU until the

@@ -78,6 +78,26 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str = Non
     return _compile(LIB_PATH, (), verbose, variant=False)
 
 
+M16_VARIANT = os.path.join(os.path.dirname(PKG_DIR), "build_variants", "m16.so")      # the head_dim-128 bodies on v_mfma_f32_16x16x32 (A/B build)
+
+
+def build_m16_variant(force: bool = False, verbose: bool = False) -> str:
+    """The 16x16x32-MFMA body of head_dim 128 as an A/B library beside the product one (``build_variants/m16.so``: git-ignored, travels
+    to the GPU box like every built .so). ``__graft_entry__.build()`` builds it so that the round-end GPU tests can run the parity suite
+    on it (tests/test_gpu_m16.py, in a subprocess with LITEATTENTION_AMD_LIB). Never the product: its record says variant=1."""
+    rec = _buildinfo.record_in_file(M16_VARIANT) if os.path.exists(M16_VARIANT) else None
+    fresh = rec is not None and rec["src"] == _buildinfo.source_hash() and rec["variant"] == "1" and "m16" in rec["opts"] and rec["wrong_results"] == "0"
+    if fresh and not force:
+        return M16_VARIANT
+    os.makedirs(os.path.dirname(M16_VARIANT), exist_ok=True)
+    env_opt = os.environ.pop("LA_X64_OPT", None)              # the variant of record is the default schedule of the m16 generator
+    try:
+        return _compile(M16_VARIANT, ["LA_X64_M16=1"], verbose, variant=True)
+    finally:
+        if env_opt is not None:
+            os.environ["LA_X64_OPT"] = env_opt
+
+
 def _generator_env(variant: bool) -> dict:
     """Environment of the body generators. Product build: no LA_X64* variable survives (LA_X64_OPT, LA_X64_D<D>_OPT, LA_X64F8_OPT,
     LA_X64F8_<FORM>_OPT, LA_X64F8_DEFAULT_OPT, LA_X64_D, LA_X64_DTYPE - the last two are set per body below)."""

@@ -4,7 +4,7 @@ ONE wave per SIMD (one 4-wave workgroup per CU). The text below describes the he
 256 x k-tile 64. LA_X64_D selects the other forms (96: the same with 12 of 16 fragments; 256 / 192: one 32-row q-block per wave,
 q-tile 128 - see the comments at D / DL / NQB below), LA_X64_DTYPE the 16-bit element type.
 
-Why this shape (measured): with two 32-row waves per SIMD the MFMA pipe idles 37 % of the
+Why this shape (measured, HISTORY.md section 4.6): with two 32-row waves per SIMD the MFMA pipe idles 37 % of the
 cycles and the chip clocks at 1.69 GHz, because every wave re-reads the whole K/V tile from LDS for only 32 rows and
 the two unsynchronised waves fight for issue slots. One wave with the whole 512-register file halves the LDS bytes
 per FLOP, and its single in-order stream is scheduled here gap by gap.
@@ -527,7 +527,7 @@ def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True, st=0):
         if do_v:
             o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {V_REGION + vbuf_imm + 4096 * grp}")
             o += [f"    global_load_lds_dwordx4 {v(LV[4 * grp + j])}, {sr(VBS[st])} offset:{1024 * j}{DMA_POLICY}" for j in range(per)]
-    if "dma2x" in OPT:                     # pricing only (two 128-row workgroups per CU): every piece staged twice
+    if "dma2x" in OPT:                     # pricing only (HISTORY.md section 8, two 128-row workgroups per CU): every piece staged twice
         o = [x + "\n" + x if "global_load_lds" in x else x for x in o]
     return o
 
@@ -1184,7 +1184,7 @@ def main():
         write_out()
         return
     loop, done = new_label("loop"), new_label("done")
-    if opt_val("align", ""):                                   # code-placement experiments: see DESIGN.md section 4.2
+    if opt_val("align", ""):                                   # code-placement experiments: see HISTORY.md section 4.2
         out.append(f".p2align {opt_val('align', '')}")
     for _ in range(int(opt_val("pad4", "0"))):
         emit("s_nop 0")
@@ -1194,7 +1194,7 @@ def main():
         emit(f"s_cbranch_scc0 {done}")
         if HALFSKIP:
             # waves 0-1 sit out the steps with i % HALFSKIP == 0, waves 2-3 those with i % HALFSKIP == HALFSKIP / 2: what a workgroup
-            # walking the union of two per-128-row lists would do on the tiles only one half lists (DESIGN.md section 8.6 a)
+            # walking the union of two per-128-row lists would do on the tiles only one half lists (HISTORY.md section 8.6 a)
             assert not W2
             lbl, after = new_label("light"), new_label("after_light")
             emit(f"s_lshr_b32 {s(S_T0)}, {s(S_WAVE)}, 1")

@@ -68,7 +68,7 @@ NG = 8                                    # QK MFMAs (gaps) of phase 1
 # every ~4.8 cycles: tools/valu_microbench.py), the packed / dot2 forms that would halve the adds are VOP3P and serialise with
 # the MFMA in flight (same tool), and the matrix pipe idles 55 % of the step. O = (sum P~ V) / (sum P~) is also the better
 # numerics under the lazy rescale: the weights sum to 1 exactly, so the e4m3 rounding of a row's dominant P (which is not 2^k
-# once m_ref lags m_true) cancels instead of scaling the whole row by up to 2^-4. The LSE inherits the rounding of P~.
+# once m_ref lags m_true) cancels instead of scaling the whole row by up to 2^-4. The LSE inherits the rounding of P~ (HISTORY.md 3.4).
 LMFMA = "lvalu" not in OPT
 # P itself. "exp" (rounds 1-2; LA_FLAG_EXACT_EXP): P = v_exp_f32(S c - m_ref c + OFF), rounded to e4m3 by v_cvt_pk_fp8_f32 - per score one
 # FMA, one transcendental (2 issue slots) and half a convert (which also costs 2 slots: tools/valu_microbench.py) = 4 slots.
@@ -78,7 +78,7 @@ LMFMA = "lvalu" not in OPT
 # linear-mantissa exponential (1 + f for 2^f, at most +6.1 %, cancelled on average by delta = 0.0575 = log2 of its mean ratio), and
 # the byte grid is then a LOG-uniform quantisation of P (step 2^(1/8)) instead of e4m3's round-to-nearest (relative step 1/8 ..
 # 1/16). Per element the error is within [-7.9 %, +6.5 %] against +-6.25 % for the hardware rounding; measured on the reference's
-# fp8 goldens the output error is 1.0-2.2 x that of the exact form and stays under the reference's own rule.
+# fp8 goldens the output error is 1.0-2.2 x that of the exact form and stays under the reference's own rule (HISTORY.md 3.4).
 # What it costs in range: bytes 1..7 (e4m3 subnormals) are reached for y in (-7, -6] only, so P below 2^-7 is dropped where the
 # hardware rounding keeps P down to 2^-10. Needs the row sums of the ENCODED P (LMFMA): no fp32 P exists in this form.
 LIN = LMFMA and "exp" not in OPT
@@ -96,7 +96,7 @@ NG2 = 10 if LMFMA else 8                  # MFMAs (gaps) of phase 2: PV + the tw
 # the skip vote needs anyway, P is encoded relative to 2^t (the tile's largest P lands in bytes 112..120 = [2^7, 2^8)) and the MFMA
 # multiplies by 2^t. What it buys: (1) the byte grid's 15 octaves hang below the TILE's maximum, not the row's - a diffuse tail far
 # below the row maximum keeps full relative precision (the plain byte grid drops keys below 2^-14.7 of the reference maximum, the
-# reference's e4m3 rounding below 2^-17; at S = 75 600 such tails carry real mass: DESIGN.md 3.4); (2) P cannot overflow whatever
+# reference's e4m3 rounding below 2^-17; at S = 75 600 such tails carry real mass: HISTORY.md 3.4); (2) P cannot overflow whatever
 # the row maximum does, so the lazy rescale only guards the fp32 accumulators: TAU = 32, i.e. never on real data. Cost: 8 vector
 # instructions per step (exponent, scale byte and encoding offset for both q-blocks).
 MX = LIN and "nomx" not in OPT
@@ -803,7 +803,7 @@ def epilogue():
 def main():
     prologue()
     loop, done = new_label("loop"), new_label("done")
-    if opt_val("align", ""):                                   # code-placement experiments: see DESIGN.md section 4.2
+    if opt_val("align", ""):                                   # code-placement experiments: see HISTORY.md section 4.2
         out.append(f".p2align {opt_val('align', '')}")
     for _ in range(int(opt_val("pad4", "0"))):
         emit("s_nop 0")

@@ -30,7 +30,7 @@ bool uses_128row(int head_dim, int element_size, uint32_t flags) {      // the f
     return element_size == 2 && (head_dim == 128 || head_dim == 64) && (flags & LA_FLAG_KERNEL_128ROW) != 0;
 }
 constexpr uint64_t kSchedWorkspaceBytes = 1024;   // 16 ticket / steal counters of 64 bytes, all of them zeroed by prepare_work_queue (no slack)
-constexpr float kRescaleTauBf16 = 8.0f;           // lazy-rescale slack of the x64 kernel, log2 units
+constexpr float kRescaleTauBf16 = 8.0f;           // lazy-rescale slack of the x64 kernel, log2 units (HISTORY.md section 3.1)
 }  // namespace
 
 extern "C" {

@@ -50,7 +50,7 @@ namespace {
 constexpr int BN = 64;                           // keys per tile
 
 // LDS swizzles (in 16-byte chunks of a row of 2*D bytes), chosen per head_dim so that the fragment reads are
-// bank-conflict free:
+// bank-conflict free (HISTORY.md section 3):
 //   K, read with ds_read_b128 by 16-lane groups of distinct rows:  D=128: chunk ^ (row & 15)   (16 chunks/row)
 //                                                                  D=64 : chunk ^ ((row>>1) & 7) (8 chunks/row,
 //                                                                         two rows per 256-byte bank row)

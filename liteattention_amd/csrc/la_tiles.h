@@ -5,7 +5,7 @@
 // hand-copied Python twin (/root/reference/hopper/lite_attention.py:87-111). The reference keeps two
 // copies that must agree; here Python asks the library.
 //
-// CDNA4 derivation. kBlockN = 64 keys: K 16 KiB + V 16 KiB per stage, double-buffered = 64 KiB
+// CDNA4 derivation (HISTORY.md §3, §4.6). kBlockN = 64 keys: K 16 KiB + V 16 KiB per stage, double-buffered = 64 KiB
 // of LDS. bf16 head_dim 128 (the headline path): ONE wave per SIMD owning the whole 512-entry register file and 64
 // query rows (two 32x32 MFMA column blocks), a workgroup is 4 waves -> kBlockM = 256; 256 x 64 = 16 Ki scores per
 // skip decision (reference Hopper tile: 128 x 176 = 22 Ki). fp8 head_dim 128 uses the same structure (kBlockM = 256). bf16

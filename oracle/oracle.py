@@ -55,6 +55,7 @@ class _Args(ctypes.Structure):
         ("tiles_done", ctypes.c_void_p),
         ("q_descale", ctypes.c_void_p), ("k_descale", ctypes.c_void_p), ("v_descale", ctypes.c_void_p),
         ("margins", ctypes.c_void_p),
+        ("lin_tau", ctypes.c_float), ("lin_group", ctypes.c_int32),
     ]
 
 
@@ -90,7 +91,7 @@ def qkskip_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, block_m: in
                softmax_scale: Optional[float] = None, p_round: bool = True,
                mask_any_tail: bool = True, nthreads: int = 0, margins: Optional[torch.Tensor] = None,
                q_descale: Optional[torch.Tensor] = None, k_descale: Optional[torch.Tensor] = None,
-               v_descale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, int]:
+               v_descale: Optional[torch.Tensor] = None, lin_lazy: bool = True) -> Tuple[torch.Tensor, torch.Tensor, int]:
     """Tiled CPU forward. q,k,v: (B,S,H,D) of any float dtype (values are taken as they are,
     i.e. bf16 tensors give bf16-representable fp32 operands). Lists are CPU int32 tensors of shape
     [>=B, H, Qt, Kt+1]; ``write_list`` is filled in place. ``must_do_list`` may be 1-D ([Kt+1]).
@@ -142,6 +143,10 @@ def qkskip_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, block_m: in
     # "fp8": e4m3 P with the 2^8 offset (reference Max_offset); "f16": P rounded to fp16; True / False: bf16 / fp32 P;
     # "fp8_lin": NOT a reference form - this build's default log-linear byte encoding of P (qkskip_oracle.c, p_round 4)
     a.p_round = {"fp8": 2, "f16": 3, "fp8_lin": 4}.get(p_round, None) if isinstance(p_round, str) else int(p_round)
+    # "fp8_lin": by default the kernel's own LAZY reference maximum (m_ref = the first walked tile's row maximum; a wave of 64 rows moves it
+    # only after growth by more than 32 log2 units), so that the encoded bytes are the kernel's wherever the scores agree exactly;
+    # lin_lazy=False: reference = the true running maximum after every tile (the restatement of rounds 3-4; another grid of the same kind)
+    a.lin_tau, a.lin_group = (32.0, 64) if (a.p_round == 4 and lin_lazy) else (0.0, 0)
     keep = []
     for name, t in (("q_descale", q_descale), ("k_descale", k_descale), ("v_descale", v_descale)):
         if t is not None:

@@ -47,8 +47,9 @@ def ref_tolerance(out_ref, pt_maxerr):
     return 2 * pt_maxerr + fwd_atol
 
 
-def fp8_lse_tol():
-    """Bound on |LSE - oracle| for the fp8 kernel, by the form of P that is selected (include/lite_attention_amd.h):
+def fp8_lse_tol_vs_exact():
+    """Bound on |LSE - EXACT LSE| (the oracle with un-rounded P) for the fp8 kernel, by the form of P that is selected
+    (include/lite_attention_amd.h):
     default - the block-scaled log-linear byte encoding of P, row sums of the ENCODED P from the matrix pipe: every P~ / P lies in
       [0.920, 1.065] (tests/test_oracle.py scans it), so |ln(sum P~ / sum P)| <= -ln 0.920 = 0.083, reached only by rows of one or two
       comparable keys; on long rows the noise averages out and a bias of about -3e-4 remains;
@@ -60,6 +61,25 @@ def fp8_lse_tol():
     if os.environ.get("LA_FP8_EXP", "").startswith("exact"):
         return math.log1p(2.0 ** -4) + 1e-3
     return -math.log(0.920) + 1e-3
+
+
+def fp8_lse_tol():
+    """Bound on |LSE - oracle IN THE SAME FORM of P| (``fp8_p_round()``). The exact forms: as ``fp8_lse_tol_vs_exact``. The default form:
+    since round 5 the oracle encodes P~ on the kernel's own grid (relative to the lazy reference maximum), so the two agree to ~1e-4 on
+    all but the rows where a score sits on a byte boundary and the last bits of S (MFMA accumulation order vs the CPU's) decide it; one
+    byte of a row's dominant key is a factor of up to 1.125 (e4m3 mantissa step at M = 0) = 0.118 in the LSE. So: 0.118 + 1e-3 for the
+    worst row - and ``fp8_rows_off_grid`` holds the NUMBER of such rows down, which is what says the grids are the same."""
+    if os.environ.get("LA_FP8_ROWSUM", "").startswith("exact") or os.environ.get("LA_FP8_EXP", "").startswith("exact"):
+        return fp8_lse_tol_vs_exact()
+    return math.log(1.125) + 1e-3
+
+
+def fp8_rows_off_grid(lse, lse_same_form, atol=0.01):
+    """Fraction of rows whose LSE differs from the same-form oracle's by more than `atol` (a flipped byte of a significant key).
+    With the oracle on the kernel's grid this is a fraction of a percent (rounds 3-4, another grid: ~60 %)."""
+    d = (lse - lse_same_form).abs()
+    d = d[torch.isfinite(d)]
+    return float((d > atol).float().mean().item()) if d.numel() else 0.0
 
 
 def fp8_p_round():

@@ -97,7 +97,7 @@ def test_shim_import_names_and_reference_signatures():
 
 def test_build_rejects_scratch_in_the_x64_kernels():
     """build.py::_check_no_scratch: the x64 kernels (an asm body that clobbers nearly the whole register file inside a C++ shell) must
-    not spill — hipcc has placed such spill stores where EXEC is 0 ('A compiler hazard')."""
+    not spill — hipcc has placed such spill stores where EXEC is 0 (HISTORY.md section 3.1, 'A compiler hazard')."""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("la_build_t", os.path.join(os.path.dirname(L.__file__), "build.py"))

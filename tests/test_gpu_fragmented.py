@@ -17,7 +17,7 @@ Why the default bound is one bf16 ulp at max|O| here and half an ulp in test_gpu
 few keys carry most of a row's weight, max|O| > 1). Both the reference and the kernel round P to bf16 before P V while the row sum
 uses the un-rounded P (softmax.h:275-296, mainloop...:1645-1647). With an exact rescale the dominant key of a row has P = 2^0:
 no rounding error where it matters. Under the lazy rescale (O kept relative to a reference max that lags the true one by up to
-2^8) the dominant P is an arbitrary value in [1, 2^8]: it carries a relative rounding error of up to 2^-9 that
+2^8, HISTORY.md 3.1) the dominant P is an arbitrary value in [1, 2^8]: it carries a relative rounding error of up to 2^-9 that
 scales the whole row of O. Measured (round 3, head_dim 256, step 2): 0.00795 at |O| = 1.19 lazily, 0.0032 exactly rescaled;
 on flat rows (random data, test_gpu_parity.py) the rounding errors of thousands of keys average out and 2^-8 holds either way.
 """

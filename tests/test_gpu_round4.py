@@ -289,3 +289,45 @@ def test_fp8_four_split_merge_against_the_fp8_oracle_on_the_full_keys(form, monk
     assert torch.allclose(lse.cpu(), ml_ref.transpose(1, 2), atol=1e-5, rtol=1e-5)
     if form == "seq_parallel_default":        # and the long-row statistics: exact row sums leave no bias in the merged LSE
         assert (lse.cpu() - lse_ref).mean().abs().item() <= 1e-4
+
+
+def test_windowed_launches_are_bit_identical_under_a_co_running_copy_stream():
+    """the overlapped all-gather puts copy kernels of another stream beside the next q-tile window. With no second
+    GPU, that is emulated by what an all-gather is on the device - copies on a side stream behind each window's rows, plus a bandwidth
+    hog that never stops: outputs, LSE and write lists of the windowed dynamic and static-after-first forms stay bit-identical to the
+    single undisturbed launch (tools/window_interference.py measures what it costs: profiles/r05_window_interference.md). The reference has
+    one launch per call and no counterpart (flash_fwd_launch_template.h:359)."""
+    from liteattention_amd.parallel import plan_q_windows
+    torch.manual_seed(0)
+    S, H, D = 8300, 6, 128
+    g = torch.Generator(device=DEV).manual_seed(5)
+    q, k, v = [torch.randn(1, S, H, D, device=DEV, generator=g).bfloat16() for _ in range(3)]
+    bm, bn = L.get_tile_sizes(D, 2)
+
+    def fresh():
+        att = L.LiteAttention(threshold=-3.0, max_batch_size=1)
+        att(q, k, v); att(q, k, v)                                   # two steps: a real (non-trivial) read list
+        return att
+    a0 = fresh()
+    ref_o, ref_l = a0(q, k, v, return_softmax_lse=True)
+    ref_lists = a0._skip_list.clone()
+    side = torch.cuda.Stream()
+    hog_src = torch.empty(64 << 20, dtype=torch.uint8, device=DEV); hog_dst = torch.empty_like(hog_src)
+    peers = torch.empty_like(ref_o)
+    for n, sched in ((3, False), (3, "after_first"), (5, "after_first")):
+        att = fresh()
+        w = plan_q_windows(-(-S // bm), H, n, slots=16)               # small "machine": several rounds per window at this size
+        assert len(w) >= 2
+
+        def hook(i, out, r0, r1):
+            e = torch.cuda.Event(); e.record()
+            with torch.cuda.stream(side):
+                side.wait_event(e)
+                peers[:, r0:r1].copy_(out[:, r0:r1], non_blocking=True)
+        with torch.cuda.stream(side):
+            for _ in range(8):
+                hog_dst.copy_(hog_src, non_blocking=True)
+        o, l = att.call_windowed(q, k, v, w, hook, return_softmax_lse=True, static_sched=sched)
+        torch.cuda.synchronize()
+        assert torch.equal(o, ref_o) and torch.equal(l, ref_l) and torch.equal(att._skip_list, ref_lists), (n, sched)
+        assert torch.equal(peers, ref_o)                               # every row was final when its window's hook saw it

@@ -196,21 +196,46 @@ def test_fp8_oracle_matches_reference_outputs(name):
 @pytest.mark.parametrize("name", FP8_CASES + ["gqa_fp8_b1_s260_h4_hk2_d128"])
 def test_fp8_log_linear_encoding_of_p_stays_inside_the_reference_rule(name):
     """The build's default fp8 form of P (NOT the reference's: include/lite_attention_amd.h LA_FLAG_EXACT_EXP; oracle p_round="fp8_lin")
-    against the reference-generated fp8 outputs: inside the reference's own rule with room to spare, at most 1.6 x the error of the
-    hardware rounding, LSE within the bound tests/helpers.py::fp8_lse_tol states for it."""
+    against the reference-generated fp8 outputs: inside the reference's own rule with room to spare, LSE within the bound
+    tests/helpers.py::fp8_lse_tol states for it.
+
+    Round 5: the oracle restates the KERNEL's grid exactly - P~ relative to the lazy reference maximum m_ref (the first walked tile's row
+    maximum; `lin_lazy`, the default) - where rounds 3-4 encoded relative to the true running maximum after every tile. That older grid
+    represents a row's dominant key exactly (its exponent lands on a byte), the kernel's does not ((m_true - m_ref) c is no integer):
+    against the hardware rounding the kernel's grid has 1.6-2.1 x the rms error and up to 2.3 x the max error on these goldens, the older
+    restatement 1.2-1.9 x / 1.1-1.9 x. Both are held here; the first is the one the GPU tests compare the kernel with."""
     c = load_dense_case(name)
     kw = dict(q_descale=c["q_descale"], k_descale=c["k_descale"], v_descale=c["v_descale"])
     o8, lse8, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=256, block_n=64, p_round="fp8", **kw)
-    ol, lsel, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=256, block_n=64, p_round="fp8_lin", **kw)
     e8 = (o8 - c["out_ref"]).abs().max().item()
-    el = (ol - c["out_ref"]).abs().max().item()
-    assert el <= 0.5 * ref_tolerance(c["out_ref"], c["pt_maxerr"]), (el, ref_tolerance(c["out_ref"], c["pt_maxerr"]))
-    assert el <= 1.6 * e8 + 1e-3, (el, e8)
     rms8 = (o8 - c["out_ref"]).pow(2).mean().sqrt().item()
-    rmsl = (ol - c["out_ref"]).pow(2).mean().sqrt().item()
-    assert rmsl <= 1.6 * rms8 + 1e-4, (rmsl, rms8)                      # (the short flat-softmax GQA case is the 1.6; the others 1.2)
-    assert (lsel - c["lse_ref"]).abs().max().item() <= 0.084
-    assert (ol - o8).abs().max().item() > 1e-4                           # a different encoding really is in the path
+    for lazy, k_max, k_rms in ((True, 2.3, 2.1), (False, 1.9, 1.9)):
+        ol, lsel, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=256, block_n=64, p_round="fp8_lin", lin_lazy=lazy, **kw)
+        el = (ol - c["out_ref"]).abs().max().item()
+        assert el <= 0.55 * ref_tolerance(c["out_ref"], c["pt_maxerr"]), (lazy, el, ref_tolerance(c["out_ref"], c["pt_maxerr"]))
+        assert el <= k_max * e8 + 1e-3, (lazy, el, e8)
+        rmsl = (ol - c["out_ref"]).pow(2).mean().sqrt().item()
+        assert rmsl <= k_rms * rms8 + 1e-4, (lazy, rmsl, rms8)
+        assert (lsel - c["lse_ref"]).abs().max().item() <= 0.084
+        assert (ol - o8).abs().max().item() > 1e-4                       # a different encoding really is in the path
+
+
+def test_fp8_lazy_reference_is_the_same_attention():
+    """The lazy reference of p_round 4 (la_oracle_args.lin_tau / lin_group) on keys whose maxima keep growing along the walk (the walk is
+    descending: the largest keys sit at the front of the sequence): the reference maximum stays the first walked tile's, the block scales
+    carry the growth, and the result is still the attention - O within the stated fp8 bound of the un-rounded oracle, LSE within the
+    encoding's bound - for the lazy and for the older restatement alike."""
+    g = torch.Generator().manual_seed(3)
+    S = 700
+    q = torch.randn(1, 130, 1, 128, generator=g)
+    k = torch.randn(1, S, 1, 128, generator=g) * torch.linspace(2.5, 0.5, S)[None, :, None, None]      # later-walked (low) keys are larger
+    v = torch.randn(1, S, 1, 128, generator=g)
+    q, k, v = [x.to(torch.float8_e4m3fn).float() for x in (q, k, v)]
+    exact, lse_e, _ = orc.qkskip_fwd(q, k, v, block_m=256, block_n=64, p_round=False)
+    for lazy in (True, False):
+        o, lse, _ = orc.qkskip_fwd(q, k, v, block_m=256, block_n=64, p_round="fp8_lin", lin_lazy=lazy)
+        assert (o - exact).abs().max().item() <= 0.05 * exact.abs().max().item() + 2e-2, lazy
+        assert (lse - lse_e).abs().max().item() <= 0.084, lazy
 
 
 def test_fp8_log_linear_byte_decoding():

@@ -5,7 +5,7 @@
       name=x64f8:<opts>  gen_fwd_x64_fp8.py with LA_X64F8_OPT=<opts>
       name=x64d<D>:<opts> gen_fwd_x64.py with LA_X64_D=<D> (64, 96, 192, 256) LA_X64_OPT=<opts>
     (GPU box)  LITEATTENTION_AMD_LIB=$PWD/build_variants/<name>.so python tools/abl_bench.py
-Ablation variants compute wrong results; they only price a component.
+Ablation variants compute wrong results; they only price a component (HISTORY.md section 4).
 """
 import os, subprocess, sys
 from concurrent.futures import ThreadPoolExecutor

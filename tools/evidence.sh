@@ -37,12 +37,15 @@ for cfg in "imposed 0.0" "imposed 0.42" "imposed 0.77" "real -4.22" "real -2.46"
   pmc ${n}_busy GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- $P
 done
 # 5. the other instantiations: bench lines + kernel stats + MFMA utilisation (d64: tools/d64_bench.py; 96 / 192 / 256: tools/d256_bench.py <D>)
-for t in d64 d96 d192 d256; do
+# (d128: the headline body on the same shape, for the stall breakdown table: what the others are measured against)
+for t in d64 d96 d128 d192 d256; do
   want other || continue
   if [ $t = d64 ]; then C="python $R/tools/d64_bench.py"; else C="python $R/tools/d256_bench.py ${t#d}"; fi
   $C > $OUT/${t}_bench.txt 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${t}_kt -o kt -- $C > $OUT/${t}_kt.log 2>&1
   pmc ${t}_mfma SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -- $C
+  # the stall breakdown: how much of the issue stall is the LDS, how busy the LDS array is, instruction counts
+  pmc ${t}_lds SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- $C
 done
 # the hipcc-scheduled A/B kernels on the same box (head dims 192 / 96 zero-padded onto 256 / 128 by the host)
 want other && LA_FWD_KERNEL=v2 python $R/tools/d256_bench.py > $OUT/v2_bench.txt 2>&1
@@ -56,7 +59,7 @@ if want fp8forms; then
     python $R/tools/debug/fp8_tail_probe.py -4.22 2>&1 | grep "real lists"
     python $R/tools/debug/fp8_tail_probe.py -2.462 2>&1 | grep "real lists"; } > $OUT/fp8_p_forms.txt 2>&1
 fi
-# 6. socket power and clocks under the kernels (rocm-smi)
+# 6. socket power and clocks under the kernels (rocm-smi; HISTORY.md section 4.2)
 want power && (cd $R && bash tools/power_probe.sh $OUT/power_probe.txt > /dev/null 2>&1)
 ls $OUT | head -80
 grep -h PROBE $OUT/traffic_*_fetch.log 2>/dev/null

@@ -17,7 +17,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from helpers import structured_qkv, fragmented_qkv, fp8_lse_tol, fp8_p_round  # noqa: E402
+from helpers import structured_qkv, fragmented_qkv, fp8_lse_tol, fp8_lse_tol_vs_exact, fp8_p_round  # noqa: E402
 from test_gpu_parity import _compare_lists  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 import liteattention_amd as L  # noqa: E402
@@ -93,14 +93,18 @@ for case in range(n_cases):
             el = (lse.cpu() - lse_ref).abs()
             el = el[torch.isfinite(el)].max().item() if torch.isfinite(el).any() else 0.0
             bad, border = _compare_lists(orc, rd, wr, wr_orc, margins, thr, B)
-            if dtype == "fp8" and tol(o_ref) < eo <= 1.5 * tol(o_ref):
-                # byte-flip rule (round 4, found by this soak: seed 7, case 2258): on very peaked rows the kernel and the oracle's restatement of
-                # the SAME 8-bit encoding of P can round a dominant key to adjacent bytes (one byte = 2^(1/8): 9 % of that weight). Such a
-                # case passes if the kernel is inside the stated bound against the oracle with UN-rounded P (the truth both approximate).
-                o_true, _, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=rd, write_list=torch.zeros_like(wr), must_do_list=md_row,
-                                              thr=thr, p_round=False, softmax_scale=scale)
-                if (out.float().cpu() - o_true).abs().max().item() <= tol(o_ref):
-                    eo = tol(o_ref)
+            # (round 4 carried a "byte-flip rule" here for the fp8 default form: the oracle encoded P~ relative to the true running maximum, the
+            # kernel relative to its lazy reference maximum - two different 8-bit grids, so on peaked rows they disagreed by up to one byte
+            # on a dominant key. Round 5: the oracle restates the kernel's grid exactly (p_round 4, lin_lazy; identical bytes on exact scores:
+            # tests/test_gpu_fp8.py), and the rule is gone.)
+            if dtype == "fp8" and fp8_p_round() == "fp8_lin":
+                # the second, independent bound of the default fp8 form: against the EXACT LSE (un-rounded P) the encoding's own bound
+                _, lse_x, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=rd, write_list=torch.zeros_like(wr), must_do_list=md_row,
+                                             thr=thr, p_round=False, softmax_scale=scale)
+                ex = (lse.cpu() - lse_x).abs()
+                ex = ex[torch.isfinite(ex)].max().item() if torch.isfinite(ex).any() else 0.0
+                if ex > fp8_lse_tol_vs_exact():
+                    el = max(el, 10.0 * lse_tol)               # fail the case
             if not (eo <= tol(o_ref) and el <= lse_tol and bad == 0 and border <= 3 and bool(torch.isfinite(out.float()).all())):
                 fails.append(f"{desc} | step {step}: O err {eo:.4g} (tol {tol(o_ref):.4g}) LSE err {el:.4g} (tol {lse_tol:.3g}) list rows bad {bad} borderline {border}")
                 break

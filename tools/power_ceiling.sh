@@ -2,7 +2,7 @@
 # GPU box, ONE session: the evidence behind "this kernel is at the socket's power limit".
 #   1. MFMA-only loops (tools/mfma_power_bench.py): 32x32x16 and 16x16x32 bf16, random vs all-zero operands, 1 and 2 waves per SIMD:
 #      ms, TFLOP/s, rocm-smi W and sclk; then GRBM_GUI_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES of the four 1-wave cases in their own PMC pass
-#   2. the ablation table of DESIGN.md 4.2 regenerated on the current body (tools/pmc_cycles.sh: cycles, clock, MFMA busy) with the
+#   2. the ablation table of HISTORY.md 4.2 regenerated on the current body (tools/pmc_cycles.sh: cycles, clock, MFMA busy) with the
 #      power of every variant beside it (tools/variant_power.py), plus the priced levers (dotsum, mfmasum, halfskip, mfma16)
 #   3. the headline configuration on THIS box: bench line (with its rocm-smi sample) + the MFMA PMC pass   (tools/box_probe.sh)
 # Variants are built on the CPU side first:  python tools/asm_variants.py x_base=x64: ...   (see profiles/r04_power_ceiling.md)

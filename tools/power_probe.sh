@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: socket power and clocks (rocm-smi) sampled while one kernel runs in a loop - the direct evidence for DESIGN.md section 4.2.
+# GPU box: socket power and clocks (rocm-smi) sampled while one kernel runs in a loop - the direct evidence for HISTORY.md section 4.2.
 # usage: tools/power_probe.sh <outfile> ; runs bf16 42 %, bf16 dense, fp8 42 %, an MFMA-idle memory copy loop for contrast
 OUT=${1:-gpurun_out/power_probe.txt}
 mkdir -p $(dirname $OUT)

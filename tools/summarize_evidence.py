@@ -192,7 +192,8 @@ md = [f"# Other instantiations `{tag}` (bf16 head_dim 64, 96, 192, 256), kernel 
 if os.path.exists(os.path.join(src, "v2_bench.txt")):
     md += ["Same box, `LA_FWD_KERNEL=v2 python tools/d256_bench.py` (the hipcc-scheduled 128-row kernels; 192 / 96 zero-padded onto 256 / 128):", "", "```"] + \
           [l for l in open(os.path.join(src, "v2_bench.txt")).read().strip().splitlines() if "amdgpu.ids" not in l] + ["```", ""]
-for t in ("d64", "d96", "d192", "d256"):
+breakdown = []
+for t in ("d64", "d96", "d128", "d192", "d256"):
     if not os.path.exists(os.path.join(src, f"{t}_bench.txt")):
         continue
     txt = open(os.path.join(src, f"{t}_bench.txt")).read().strip().splitlines() if os.path.exists(os.path.join(src, f"{t}_bench.txt")) else []
@@ -204,6 +205,30 @@ for t in ("d64", "d96", "d192", "d256"):
     d = derived(pmc, avg)
     md += ["", f"PMC (all forward dispatches of the tool averaged): {json.dumps({k: round(v, 4) if isinstance(v, float) else v for k, v in d.items()})}",
            f"kernel resources: {meta}", ""]
+    lds, _, _ = counters(f"{t}_lds")
+    if lds and pmc.get("SQ_WAVE_CYCLES"):
+        wc = pmc["SQ_WAVE_CYCLES"]
+        cyc_l = lds.get("GRBM_GUI_ACTIVE", 0) / 8
+        tfl = next((l for l in txt if " TF" in l), "")
+        breakdown.append({"head_dim": int(t[1:]), "bench": tfl.strip(), "mfma_busy": d.get("mfma_util"), "clock_GHz": d.get("clock_GHz"),
+                          "issuing": pmc.get("SQ_ACTIVE_INST_ANY", 0) / wc, "stalled": pmc.get("SQ_WAIT_INST_ANY", 0) / wc, "parked": pmc.get("SQ_WAIT_ANY", 0) / wc,
+                          "valu_active": pmc.get("SQ_ACTIVE_INST_VALU", 0) / wc,
+                          "stalled_on_lds_issue": lds.get("SQ_WAIT_INST_LDS", 0) / max(lds.get("SQ_WAVE_CYCLES", 1), 1),
+                          "lds_issuing": lds.get("SQ_ACTIVE_INST_LDS", 0) / max(lds.get("SQ_WAVE_CYCLES", 1), 1),
+                          "lds_array_busy": lds.get("SQ_LDS_IDX_ACTIVE", 0) / (256 * max(cyc_l, 1)), "lds_bank_conflict_cycles": lds.get("SQ_LDS_BANK_CONFLICT", 0),
+                          "lds_insts_per_launch": lds.get("SQ_INSTS_LDS", 0), "valu_insts_per_launch": lds.get("SQ_INSTS_VALU", 0)})
+if breakdown:
+    tb = ["## Stall breakdown per head dim (fractions of the waves' cycles; dense S = 16 384 H = 40; VERDICT r4 item 6)", "",
+          "`SQ_ACTIVE_INST_ANY` issuing / `SQ_WAIT_INST_ANY` stalled at issue (dependencies, pipes; `SQ_WAIT_INST_LDS` = the part of it waiting to issue an LDS "
+          "instruction) / `SQ_WAIT_ANY` parked on `s_waitcnt` or the barrier (this is where a wave waits for fragment DATA); LDS array busy = `SQ_LDS_IDX_ACTIVE` / 256 per CU-cycle.", "",
+          "| head_dim | tool line | MFMA busy | clock GHz | issuing | stalled (of which LDS issue) | parked | VALU active | LDS instr. issuing | LDS array busy | bank conflicts |",
+          "|---|---|---|---|---|---|---|---|---|---|---|"]
+    for b in breakdown:
+        tb.append(f"| {b['head_dim']} | {b['bench']} | {100 * (b['mfma_busy'] or 0):.1f} % | {(b['clock_GHz'] or 0):.2f} | {100 * b['issuing']:.1f} % | "
+                  f"{100 * b['stalled']:.1f} % ({100 * b['stalled_on_lds_issue']:.1f} %) | {100 * b['parked']:.1f} % | {100 * b['valu_active']:.1f} % | "
+                  f"{100 * b['lds_issuing']:.1f} % | {100 * b['lds_array_busy']:.1f} % | {b['lds_bank_conflict_cycles']:.0f} |")
+    md = md[:2] + tb + [""] + md[2:]
+    json.dump({"kernel_source_sha16": sha, "rows": breakdown}, open(os.path.join(PROF, f"{tag}_stall_breakdown.json"), "w"), indent=1)
 open(os.path.join(PROF, f"{tag}_other_head_dims.md"), "w").write("\n".join(md) + "\n")
 if os.path.exists(os.path.join(src, "fp8_p_forms.txt")):
     shutil.copy(os.path.join(src, "fp8_p_forms.txt"), os.path.join(PROF, f"{tag}_fp8_p_forms.txt"))

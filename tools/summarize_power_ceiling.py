@@ -87,7 +87,7 @@ json.dump(res, open(os.path.join(ROOT, "profiles", "r04_power_ceiling.json"), "w
 
 md = ["# r04 — the power ceiling of the bf16 kernel: evidence (generated by tools/summarize_power_ceiling.py)", "",
       "VERDICT r3 asked for four things under `profiles/`: (i) the MFMA-only loop with random vs all-zero operands, (ii) the same for",
-      "`v_mfma_f32_16x16x32_bf16`, (iii) the ablation table of DESIGN.md 4.2 regenerated on the current body, (iv) the headline on >= 3 boxes",
+      "`v_mfma_f32_16x16x32_bf16`, (iii) the ablation table of HISTORY.md 4.2 regenerated on the current body, (iv) the headline on >= 3 boxes",
       "with clock, watts and MFMA busy. Then two energy levers priced (row sums off the vector unit; per-half skipping). All of it is here;",
       "(i)-(iii) are ONE session on one box (`gpurun_out/r04_power`), the re-spaced 16x16x32 stand-ins a second one (`r04_m16`).", "",
       "## (i) (ii) The matrix pipe alone: `tools/mfma_power_bench.py`", "",

@@ -8,7 +8,7 @@ Every case is a loop of 64 independent VALU instructions (sources v0..v31, desti
 4 waves with 100 KiB of LDS each (one workgroup per CU), optionally with one MFMA in front of every `per_mfma` instructions.
 Reported: shader cycles per instruction (s_memtime) and the effective clock (cycles / wall time). What it answers: the real
 issue cost of the softmax instructions (v_exp_f32 vs v_exp_f16, packed fp32 / fp16 forms, the fp8 / f16 converts, v_dot2 row
-sums) alone and under MFMAs — the numbers the fp8 softmax redesign of round 3 is priced with.
+sums) alone and under MFMAs — the numbers the fp8 softmax redesign of round 3 is priced with (HISTORY.md section 4.2).
 """
 import os
 import subprocess
