@@ -1,5 +1,6 @@
-"""CPU: the measured tables of DESIGN.md are the ones tools/gen_design_tables.py writes from the committed evidence of ONE run
-(profiles/r04_*): prose may interpret the numbers, it may not drift from them."""
+"""CPU: the measured tables of MEASUREMENTS.md are the ones tools/gen_design_tables.py writes from the committed evidence of ONE run
+(the newest profiles/rNN_*): prose may interpret the numbers, it may not drift from them. DESIGN.md is the short
+current-state document (<= 300 lines, <= 120 columns), HISTORY.md the record of rounds 1-4."""
 import os
 import subprocess
 import sys
@@ -8,9 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_design_tables_are_generated_from_the_committed_profiles():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_design_tables.py"), "r04", "--check"], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_design_tables.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    text = open(os.path.join(ROOT, "MEASUREMENTS.md")).read()
     for name in ("headline", "rocprof_bf16", "rocprof_fp8", "traffic", "real_gap", "fp8_forms", "sched_sweep", "denoise50"):
         body = text.split(f"<!-- GEN:{name} -->")[1].split(f"<!-- /GEN:{name} -->")[0]
         assert body.strip(), f"generated block {name} is empty"
@@ -42,3 +43,12 @@ def test_tools_readme_indexes_exactly_the_scripts_that_exist():
     named = set(re.findall(r"`((?:debug/)?[a-z0-9_]+\.(?:py|sh|hip))", readme))
     assert have - named == set(), f"scripts tools/README.md does not index: {sorted(have - named)}"
     assert named - have == set(), f"tools/README.md names scripts that do not exist: {sorted(named - have)}"
+
+
+def test_design_md_is_the_short_current_state_document():
+    """DESIGN.md = current state, at most 300 lines of at most 120 columns; the history lives in HISTORY.md."""
+    lines = open(os.path.join(ROOT, "DESIGN.md")).read().splitlines()
+    assert len(lines) <= 300, len(lines)
+    long = [(i + 1, len(l)) for i, l in enumerate(lines) if len(l) > 120]
+    assert not long, long[:5]
+    assert os.path.exists(os.path.join(ROOT, "HISTORY.md")) and os.path.exists(os.path.join(ROOT, "MEASUREMENTS.md"))

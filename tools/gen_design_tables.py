@@ -1,9 +1,9 @@
 #!/usr/bin/env python
-"""Rewrites the measured tables of DESIGN.md from the committed evidence of ONE run (profiles/<tag>_*; tools/evidence.sh ->
+"""Rewrites the measured tables of MEASUREMENTS.md from the committed evidence of ONE run (profiles/<tag>_*; tools/evidence.sh ->
 tools/summarize_evidence.py): every block between `<!-- GEN:name -->` and `<!-- /GEN:name -->` is regenerated, nothing else is touched.
 
-    python tools/gen_design_tables.py [tag]            rewrite DESIGN.md in place (default tag r04)
-    python tools/gen_design_tables.py [tag] --check    exit 1 if DESIGN.md is not what the profiles say (tests/test_docs.py)
+    python tools/gen_design_tables.py [tag]            rewrite MEASUREMENTS.md in place (default tag: the newest profiles/rNN_bench_line.json)
+    python tools/gen_design_tables.py [tag] --check    exit 1 if MEASUREMENTS.md is not what the profiles say (tests/test_docs.py)
 
 The prose around the blocks may interpret the numbers; it must not restate them from memory."""
 import json
@@ -134,10 +134,15 @@ def blocks(tag):
     return out
 
 
+def latest_tag():
+    tags = sorted(f[:3] for f in os.listdir(PROF) if re.fullmatch(r"r\d\d_bench_line\.json", f))
+    return tags[-1] if tags else "r04"
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    tag = args[0] if args else "r04"
-    path = os.path.join(ROOT, "DESIGN.md")
+    tag = args[0] if args else latest_tag()
+    path = os.path.join(ROOT, "MEASUREMENTS.md")
     text = open(path).read()
     new = text
     for name, rows in blocks(tag).items():
@@ -146,12 +151,12 @@ def main():
             new = pat.sub(lambda m: m.group(1) + "\n".join(rows) + "\n" + m.group(2), new)
     if "--check" in sys.argv:
         if new != text:
-            print("DESIGN.md tables are stale: run python tools/gen_design_tables.py", tag)
+            print("MEASUREMENTS.md tables are stale: run python tools/gen_design_tables.py", tag)
             sys.exit(1)
-        print("DESIGN.md tables match profiles/" + tag + "_*")
+        print("MEASUREMENTS.md tables match profiles/" + tag + "_*")
         return
     open(path, "w").write(new)
-    print("DESIGN.md: regenerated blocks", sorted(blocks(tag)))
+    print("MEASUREMENTS.md: regenerated blocks", sorted(blocks(tag)), "from", tag)
 
 
 if __name__ == "__main__":
