@@ -210,7 +210,7 @@ for t in ("d64", "d96", "d128", "d192", "d256"):
         wc = pmc["SQ_WAVE_CYCLES"]
         cyc_l = lds.get("GRBM_GUI_ACTIVE", 0) / 8
         tfl = next((l for l in txt if " TF" in l), "")
-        breakdown.append({"head_dim": int(t[1:]), "bench": tfl.strip(), "mfma_busy": d.get("mfma_util"), "clock_GHz": d.get("clock_GHz"),
+        breakdown.append({"head_dim": int(t[1:]), "bench": tfl.strip().replace("|", ";"), "mfma_busy": d.get("mfma_util"), "clock_GHz": d.get("clock_GHz"),
                           "issuing": pmc.get("SQ_ACTIVE_INST_ANY", 0) / wc, "stalled": pmc.get("SQ_WAIT_INST_ANY", 0) / wc, "parked": pmc.get("SQ_WAIT_ANY", 0) / wc,
                           "valu_active": pmc.get("SQ_ACTIVE_INST_VALU", 0) / wc,
                           "stalled_on_lds_issue": lds.get("SQ_WAIT_INST_LDS", 0) / max(lds.get("SQ_WAVE_CYCLES", 1), 1),
