@@ -244,12 +244,16 @@ def k_read(kbuf_imm, j):
     """K fragment j: rows 32 kb + (lane & 31), 16-byte chunk 2 ks + hh (XOR-swizzled by the row: KADDR[ks & 7]); the chunks of
     k-steps 8..15 (head_dim 256) are the same addresses + 256 bytes (the swizzle stays inside a 256-byte half row)."""
     kb, ks = j // KS, j % KS
+    if "lds23" in OPT and j % 3 == 2:      # PRICING ONLY (wrong results): every third fragment read dropped - what a body with 1.5 x the rows per fragment would read
+        return "    ; (lds23: K fragment read dropped)"
     return ("LDS", f"ds_read_b128 {KFRAG(j)}, {v(KADDR[ks & 7])} offset:{kbuf_imm + kb * 32 * ROW + (ks >> 3) * 256}", ("k", j))
 
 
 def v_read(slot, vbuf_imm, m):
     """V^T fragment m = 4 db + kk: keys 16 kk .. 16 kk + 15, d-block db (VADDR[db & 3]; d-blocks 4..7 of head_dim 256: + 256 bytes)."""
     db, kk = m >> 2, m & 3
+    if "lds23" in OPT and m % 3 == 2:
+        return ["    ; (lds23: V^T fragment read dropped)"]
     if "vfake" in OPT:      # pricing only: ONE b128 read per fragment, as a pre-transposed V^T image would need
         return [("LDS", f"ds_read_b128 {vr(VF[slot], 4)}, {v(KADDR[2 * kk])} offset:{V_REGION + vbuf_imm + db * 4096}", ("v", m, 1))]
     off = vbuf_imm + kk * 16 * ROW + (db >> 2) * 256
