@@ -621,7 +621,7 @@ def main():
             res["verified"] = ver
 
         # ---- package power / clock under the timed configuration (1 GPU only; about a second)
-        if use_dist is None and not args.no_power:
+        if use_dist is None and seam is None and not args.no_power:
             try:
                 set_sparsity(HEADLINE_SPARSITY)
                 n_q = max(8, int(1.2 / max(step_s, 1e-4)))
@@ -656,7 +656,8 @@ def main():
         res["_headline_again"] = headline_again
         return res
 
-    main_res = run_dtype(args.dtype, args.steps, args.warmup, sweep=(world == 1 and not args.no_sweep), distributed=True)
+    # (the stand-in seam of the CPU tests has no device: the 1-GPU sub-records - sweep, fp8, head dims, 50-step run, CPU baseline - stay out of its line)
+    main_res = run_dtype(args.dtype, args.steps, args.warmup, sweep=(world == 1 and seam is None and not args.no_sweep), distributed=True)
     bm, bn, q_tiles, k_tiles = main_res.pop("_bm_bn_tiles")
     headline_again = main_res.pop("_headline_again")
 
@@ -685,7 +686,7 @@ def main():
             result[key] = main_res[key]
 
     # ---- BASELINE.json configs[4] beside the headline: the same workload with e4m3 Q/K/V (bf16 out), a few extra seconds
-    if world == 1 and args.dtype == "bf16" and not args.no_fp8:
+    if world == 1 and seam is None and args.dtype == "bf16" and not args.no_fp8:
         try:
             f8 = run_dtype("fp8", max(5, args.steps // 2), 2, sweep=False, distributed=False)
             f8.pop("_bm_bn_tiles"); f8.pop("_headline_again")
@@ -711,14 +712,14 @@ def main():
             result["fp8"] = {"value": None, "error": repr(e)}
 
     # ---- BASELINE.json configs[1]: dense S=32768 H=40 (well under a second)
-    if world == 1 and args.dtype == "bf16" and not args.no_head_dims:
+    if world == 1 and seam is None and args.dtype == "bf16" and not args.no_head_dims:
         try:
             result["config1_dense_s32768"] = config1_dense(L, dev)
         except Exception as e:  # noqa: BLE001
             result["config1_dense_s32768"] = {"error": repr(e)}
 
     # ---- the reference's other default head sizes beside the headline 128 (about a second)
-    if world == 1 and args.dtype == "bf16" and not args.no_head_dims:
+    if world == 1 and seam is None and args.dtype == "bf16" and not args.no_head_dims:
         try:
             result["other_head_dims"] = other_head_dims(L, dev)
         except Exception as e:  # noqa: BLE001
@@ -726,7 +727,7 @@ def main():
 
     # ---- BASELINE.json configs[2]: 50 synthetic denoising steps with REAL (fragmented, per-head) skip lists at fixed thresholds
     # (selfcheck.DENOISE_THRESHOLDS: bisected on all 40 heads for 21 / 42 / 57 / 77 % +- 1 % last-step sparsity, tools/calibrate_denoise.py)
-    if world == 1 and args.dtype == "bf16" and not args.no_denoise and S == 75600 and H == 40:
+    if world == 1 and seam is None and args.dtype == "bf16" and not args.no_denoise and S == 75600 and H == 40:
         try:
             sw0 = result.get("sweep", [{}])[0].get("kernel_ms")
             result["denoise50"] = denoise50(L, dev, sweep0_ms=sw0, random_qkv=qkv_bf16 if world == 1 else None,
@@ -737,7 +738,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             result["denoise50"] = {"error": repr(e)}
 
-    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.dtype == "bf16":
+    if world == 1 and seam is None and rank == 0 and not args.no_cpu_baseline and args.dtype == "bf16":
         try:
             result["cpu_baseline"] = cpu_baseline(S, D, bm, bn, banded_rows(q_tiles, k_tiles, bm, bn, HEADLINE_SPARSITY))
         except Exception as e:  # the baseline is a reported number, never the measured path

@@ -90,12 +90,11 @@ def build_m16_variant(force: bool = False, verbose: bool = False) -> str:
     if fresh and not force:
         return M16_VARIANT
     os.makedirs(os.path.dirname(M16_VARIANT), exist_ok=True)
-    env_opt = os.environ.pop("LA_X64_OPT", None)              # the variant of record is the default schedule of the m16 generator
+    saved = {k: os.environ.pop(k) for k in list(os.environ) if k.startswith("LA_X64")}      # the variant of record: every body at its default schedule
     try:
         return _compile(M16_VARIANT, ["LA_X64_M16=1"], verbose, variant=True)
     finally:
-        if env_opt is not None:
-            os.environ["LA_X64_OPT"] = env_opt
+        os.environ.update(saved)
 
 
 def _generator_env(variant: bool) -> dict:

@@ -49,11 +49,6 @@ for G in (8, 4, 2):
             run = lambda hook=None: att.call_windowed(q, k, v, w, hook, static_sched=sched[0])
             alone = timed(run)
             # (a) a copy stream that never stops
-            stop = [False]
-            def hogged():
-                out = run()
-                return out
-            ev = torch.cuda.Event()
             def with_hog():
                 with torch.cuda.stream(side):
                     for _ in range(24):                       # ~24 x 256 MiB queued beside one step
