@@ -157,10 +157,12 @@ typedef struct la_fwd_args {
     /* Caller-owned scratch (the library allocates nothing). Size from la_fwd_workspace_bytes(); 16-byte aligned;
      * contents are scratch, valid during the call (stream-ordered).
      *   fp8: REQUIRED — the pre-transposed V tiles.
-     *   bf16 with skip lists: OPTIONAL, 1 KiB — eight ticket counters (one queue per XCD). With it the launch uses one
+     *   bf16 / fp16: OPTIONAL, 1 KiB — eight ticket counters (one queue per XCD). With it the launch uses one
      *   persistent workgroup per CU and distributes the (batch, head, q-tile) items dynamically, which removes the
      *   cross-XCD imbalance real skip lists cause (items differ 2-3x in length; the hardware's workgroup->XCD
-     *   assignment is static). Without it: one workgroup per item, static map. Results are identical. */
+     *   assignment is static) and, for dense launches too since round 5 (hand-scheduled kernels; the 128-row template
+     *   keeps the static map there), the per-item workgroup launch (+3.5 % at S = 75 600, +0.7 % at 16 384).
+     *   Without it: one workgroup per item, static map. Results are identical. */
     void*    workspace;
     uint64_t workspace_bytes;
 
@@ -198,8 +200,8 @@ int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n
 /* The same for a launch that sets `flags` (only LA_FLAG_KERNEL_128ROW changes the answer). */
 int la_get_tile_sizes_ex(int head_dim, int element_size, uint32_t flags, int* block_m, int* block_n);
 
-/* Bytes of `workspace` la_fwd wants for these arguments (fp8: required; bf16 with lists: optional, see la_fwd_args;
- * 0 otherwise). Negative la_status on bad arguments. */
+/* Bytes of `workspace` la_fwd wants for these arguments (fp8: required; bf16 / fp16: optional, see la_fwd_args;
+ * 0 under LA_FLAG_STATIC_SCHED and for dense launches of the 128-row template). Negative la_status on bad arguments. */
 int64_t la_fwd_workspace_bytes(const la_fwd_args* args);
 
 /* The forward pass. `stream` is a hipStream_t. */

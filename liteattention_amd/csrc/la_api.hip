@@ -85,8 +85,10 @@ int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n
 int64_t la_fwd_workspace_bytes(const la_fwd_args* a) {
     if (a == nullptr) return LA_ERR_NULL_ARG;
     if (a->struct_size != sizeof(la_fwd_args)) return LA_ERR_STRUCT_SIZE;
-    if (a->dtype == LA_DTYPE_BF16 || a->dtype == LA_DTYPE_FP16)      // ticket counters of the dynamic work distribution (launches with lists)
-        return (a->read_list != nullptr && !(a->flags & LA_FLAG_STATIC_SCHED)) ? static_cast<int64_t>(kSchedWorkspaceBytes) : 0;
+    if (a->dtype == LA_DTYPE_BF16 || a->dtype == LA_DTYPE_FP16)      // ticket counters of the dynamic work distribution: launches with lists, and
+        // (round 5) dense launches of the hand-scheduled kernels; the 128-row template keeps the static map for dense
+        return ((a->read_list != nullptr || !(a->flags & LA_FLAG_KERNEL_128ROW)) && !(a->flags & LA_FLAG_STATIC_SCHED))
+                   ? static_cast<int64_t>(kSchedWorkspaceBytes) : 0;
     if (a->dtype != LA_DTYPE_FP8_E4M3) return LA_ERR_DTYPE;
     int bm = 0, bn = 0;
     const int trc = la_get_tile_sizes_ex(a->head_dim, 1, a->flags, &bm, &bn);
@@ -157,7 +159,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         const size_t tiles = la::fp8_workspace_bytes(a->batch, a->num_heads_k, (a->seqlen_k + bn - 1) / bn);
         if (a->workspace == nullptr || a->workspace_bytes < tiles + kSchedWorkspaceBytes || !aligned16(a->workspace))
             return LA_ERR_WORKSPACE;
-        if (a->read_list != nullptr && !(a->flags & LA_FLAG_STATIC_SCHED))
+        if (!(a->flags & LA_FLAG_STATIC_SCHED))        // lists or dense: persistent workgroups + ticket queues
             p.work_counter = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(a->workspace) + tiles);
     }
     p.q = static_cast<const uint16_t*>(a->q);
@@ -215,9 +217,9 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     const bool skipable = a->read_list != nullptr;                                      // is_skipable, flash_api.cpp:931
     const bool x64 = !(a->flags & LA_FLAG_KERNEL_128ROW);
     hipError_t err;
-    // optional workspace (la_fwd_workspace_bytes): with it, launches that walk lists use persistent workgroups and the
-    // ticket queues; without it, the static one-workgroup-per-item map (same results either way)
-    if (skipable && a->workspace != nullptr && a->workspace_bytes >= kSchedWorkspaceBytes && aligned16(a->workspace) &&
+    // optional workspace (la_fwd_workspace_bytes): with it, the launch uses persistent workgroups and the ticket queues (lists:
+    // every kernel; dense: the hand-scheduled ones); without it, the static one-workgroup-per-item map (same results either way)
+    if ((skipable || x64) && a->workspace != nullptr && a->workspace_bytes >= kSchedWorkspaceBytes && aligned16(a->workspace) &&
         !(a->flags & LA_FLAG_STATIC_SCHED))
         p.work_counter = static_cast<unsigned*>(a->workspace);
     if (x64) {

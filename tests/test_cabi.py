@@ -122,7 +122,13 @@ def test_argument_validation_returns_codes_without_launching():
     assert lib.la_fwd(ctypes.byref(a), None) == _cabi.LA_ERR_WORKSPACE
     a.dtype = _cabi.LA_DTYPE_BF16
     a.block_m = 256
-    assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 0                     # bf16 dense: nothing
+    assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 1024                  # bf16 dense: the optional ticket counters too (round 5)
+    a.flags = _cabi.LA_FLAG_STATIC_SCHED
+    assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 0                     # ... not under the static map
+    a.flags = _cabi.LA_FLAG_KERNEL_128ROW
+    a.block_m = 128
+    assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 0                     # ... nor for dense launches of the 128-row template
+    a.flags, a.block_m = 0, 256
     a.read_list, a.write_list = 0x2000, 0x3000
     assert lib.la_fwd_workspace_bytes(ctypes.byref(a)) == 1024                  # bf16 with lists: the optional ticket counter
     assert lib.la_skip_list_stats(None, 1, 1, 1, 1, None, None) == _cabi.LA_ERR_NULL_ARG
