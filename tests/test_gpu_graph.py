@@ -78,3 +78,34 @@ def test_list_growth_cannot_happen_inside_a_capture_and_preallocate_avoids_it():
     g.replay()
     torch.cuda.synchronize()
     assert att._skip_list.data_ptr() == ptr and torch.equal(o0, e[2]) and torch.equal(o1, e[3])
+
+
+@pytest.mark.parametrize("D", [128, 192])
+def test_dense_calls_on_the_ticket_queues_capture_and_replay(D, monkeypatch):
+    """Round 5: dense launches of the hand-scheduled kernels run on persistent workgroups + ticket queues too (a 1 KiB workspace per
+    call, its memset on the capture stream). Captured in a HIP graph and replayed on new inputs they equal the eager calls bit for bit -
+    and the eager dense call equals the same call forced onto the static map (LA_FLAG_STATIC_SCHED): scheduling never changes results."""
+    import liteattention_amd as L
+    monkeypatch.delenv("LA_SCHED", raising=False)
+    g = torch.Generator(device="cuda").manual_seed(77)
+    S, H = 3000, 7                                               # 12 (24 at head_dim 192) q-tiles x 7 heads: more items than one round of stealing needs
+    data = [[torch.randn(1, S, H, D, device="cuda", generator=g).bfloat16() for _ in range(3)] for _ in range(3)]
+    eager = [L.flash_attn_func(*d, return_softmax_lse=True) for d in data]
+    monkeypatch.setenv("LA_SCHED", "static")                     # the host layer's switch for LA_FLAG_STATIC_SCHED (read per call)
+    static_map = [L.flash_attn_func(*d, return_softmax_lse=True) for d in data]
+    monkeypatch.delenv("LA_SCHED")
+    for (o, l), (os_, ls) in zip(eager, static_map):
+        assert torch.equal(o, os_) and torch.equal(l, ls)
+    buf = [torch.empty_like(x) for x in data[0]]
+    for b, x in zip(buf, data[0]):
+        b.copy_(x)
+    L.flash_attn_func(*buf)                                      # warm-up outside the capture
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        o_g, l_g = L.flash_attn_func(*buf, return_softmax_lse=True)
+    for d, (o, l) in zip(data, eager):
+        for b, x in zip(buf, d):
+            b.copy_(x)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(o_g, o) and torch.equal(l_g, l)
