@@ -48,7 +48,7 @@ def opt_val(key, default):
 # for bit. Every other option drops work or changes the arithmetic - pricing experiments (tools/asm_variants.py). The first line of a
 # generated body says which kind went in; liteattention_amd/build.py refuses the latter for the product library and records both in
 # la_build_info() for A/B builds (--out=).
-SCHEDULE_ONLY = {"x", "cap1", "cap2", "dmagaps", "dmapol", "align", "pad4", "kearly", "klate", "klate2", "expblock", "norot", "w2", "pk"}
+SCHEDULE_ONLY = {"x", "cap1", "cap2", "dmagaps", "dmapol", "align", "pad4", "pad4b", "kearly", "klate", "klate2", "expblock", "norot", "w2", "pk"}
 
 
 def option_tag():
@@ -115,6 +115,7 @@ DMA_GAPS = [int(x) for x in opt_val("dmagaps", {128: "1,2,4,6,8,10,11,13,15,17",
 assert W2 or max(DMA_GAPS) < NG          # (step_w2 places its DMA pieces itself)
 
 Q_A0, K_A0 = (32, 48) if W2 else (128, 192)     # first AGPR of the Q fragments / of the K fragments
+LOOP_PHASE = {64: 24, 96: 8, 128: 8, 192: 8, 256: 0}[D]      # bytes past a 32-byte boundary at which the loop head is placed (see main())
 
 
 # ---------------------------------------------------------------- AGPR map
@@ -1188,12 +1189,26 @@ def main():
         write_out()
         return
     loop, done = new_label("loop"), new_label("done")
-    if opt_val("align", ""):                                   # code-placement experiments: see HISTORY.md section 4.2
-        out.append(f".p2align {opt_val('align', '')}")
-    for _ in range(int(opt_val("pad4", "0"))):
-        emit("s_nop 0")
+    # Code placement (round 5). Where the loop head falls inside a 32-byte fetch window moves the body's throughput by up to 2-3 % with a
+    # period of 32 bytes (tools/debug/phase_sweep_bench.py, profiles/r05_code_placement.md: head_dim 128: 1311-1316 TFLOP/s at phase 0,
+    # 1329-1334 at phase 8; head_dim 64: 1011-1015 at 0, 1041 at 24) - and until round 5 that phase was whatever the C++ shell in front of
+    # the asm statement happened to leave: an edit to the list writer moved the headline kernel from phase 8 to phase 16 and cost 0.8 %.
+    # The head is now pinned: .p2align 5, then PHASE / 4 s_nop (executed once per item), per body the best measured phase.
+    # `align:N` / `pad4:N` override it for experiments.
+    if opt_val("align", "") or opt_val("pad4", ""):
+        if opt_val("align", ""):
+            out.append(f".p2align {opt_val('align', '')}")
+        for _ in range(int(opt_val("pad4", "0"))):
+            emit("s_nop 0")
+    else:
+        out.append(".p2align 5")
+        for _ in range(LOOP_PHASE // 4):
+            emit("s_nop 0")
     label(loop)
     for variant in (0, 1):
+        if variant == 1:
+            for _ in range(int(opt_val("pad4b", "0"))):        # code-placement experiments: the second copy of the step against the first
+                emit("s_nop 0")
         emit(f"s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}")
         emit(f"s_cbranch_scc0 {done}")
         if HALFSKIP:

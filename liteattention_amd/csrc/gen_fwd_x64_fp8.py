@@ -803,10 +803,17 @@ def epilogue():
 def main():
     prologue()
     loop, done = new_label("loop"), new_label("done")
-    if opt_val("align", ""):                                   # code-placement experiments: see HISTORY.md section 4.2
-        out.append(f".p2align {opt_val('align', '')}")
-    for _ in range(int(opt_val("pad4", "0"))):
-        emit("s_nop 0")
+    # Code placement (round 5; see gen_fwd_x64.py main()): the loop head is pinned at the best measured phase inside a 32-byte window -
+    # default form 0, exact-exp 24 (30.65 ms against 31.25 at phases 8 / 16: 2 %), exact-rowsum 8 (flat). `align:N` / `pad4:N` override.
+    if opt_val("align", "") or opt_val("pad4", ""):
+        if opt_val("align", ""):
+            out.append(f".p2align {opt_val('align', '')}")
+        for _ in range(int(opt_val("pad4", "0"))):
+            emit("s_nop 0")
+    else:
+        out.append(".p2align 5")
+        for _ in range((8 if not LMFMA else (0 if LIN else 24)) // 4):
+            emit("s_nop 0")
     label(loop)
     emit(f"s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}")
     emit(f"s_cbranch_scc0 {done}")

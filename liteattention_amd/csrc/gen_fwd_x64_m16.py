@@ -785,9 +785,14 @@ def epilogue():
 def main():
     prologue()
     loop, done = new_label("loop"), new_label("done")
-    if opt_val("align", ""):
-        out.append(f".p2align {opt_val('align', '')}")
-    for _ in range(int(opt_val("pad4", "0"))):
+    if opt_val("align", "") or opt_val("pad4", ""):           # code placement: see gen_fwd_x64.py main(); this body is pinned at phase 8 (not swept)
+        if opt_val("align", ""):
+            out.append(f".p2align {opt_val('align', '')}")
+        for _ in range(int(opt_val("pad4", "0"))):
+            emit("s_nop 0")
+    else:
+        out.append(".p2align 5")
+        emit("s_nop 0")
         emit("s_nop 0")
     label(loop)
     for variant in (0, 1):

@@ -105,6 +105,20 @@ __device__ __noinline__ void write_skip_list(const int* seq, const unsigned* end
     write_row[0] = min(w - 1, k_tiles);                                  // finalize :185-191
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave on the DPP datapath (round 5): four row_shr steps scan each 16-lane row, then
+// row_bcast:15 adds lane 15 of rows 0 / 2 to rows 1 / 3 and row_bcast:31 adds lane 31 to rows 2 and 3 - six dependent VALU
+// instructions. The __shfl_up form it replaces is six ds_bpermute round trips through the LDS crossbar (~100 cycles each, and the
+// list writer / expander are the one place where a lone wave sits on a chain of them while three waves wait).
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);      // row_shr:1, invalid lanes read 0
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3 (other rows keep `old` = 0)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // Wave-parallel form of write_skip_list (same inputs, run by all 64 lanes of ONE wave). Lane l takes position
 // base + l: with skip(p) the must-do-adjusted flag and raw(p) the raw one, the serial writer emits
 //     n(p)   if skip(p) != (p is the first position of its range ? true : skip(p-1))       (record_transition)
@@ -138,24 +152,20 @@ __device__ __forceinline__ void write_skip_list_wave(const int* seq, const unsig
             is_end = (endflags[pos >> 5] >> (pos & 31)) & 1u;
         }
         const bool skip = raw && !(n <= md_start && n > md_end);
-        // state left behind by this position: forced to "skipping" after a range end
-        const int after = (is_end || skip) ? 1 : 0;
-        int before = __shfl_up(after, 1);
-        if (lane == 0) before = carry_skip;
-        const int e1 = live && (static_cast<int>(skip) != before);
-        const int e2 = live && is_end && !raw;
-        const int cnt = e1 + e2;
-        int incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
-        int slot = w + incl - cnt;
+        // state left behind by this position: forced to "skipping" after a range end. Every quantity here is ONE BIT per lane, so the
+        // neighbour's state and the entry slots come from wave ballots and popcounts (round 5; the shuffle-scan form took ~1 100
+        // cycles per 64 positions: 12 k cycles per item at the headline's 686 positions, with the other three waves waiting)
+        const unsigned long long after_b = __ballot(live && (is_end || skip));
+        const unsigned long long below = (1ull << lane) - 1ull;                        // lanes before this one
+        const int before = lane == 0 ? carry_skip : static_cast<int>((after_b >> ((lane - 1) & 63)) & 1ull);
+        const bool e1 = live && (static_cast<int>(skip) != before);
+        const bool e2 = live && is_end && !raw;
+        const unsigned long long e1_b = __ballot(e1), e2_b = __ballot(e2);
+        int slot = w + __popcll(e1_b & below) + __popcll(e2_b & below);
         if (e1) { if (slot <= k_tiles) write_row[slot] = n; ++slot; }
         if (e2) { if (slot <= k_tiles) write_row[slot] = n; }
-        w += __shfl(incl, 63);
-        carry_skip = __shfl(after, 63);
+        w += __popcll(e1_b) + __popcll(e2_b);
+        carry_skip = static_cast<int>((after_b >> 63) & 1ull);
     }
     if (lane == 0) write_row[0] = min(w - 1, k_tiles);
 }
@@ -350,12 +360,7 @@ __device__ __forceinline__ int expand_read_list(const int* __restrict__ row, int
             cnt = max(start - end + 1, 0);
             if (r == 0) cnt = max(cnt, 1);        // the first tile of the first range is always walked (mainloop...:1614-1660)
         }
-        int incl = cnt;                                       // inclusive scan over the wave
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
+        const int incl = wave_inclusive_scan(cnt);            // inclusive scan over the wave (DPP)
         const int first = pos + incl - cnt;
         const int room = max(k_tiles - first, 0);
         cnt = min(cnt, room);
