@@ -479,6 +479,10 @@ def main():
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock sample")
     ap.add_argument("--no-head-dims", action="store_true", help="skip the head_dim 64 / 96 / 192 / 256 sub-record of the 1-GPU bf16 line")
     ap.add_argument("--no-denoise", action="store_true", help="skip the 50-step denoising run (BASELINE.json configs[2]) of the 1-GPU bf16 line")
+    ap.add_argument("--prewarm-steps", type=int, default=30,
+                    help="untimed steps of the timed configuration BEFORE the W warm-up steps (outside the contract's warm-up and timed region): the socket is at "
+                         "its power cap and the clock the first steps after start-up run at is 1-3 %% below the sustained one (round 5: the 20 steps after 3 warm-ups "
+                         "51.0 ms, the same configuration a few seconds later in the same process 50.4 ms); 0 = off")
     ap.add_argument("--overlap-windows", type=int, default=3,
                     help="N > 1: q-tile windows per step whose all-gathers overlap the next window's compute (1 = off)")
     ap.add_argument("--dtype", choices=["bf16", "fp16", "fp8"], default="bf16",
@@ -567,6 +571,8 @@ def main():
         if use_dist is not None and att.overlap_windows > 1:
             overlap_note = agree_on_overlapped_form(att, (q, k, v), dist, dev, device_sync)
         flops_rank = executed_flops(rows, Hl, B, S, S, bm, bn, D)
+        for _ in range(max(0, args.prewarm_steps)):          # the same number on every rank (the step may hold a collective)
+            att(q, k, v)
         step_s, kern_s = timed(steps, warmup)
         flops_job = flops_rank * world
         listed_frac = listed_tiles_of_rows(rows) / (q_tiles * k_tiles)
@@ -678,7 +684,7 @@ def main():
         "metric": "self-attn TFLOPS + ms/step @ seq=75k d=128 bf16, sparsity 0->77%; 1/2/4/8 GPU",
         "value": main_res["value"],
         "unit": "TFLOP/s (executed: FLOPs of listed tiles only)",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": max(0, args.prewarm_steps),
         "ms_per_step": main_res["ms_per_step"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic" if seam is None else "STAND-IN attention on the CPU over gloo (test seam): NOT a measurement",

@@ -23,7 +23,7 @@ def _clean_env(**extra):
 
 
 def _bench(args, **env_extra):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--seqlen", "1000", "--heads", "4", "--steps", "2", "--warmup", "1",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--seqlen", "1000", "--heads", "4", "--steps", "2", "--warmup", "1", "--prewarm-steps", "1",
            "--no-cpu-baseline", "--no-power"] + args
     return subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_clean_env(**env_extra), cwd=ROOT)
 
@@ -62,7 +62,7 @@ def test_the_plain_all_gather_form_and_the_external_launcher_form():
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--seqlen", "1000", "--heads", "4", "--steps", "2",
-           "--warmup", "1", "--no-cpu-baseline", "--no-power"]
+           "--warmup", "1", "--prewarm-steps", "1", "--no-cpu-baseline", "--no-power"]
     r = _line(subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_clean_env(), cwd=ROOT))
     assert r["n_gpus"] == 2 and r["config"]["launcher"].startswith("external launcher") and r["multi_gpu"]["rccl_world_size"] == 2
 
