@@ -456,12 +456,14 @@ def denoise50(L, dev, thresholds=None, sweep0_ms=None, dense_steps=(5, 15, 25, 3
             dr = sorted(all_dense_random)[len(all_dense_random) // 2]
             res["dense_vs_sweep0"].update({
                 "dense_ms_on_the_sweeps_random_tensors_inside_the_loop": round(dr, 3), "samples": len(all_dense_random),
-                "same_tensors_ratio": round(dr / sweep0_ms, 4), "within_2pct": bool(abs(dr / sweep0_ms - 1.0) <= 0.02),
+                "same_tensors_ratio": round(dr / sweep0_ms, 4), "launch_context_effect_pct": round(100.0 * (dr / sweep0_ms - 1.0), 2),
                 "structured_over_random_inside_the_loop": round(dense_all / dr, 4),
-                "how": "within_2pct compares the SAME dense launch (the sweep's random tensors) inside the denoising loop and in the sweep: the thermal-"
-                       "state check; structured_over_random is what the data does to a power-limited kernel"})
+                "how": "launch_context_effect_pct: the SAME dense launch (the sweep's random tensors) inside the denoising loop against the back-to-back sweep. "
+                       "An observation, not a pass / fail: at the power cap a launch that follows ~30 ms of memory-bound tensor generation runs -3...+3 % "
+                       "off the back-to-back time, by box and session (both signs were seen); sparse and dense are BOTH timed inside the loop, which is what "
+                       "t / t_dense needs. structured_over_random is what the data does to a power-limited kernel"})
         else:
-            res["dense_vs_sweep0"]["within_2pct"] = bool(abs(dense_all / sweep0_ms - 1.0) <= 0.02)
+            res["dense_vs_sweep0"]["launch_context_effect_pct"] = round(100.0 * (dense_all / sweep0_ms - 1.0), 2)
     return res
 
 
