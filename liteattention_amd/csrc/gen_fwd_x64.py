@@ -48,7 +48,7 @@ def opt_val(key, default):
 # for bit. Every other option drops work or changes the arithmetic - pricing experiments (tools/asm_variants.py). The first line of a
 # generated body says which kind went in; liteattention_amd/build.py refuses the latter for the product library and records both in
 # la_build_info() for A/B builds (--out=).
-SCHEDULE_ONLY = {"x", "cap1", "cap2", "dmagaps", "dmapol", "align", "pad4", "pad4b", "kearly", "klate", "klate2", "expblock", "norot", "w2", "pk"}
+SCHEDULE_ONLY = {"x", "cap1", "cap2", "dmagaps", "dmapol", "align", "pad4", "pad4b", "e64", "kearly", "klate", "klate2", "expblock", "norot", "w2", "pk"}
 
 
 def option_tag():
@@ -1234,8 +1234,15 @@ def main():
     write_out()
 
 
+E64_OPS = ("v_exp_f32", "v_add_f32", "v_mul_f32", "v_sub_f32", "v_max_f32", "v_mov_b32", "v_add_u32")
+
+
 def write_out():
     lines = finalize(out)
+    if "e64" in OPT:       # code-placement experiment: every 4-byte VOP1 / VOP2 of the body in its 8-byte VOP3 encoding (same operation, same issue cost)
+        import re
+        pat = re.compile(r"^(\s*)(" + "|".join(E64_OPS) + r")(\s+[vs]\d+(?:,\s*-?[vs]\d+)+\s*)$")      # register operands only: VOP3 takes no literals on gfx9
+        lines = [pat.sub(lambda m: m.group(1) + m.group(2) + "_e64" + m.group(3), ln) for ln in lines]
     text = "\n".join(lines)
     path = sys.argv[1] if len(sys.argv) > 1 else "la_fwd_x64_body.inc"
     with open(path, "w") as f:
