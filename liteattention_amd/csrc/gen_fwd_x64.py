@@ -48,7 +48,7 @@ def opt_val(key, default):
 # for bit. Every other option drops work or changes the arithmetic - pricing experiments (tools/asm_variants.py). The first line of a
 # generated body says which kind went in; liteattention_amd/build.py refuses the latter for the product library and records both in
 # la_build_info() for A/B builds (--out=).
-SCHEDULE_ONLY = {"x", "cap1", "cap2", "dmagaps", "dmapol", "align", "pad4", "pad4b", "e64", "kearly", "klate", "klate2", "expblock", "norot", "w2", "pk"}
+SCHEDULE_ONLY = {"x", "cap1", "cap2", "dmagaps", "dmapol", "align", "pad4", "pad4b", "e64", "wp2", "wp2b", "wc2", "kearly", "klate", "klate2", "expblock", "norot", "w2", "pk"}
 
 
 def option_tag():
@@ -583,6 +583,20 @@ def emit_gaps(pre, mf, post):
 deferred = []     # out-of-line blocks emitted after the loop: callables
 
 
+def widen_last(n, since):
+    """Code-placement experiments (profiles/r05_code_placement.md): shift everything BEHIND this point by 4 n bytes at no issue cost -
+    the last n register-operand VOP1 / VOP2 instructions emitted since index `since` of `out` take their 8-byte VOP3 encoding."""
+    import re
+    pat = re.compile(r"^(\s*)(v_exp_f32|v_add_f32|v_max_f32|v_mul_f32|v_sub_f32)(\s+[vs]\d+(?:,\s*-?[vs]\d+)+\s*)$")
+    i = len(out) - 1
+    while n > 0 and i >= since:
+        if isinstance(out[i], str) and pat.match(out[i]):
+            out[i] = pat.sub(lambda m: m.group(1) + m.group(2) + "_e64" + m.group(3), out[i])
+            n -= 1
+        i -= 1
+    assert n == 0, "not enough 4-byte instructions to widen"
+
+
 HALFSKIP = int(opt_val("halfskip", "0"))     # PRICING ONLY: every wave sits out one step in HALFSKIP (no MFMA, no softmax, no fragment reads)
 
 
@@ -627,7 +641,9 @@ def _step(variant):
             post[NG // 2 + f * (NG // 2) // 8] += v_read(f, vbuf_cur, ord2[f])
     vq = softmax_stream(cur, list(range(XPAIRS, 16)))
     distribute(vq, post, 0, CAP1)
+    mark = len(out)
     emit_gaps(pre, mf, post)
+    widen_last(int(opt_val("wp2", "0")) if variant == 0 else int(opt_val("wp2b", opt_val("wp2", "0"))), mark)      # shift phase 2 (copy 0 / copy 1 of the step)
 
     # ---- phase 2: PV(i) || K(i+2) fragments -> AGPRs, rest of the V^T fragments, next step's DMA bases,
     #               stats(i+1), first part of softmax(i+1)
@@ -687,7 +703,10 @@ def _step(variant):
     # the first two gaps may only hold ops that do not read S_nxt (MFMA -> VALU read hazard): the SALU / seq part
     distribute(vq[:n_head], post, 0, CAP2 if CAP2 > 0 else 6)
     distribute(vq[n_head:], post, 2, CAP2)
+    mark = len(out)
     emit_gaps(pre, mf, post)
+    if variant == 0:
+        widen_last(int(opt_val("wc2", "0")), mark)                 # shift the second copy of the step against the first
 
     # ---- tail: the rare O rescale, drain, barrier
     resc, resc_back = new_label("resc"), new_label("resc_back")
