@@ -286,13 +286,16 @@ def walk_tiles(row: Sequence[int]) -> List[int]:
     L = int(row[0])
     out: List[int] = []
     idx = 1
-    start, end = int(row[1]), int(row[2])
+
+    def at(i):          # an entry behind the row reads as 0 (qkskip_oracle.c reader_load: a one-tile row [len, start] has no room for its end)
+        return int(row[i]) if i < len(row) else 0
+    start, end = at(1), at(2)
     while True:
         out.extend(range(start, end - 1, -1))
         idx += 2
         if not idx <= L:
             break
-        start, end = int(row[idx]), int(row[idx + 1])
+        start, end = at(idx), at(idx + 1)
     return out
 
 
