@@ -294,6 +294,48 @@ def mfma_pv(sset, slot, m, qb):
 # |LSE - exact| <= 2^-9 for bf16, 2^-12 for fp16, on a row of one dominant key; 2^-9 / sqrt(n) on n comparable keys). The reference
 # sums the un-rounded fp32 P (softmax.h:275-296): this form is LA_FLAG_FAST_ROWSUM, never the default of the head_dim-128 body.
 DOTSUM = "dotsum" in OPT
+# `stamps` (tools/debug/body_stage_profile.py; results are WRONG by construction): wave 0 reads the shader clock at six points of an item -
+# body start, Q loads issued, Q in registers, loop entry, loop exit, body end - and lanes 0..4 overwrite the first five LSE values of the
+# item's q-tile with the five differences (as floats): what the body's fixed part is made of, per item, without a byte of C++ changed.
+STAMPS = "stamps" in OPT
+STAMP_REGS = [65, 66, 67, 81, 83, 86]           # S_FREE0..5; the clock lands in s[50:51] (S_T64B, unused by this body)
+
+
+def stamp(k):
+    if STAMPS:
+        emit(f"s_memtime {sr(S_T64B)}")
+        emit("s_waitcnt lgkmcnt(0)")
+        emit(f"s_mov_b32 {s(STAMP_REGS[k])}, {s(S_T64B)}")
+
+
+def stamps_out():
+    if not STAMPS:
+        return
+    skip = new_label("nostamps")
+    emit(f"s_cmp_eq_u32 {s(S_WAVE)}, 0")
+    emit(f"s_cbranch_scc0 {skip}")
+    emit(f"s_cmp_eq_u64 {sr(S_VB)}, 0")                     # the epilogue's LSE base (gen_epilogue.py S_LSEB): no LSE asked for
+    emit(f"s_cbranch_scc1 {skip}")
+    for i in range(5):
+        emit(f"s_sub_u32 {s(STAMP_REGS[i])}, {s(STAMP_REGS[i + 1])}, {s(STAMP_REGS[i])}")
+    emit("s_waitcnt vmcnt(0)")                               # the item's own LSE stores have left
+    emit(f"v_mbcnt_lo_u32_b32 {v(T[7])}, -1, 0")
+    emit(f"v_mbcnt_hi_u32_b32 {v(T[7])}, -1, {v(T[7])}")
+    emit(f"v_mov_b32 {v(T[0])}, {s(STAMP_REGS[0])}")
+    for i in range(1, 5):
+        emit(f"v_mov_b32 {v(T[1])}, {s(STAMP_REGS[i])}")
+        emit(f"v_cmp_eq_u32 vcc, {i}, {v(T[7])}")
+        emit(f"v_cndmask_b32 {v(T[0])}, {v(T[0])}, {v(T[1])}, vcc")
+    emit(f"v_cvt_f32_u32 {v(T[0])}, {v(T[0])}")
+    emit(f"v_add_u32 {v(T[2])}, {s(S_QROW0)}, {v(T[7])}")
+    emit(f"v_lshlrev_b32 {v(T[2])}, 2, {v(T[2])}")
+    emit(f"v_add_co_u32 {v(T[4])}, vcc, {s(S_VB)}, {v(T[2])}")
+    emit(f"v_mov_b32 {v(T[5])}, {s(S_VB + 1)}")
+    emit(f"v_addc_co_u32 {v(T[5])}, vcc, 0, {v(T[5])}, vcc")
+    emit("s_mov_b64 exec, 0x1f")
+    emit(f"global_store_dword {vr(T[4], 2)}, {v(T[0])}, off")
+    emit("s_mov_b64 exec, -1")
+    label(skip)
 DOT_OP = {"bf16": "v_dot2c_f32_bf16", "f16": "v_dot2c_f32_f16"}[DTYPE]
 ONES_BITS = {"bf16": "0x3f803f80", "f16": "0x3c003c00"}[DTYPE]
 PK = "pk" in OPT           # packed-fp32 VALU (v_pk_fma_f32 / v_pk_add_f32). MEASURED ANTI-LEVER beside MFMAs: -64 issue slots
@@ -935,6 +977,7 @@ def step_w2(p, group):
 
 
 def prologue():
+    stamp(0)
     emit("; ---- lane id, parameter block -> SGPRs")
     emit(f"v_mbcnt_lo_u32_b32 {v(LANE)}, -1, 0")
     emit(f"v_mbcnt_hi_u32_b32 {v(LANE)}, -1, {v(LANE)}")
@@ -1072,7 +1115,9 @@ def prologue():
         emit(f"v_addc_co_u32 {v(T[5])}, vcc, {v(T[5])}, {v(T[7])}, vcc")
         for ks in range(KS):
             emit(f"global_load_dwordx4 {vr(4 * KS * qb + 4 * ks, 4)}, {vr(T[4], 2)}, off offset:{32 * ks}")
+    stamp(1)
     emit("s_waitcnt vmcnt(0)")
+    stamp(2)
     for qb in range(NQB):
         emit(f"v_cmp_gt_i32 vcc, {s(S_SEQLENQ)}, {v(QROW[qb])}")
         for r in range(4 * KS):
@@ -1223,6 +1268,7 @@ def main():
         out.append(".p2align 5")
         for _ in range(LOOP_PHASE // 4):
             emit("s_nop 0")
+    stamp(3)
     label(loop)
     for variant in (0, 1):
         if variant == 1:
@@ -1249,7 +1295,10 @@ def main():
     for blk in deferred:
         blk()
     label(done)
+    stamp(4)
     epilogue()
+    stamp(5)
+    stamps_out()
     write_out()
 
 
