@@ -48,7 +48,7 @@ def opt_val(key, default):
 # for bit. Every other option drops work or changes the arithmetic - pricing experiments (tools/asm_variants.py). The first line of a
 # generated body says which kind went in; liteattention_amd/build.py refuses the latter for the product library and records both in
 # la_build_info() for A/B builds (--out=).
-SCHEDULE_ONLY = {"x", "cap1", "cap2", "dmagaps", "dmapol", "align", "pad4", "pad4b", "e64", "wp2", "wp2b", "wc2", "kearly", "klate", "klate2", "expblock", "norot", "w2", "pk"}
+SCHEDULE_ONLY = {"snake", "x", "cap1", "cap2", "dmagaps", "dmapol", "align", "pad4", "pad4b", "e64", "wp2", "wp2b", "wc2", "kearly", "klate", "klate2", "expblock", "norot", "w2", "pk"}
 
 
 def option_tag():
@@ -108,6 +108,18 @@ PW = (64 // NW) * ROW // 1024             # 1-KiB DMA pieces per wave per tile (
 K_EARLY = NQB == 1 and (D == 256 or "kearly" in OPT) and "klate2" not in OPT
 XPAIRS = int(opt_val("x", {64: "4", 256: "6"}.get(D, "5")))   # pair-groups (of 16; one group = the same pair of both q-blocks) done in phase 2 (head_dim 64: 4 since round 4,
                                                       # +1.8-2.2 % over round 3's 8 on two boxes; 1 / 2 / 3 / 6 / 10 / 12 lose to it; head_dim 256: 6, +1 % over 5; 96 / 192: 5 stays)
+# `snake` (A/B): the q-block order of a fragment's two MFMAs flips with the fragment's parity, so that every MFMA shares an operand register
+# with its predecessor inside a group - (K0,Q0) (K0,Q1) (K1,Q1) (K1,Q0) instead of (K0,Q0) (K0,Q1) (K1,Q0) (K1,Q1). The matrix pipe
+# ALONE gains 0.9 % from it on N(0,1) data (tools/debug/mfma_order_bench.py: operand toggling is what an MFMA's energy depends on).
+SNAKE = "snake" in OPT
+
+
+def qb_of(t):
+    """q-block of the MFMA at position t of a phase (NQB MFMAs per fragment, fragment t // NQB)"""
+    pos, f = t % NQB, t // NQB
+    return pos ^ (f & 1) if SNAKE and NQB == 2 else pos
+
+
 CAP1 = int(opt_val("cap1", "0"))          # fillers per MFMA gap the distributor may place (0 = balance evenly)
 CAP2 = int(opt_val("cap2", "0"))
 DMA_GAPS = [int(x) for x in opt_val("dmagaps", {128: "1,2,4,6,8,10,11,13,15,17", 96: "0,1,3,4,6,7,8,9,11,12", 64: "1,2,4,8,9,11"}[D] if DL <= 128 else
@@ -671,7 +683,7 @@ def _step(variant):
     post = [[] for _ in range(NG)]
     mf = []
     for t in range(NG):
-        mf.append(mfma_qk(nxt, ord1[t // NQB], t % NQB) if "nomfma1" not in OPT else "    s_nop 0")
+        mf.append(mfma_qk(nxt, ord1[t // NQB], qb_of(t)) if "nomfma1" not in OPT else "    s_nop 0")
     for g, op in zip(DMA_GAPS, dma_ops(kbuf_stage, vbuf_stage, st=variant)):
         post[g].append(op)
     if K_EARLY and "nokread" not in OPT:
@@ -696,7 +708,7 @@ def _step(variant):
         f, qb = t // NQB, t % NQB
         if qb == 0 and "novread" not in OPT and "nowaitv" not in OPT:
             pre[t].append(("WAIT", ("v", ord2[f], 1)))
-        mf.append(mfma_pv(cur, f % 8, ord2[f], qb) if "nomfma2" not in OPT else "    s_nop 0")
+        mf.append(mfma_pv(cur, f % 8, ord2[f], qb_of(t)) if "nomfma2" not in OPT else "    s_nop 0")
         if qb == NQB - 1 and f + 8 < NVF and "novread" not in OPT:
             post[t] += v_read(f % 8, vbuf_cur, ord2[f + 8])
         if "nokread" not in OPT and not K_EARLY and (t < NKF if "klate" not in OPT else (t & 1) == 0):
@@ -1160,7 +1172,7 @@ def prologue():
     emit(f"v_readfirstlane_b32 {s(TBS[0] + 1)}, {v(T[9])}")
     ord1 = [(f & 1) * KS + (f >> 1) for f in range(NKF)]
     for t in range(NG):
-        out.append(mfma_qk(0, ord1[t // NQB], t % NQB))
+        out.append(mfma_qk(0, ord1[t // NQB], qb_of(t)))
     for j in range(NKF):
         emit(k_read(KV_TILE, j))
     emit(("DRAIN",))
