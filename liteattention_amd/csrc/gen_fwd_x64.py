@@ -304,7 +304,7 @@ def mfma_pv(sset, slot, m, qb):
 # pair of scores behind the pack instead of two v_add_f32 in front of it - 32 of the step's VALU instructions fewer. l is then the sum
 # of exactly the weights the PV MFMA uses (O = sum P~ V / sum P~ is self-normalised); the LSE carries the rounding of P~ (RNE: unbiased,
 # |LSE - exact| <= 2^-9 for bf16, 2^-12 for fp16, on a row of one dominant key; 2^-9 / sqrt(n) on n comparable keys). The reference
-# sums the un-rounded fp32 P (softmax.h:275-296): this form is LA_FLAG_FAST_ROWSUM, never the default of the head_dim-128 body.
+# sums the un-rounded fp32 P (softmax.h:275-296): this form changes the LSE's rounding, so it is a pricing option of the generator (`dotsum`, recorded as wrong_results=1), never a product body and not a flag of the C-ABI.
 DOTSUM = "dotsum" in OPT
 # `stamps` (tools/debug/body_stage_profile.py; results are WRONG by construction): wave 0 reads the shader clock at six points of an item -
 # body start, Q loads issued, Q in registers, loop entry, loop exit, body end - and lanes 0..4 overwrite the first five LSE values of the

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box, one session: same-box prices of the bf16 energy levers of VERDICT r3 item 2 (variants built by tools/asm_variants.py):
-#   x_dotsum   row sums of the rounded P by v_dot2c (32 VALU instructions fewer per step; LA_FLAG_FAST_ROWSUM candidate)
+#   x_dotsum   row sums of the rounded P by v_dot2c (32 VALU instructions fewer per step; a candidate for a caller-selected fast form; not built)
 #   x_mfmasum  row sums from the matrix pipe (64 v_add_f32 fewer, 8 MFMAs more per step; pricing stand-in, wrong results)
 #   x_hs8/4    every wave sits out one step in 8 / 4 (per-128-row-half lists walked as their union; pricing stand-in, wrong results)
 # and the same dot-product row sums on the issue-bound head dims 64 / 96. Output: gpurun_out/<tag>/levers.txt
