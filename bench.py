@@ -46,7 +46,7 @@ SPARSITIES = (0.0, 0.21, 0.42, 0.57, 0.77)
 HEADLINE_SPARSITY = 0.42
 
 
-from liteattention_amd.selfcheck import (banded_rows, executed_flops, impose_lists,  # noqa: E402,F401  (re-exported:
+from tools.selfcheck import (banded_rows, executed_flops, impose_lists,  # noqa: E402,F401  (re-exported:
                                          listed_tiles_of_rows, sampled_row_check)          # tools/ and tests import them from here)
 
 
@@ -293,7 +293,7 @@ def other_head_dims(L, dev, dims=(64, 96, 192, 256), S=16384, H=40):
     """The reference's other default head sizes (hopper/setup.py:57-61), dense bf16 at S=16384 H=40: useful TFLOP/s by HIP events on
     the launch stream (steady state: `steady_state_ms`), and a sampled-row check of the timed output against fp32 torch."""
     import torch
-    from liteattention_amd.selfcheck import sampled_row_check
+    from tools.selfcheck import sampled_row_check
     out = {"what": f"dense bf16 B=1 S={S} H={H}; per head dim ~150 ms of warm-up launches, then >= 300 ms of timed launches, median", "runs": []}
     g = torch.Generator(device=dev).manual_seed(2)
     for D in dims:
@@ -357,7 +357,7 @@ def denoise50(L, dev, thresholds=None, sweep0_ms=None, dense_steps=(5, 15, 25, 3
     `headline_launch`: the HEADLINE launch itself - the imposed 42 % list on the sweep's random tensors - is timed
     in the same context, one launch per sampled step, and reported as `headline_in_loop` beside the back-to-back `headline_ms`: the
     top-level `ms_per_step` is the cool number, this is the same work inside a pipeline-like loop."""
-    from liteattention_amd.selfcheck import DENOISE_THRESHOLDS, REFERENCE_T_OVER_T0, DenoiseWorkload, lists_to_bitmap, vote_writer_check
+    from tools.selfcheck import DENOISE_THRESHOLDS, REFERENCE_T_OVER_T0, DenoiseWorkload, lists_to_bitmap, vote_writer_check
     thresholds = DENOISE_THRESHOLDS if thresholds is None else thresholds
     wl = DenoiseWorkload(40, dev)
     ev = lambda: torch.cuda.Event(enable_timing=True)                                           # noqa: E731
@@ -437,7 +437,7 @@ def denoise50(L, dev, thresholds=None, sweep0_ms=None, dense_steps=(5, 15, 25, 3
         del att, out, d, ref
     dense_all = sorted(all_dense)[len(all_dense) // 2]
     res = {"what": "50 synthetic denoising steps, B=1 S=75600 H=40 D=128 bf16, real skip lists at fixed thresholds "
-                   "(liteattention_amd.selfcheck.DenoiseWorkload, generator 'anchored'; thresholds bisected for 21 / 42 / 57 / 77 % +- 1 % at "
+                   "(tools.selfcheck.DenoiseWorkload, generator 'anchored'; thresholds bisected for 21 / 42 / 57 / 77 % +- 1 % at "
                    "step 49: profiles/r04_denoise50_calibration.json)",
            "dense_ms_per_step": round(dense_all, 3),
            "dense_how": f"median of {len(all_dense)} warmed dense launches interleaved with the sparse runs (steps {list(dense_steps)} of each "
@@ -481,10 +481,11 @@ def main():
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock sample")
     ap.add_argument("--no-head-dims", action="store_true", help="skip the head_dim 64 / 96 / 192 / 256 sub-record of the 1-GPU bf16 line")
     ap.add_argument("--no-denoise", action="store_true", help="skip the 50-step denoising run (BASELINE.json configs[2]) of the 1-GPU bf16 line")
-    ap.add_argument("--prewarm-steps", type=int, default=30,
+    ap.add_argument("--prewarm-steps", type=int, default=0,
                     help="untimed steps of the timed configuration BEFORE the W warm-up steps (outside the contract's warm-up and timed region): the socket is at "
                          "its power cap and the clock the first steps after start-up run at is 1-3 %% below the sustained one (round 5: the 20 steps after 3 warm-ups "
-                         "51.0 ms, the same configuration a few seconds later in the same process 50.4 ms); 0 = off")
+                         "51.0 ms, the same configuration a few seconds later in the same process 50.4 ms); 0 = off (the default since round 6: the contract's --warmup W alone "
+                         "governs the state that is timed)")
     ap.add_argument("--overlap-windows", type=int, default=3,
                     help="N > 1: q-tile windows per step whose all-gathers overlap the next window's compute (1 = off)")
     ap.add_argument("--dtype", choices=["bf16", "fp16", "fp8"], default="bf16",

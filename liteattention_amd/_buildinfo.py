@@ -13,7 +13,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 PUBLIC_HEADER = os.path.join(os.path.dirname(PKG_DIR), "include", "lite_attention_amd.h")
 SOURCES = ["la_fwd_kernel_v2.hip", "la_fwd_kernel_x64.hip", "la_prep_fp8.hip", "la_fwd_kernel_x64_fp8.hip", "la_aux_kernels.hip",
            "la_api.hip"]
-HEADERS = ["la_kernel_params.h", "la_tiles.h", "la_fwd_common.h", "gen_fwd_x64.py", "gen_fwd_x64_m16.py", "gen_fwd_x64_fp8.py", "gen_epilogue.py"]
+HEADERS = ["la_kernel_params.h", "la_tiles.h", "la_fwd_common.h", "gen_fwd_x64.py", "gen_fwd_x64_fp8.py", "gen_epilogue.py"]
 
 
 def source_hash() -> Optional[str]:

@@ -207,7 +207,12 @@ def _blockmask_to_lists_host(blockmask: torch.Tensor, k_tiles_valid: Optional[to
     tile = torch.arange(kt - 1, -1, -1, device=m.device)                       # position j of the descending walk <-> tile kt-1-j
     m = m.flip(-1)
     if k_tiles_valid is not None:
-        m = m & (tile < k_tiles_valid.to(m.device)[..., None, None])
+        # PER BATCH (as on the device path): [B] lines up with the mask's FIRST axis whatever its rank - [B, q, k] or [B, H, q, k]; a 2-D
+        # (shared) mask is expanded to one copy per batch entry
+        kv = torch.as_tensor(k_tiles_valid).to(m.device).reshape(-1)
+        if m.dim() == 2:
+            m = m[None].expand(kv.numel(), -1, -1)
+        m = m & (tile < kv.reshape([kv.numel()] + [1] * (m.dim() - 1)))
     if validate and not bool(m.any(-1).all()):
         raise ValueError("a q-tile keeps no k-tile: not representable as a skip list")
     prev = torch.nn.functional.pad(m[..., :-1], (1, 0))

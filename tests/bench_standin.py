@@ -9,7 +9,7 @@ import os
 
 import torch
 
-from liteattention_amd.selfcheck import lists_to_bitmap
+from tools.selfcheck import lists_to_bitmap
 
 
 class StandIn:

@@ -131,3 +131,32 @@ def test_op_has_a_meta_kernel_for_fake_tensor_tracing():
     cu = torch.empty(4, dtype=torch.int32, device="meta")
     o, l, _, _ = torch.ops.lite_attention.fwd(qp, qp, qp, None, None, None, None, cu, cu, None, None, None, 120, 120)
     assert o.shape == (300, 4, 128) and l.shape == (4, 300)
+
+
+@pytest.mark.parametrize("B,H", [(3, 3), (2, 5), (4, 1)])
+@pytest.mark.parametrize("rank", [2, 3, 4])
+def test_host_blockmask_k_tiles_valid_is_per_batch(B, H, rank):
+    """on the host path a 4-D mask [B, H, q, k] used to line `k_tiles_valid` [B] up with the HEADS axis (wrong lists when
+    B == H, a broadcast error otherwise). Row-by-row reference: the rows of `blockmask_to_rows` on the mask with the columns beyond
+    batch b's valid count cleared."""
+    from liteattention_amd.compat import blockmask_to_lists
+    g = torch.Generator().manual_seed(5 + 10 * B + H)
+    qt, kt = 4, 9
+    shape = {2: (qt, kt), 3: (B, qt, kt), 4: (B, H, qt, kt)}[rank]
+    mask = torch.rand(shape, generator=g) < 0.5
+    mask[..., 0] = True                                            # every row keeps tile 0: valid under every k_tiles_valid >= 1
+    kv = torch.randint(1, kt + 1, (B,), generator=g)
+    got = blockmask_to_lists(mask, k_tiles_valid=kv)
+    full = mask.expand(B, qt, kt) if rank == 2 else mask
+    assert got.shape[0] == B and got.shape[-2:] == (qt, kt + 1)
+    for b in range(B):
+        for h in range(H if rank == 4 else 1):
+            m2 = (full[b, h] if rank == 4 else full[b]).clone()
+            m2[:, int(kv[b]):] = False
+            want = blockmask_to_rows(m2)
+            rows = got[b, h] if rank == 4 else got[b]
+            for r, w in zip(rows.tolist(), want):
+                assert r[: len(w)] == w and not any(r[len(w):]), (b, h, r, w)
+    if rank >= 3:
+        with pytest.raises(ValueError):
+            blockmask_to_lists(mask, k_tiles_valid=torch.ones(B + 1, dtype=torch.int64))

@@ -2,7 +2,7 @@
 ``LiteAttention.__call__`` at the two thresholds of the committed runs (thr -4.22 -> ~44 %, -2.46 -> ~78 % last-step sparsity) —
 checked against references at the size they run at (VERDICT r2 "what's weak" 1b; the mid-size oracle counterpart is
 tests/test_gpu_fragmented.py). At this size the CPU oracle cannot finish, so the checkers are fp32 torch restatements on the
-device (liteattention_amd/selfcheck.py), each citing the reference lines it follows:
+device (tools/selfcheck.py), each citing the reference lines it follows:
 
   * step-49 output: 256 sampled rows x 3 heads vs fp32 attention over exactly the keys the row's q-tile READ list names
         bf16 |O - ref| <= 2^-7 max|ref| + 1e-4 (one bf16 ulp at the maximum: these rows are peaked — a few keys carry 5-10 % of
@@ -28,7 +28,7 @@ F8 = torch.float8_e4m3fn
 def run49(request):
     """50 steps; keeps what step 49 read, wrote and returned."""
     import liteattention_amd as L
-    from liteattention_amd.selfcheck import DenoiseWorkload
+    from tools.selfcheck import DenoiseWorkload
     thr = request.param
     wl = DenoiseWorkload(H, torch.device("cuda", 0))
     att = L.LiteAttention(threshold=thr, max_batch_size=1)
@@ -55,7 +55,7 @@ def _items(qt, n=24, seed=3):
 
 def test_step49_bf16(run49):
     import liteattention_amd as L
-    from liteattention_amd import selfcheck as sc
+    from tools import selfcheck as sc
     from liteattention_amd.flash_attn_interface import mha_fwd
     r = run49
     bm, bn = L.get_tile_sizes(D, 2)
@@ -92,7 +92,7 @@ def test_step49_bf16(run49):
 def test_step49_fp8_on_the_same_lists(run49):
     """The fp8 kernel walks the SAME fragmented read lists (same 256 x 64 tile geometry) on the e4m3 cast of step 49's tensors."""
     import liteattention_amd as L
-    from liteattention_amd import selfcheck as sc
+    from tools import selfcheck as sc
     from liteattention_amd.flash_attn_interface import mha_fwd
     r = run49
     assert L.get_tile_sizes(D, 1) == L.get_tile_sizes(D, 2)

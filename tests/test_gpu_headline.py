@@ -41,7 +41,7 @@ def test_headline_shape(qkv, dtype, sparsity, monkeypatch):
     if dtype == "fp8-exact-exp":                                          # LA_FLAG_EXACT_EXP: v_exp_f32 + hardware e4m3 rounding of P
         monkeypatch.setenv("LA_FP8_EXP", "exact")
         dtype = "fp8"
-    from liteattention_amd import selfcheck as sc
+    from tools import selfcheck as sc
     from liteattention_amd.flash_attn_interface import mha_fwd
     fp8 = dtype == "fp8"
     q, k, v = [x.to(F8) for x in qkv] if fp8 else qkv

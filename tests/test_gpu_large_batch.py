@@ -13,7 +13,7 @@ S, H, D, B = 75600, 40, 128, 6
 @pytest.mark.parametrize("dtype", ["bf16", "fp8"])
 def test_batch_of_six_at_the_headline_shape(dtype):
     import liteattention_amd as L
-    from liteattention_amd import selfcheck as sc
+    from tools import selfcheck as sc
     fp8 = dtype == "fp8"
     g = torch.Generator(device="cuda").manual_seed(7)
     q, k, v = [torch.randn(B, S, H, D, device="cuda", generator=g, dtype=torch.bfloat16) for _ in range(3)]

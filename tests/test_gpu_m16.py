@@ -1,5 +1,5 @@
 """GPU: the head_dim-128 path on the OTHER matrix shape of gfx950 - v_mfma_f32_16x16x32 (liteattention_amd/csrc/gen_fwd_x64_m16.py,
-round 5, A/B library build_variants/m16.so built by __graft_entry__.build()). Not the product default (profiles/r05_m16.md: at parity,
+round 5, A/B library build_variants/m16.so built on request: python -m liteattention_amd.build --m16). Not the product default (profiles/r05_m16.md: at parity,
 +0.6 / -0.8 / -1.6 %), but a second, independently derived implementation of the same path - another register map, another cross-lane
 scheme, another V image in LDS - that must pass the SAME parity tests against the same oracle: dense goldens, ragged grids, multi-step
 lists bit-exact, fragmented lists, the headline-shape checks, fp16. One library per process, hence the subprocess.
@@ -24,7 +24,7 @@ def _run(args, timeout=900):
 @pytest.fixture(scope="module", autouse=True)
 def _library():
     if not os.path.exists(M16):     # an A/B library, not the product: its absence must not stop a `pytest -x` run of the product's tests
-        pytest.skip("build_variants/m16.so is missing: __graft_entry__.build() builds it (python -m liteattention_amd.build -DLA_X64_M16=1 --out=build_variants/m16.so)")
+        pytest.skip("build_variants/m16.so is missing: python -m liteattention_amd.build --m16")
     code = ("import os, ctypes, torch; lib = ctypes.CDLL(%r); lib.la_build_info.restype = ctypes.c_char_p; print(lib.la_build_info().decode())" % M16)
     info = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300).stdout
     assert "variant=1" in info and "wrong_results=0" in info and "m16" in info, info

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """BASELINE.json configs[2]: bisect the constant thresholds at which the list the LAST of 50 denoising steps reads has
-21 / 42 / 57 / 77 % (+- 1 %) sparsity, on ALL 40 heads of liteattention_amd.selfcheck.DenoiseWorkload with the kernel's own tile
+21 / 42 / 57 / 77 % (+- 1 %) sparsity, on ALL 40 heads of tools.selfcheck.DenoiseWorkload with the kernel's own tile
 ("bisection on thr in [-20, 0) (constant over steps) so that the step-49 read-list sparsity hits the target +- 1 %;
 report thr found, per-step sparsity trace and mean sparsity"). Round 1 bisected on 4 heads and extrapolated: three of the four
 targets were missed by 2-4 points. Also runs the generator SURVEY.md pins (generator="survey") at the same
@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import liteattention_amd as L                                                   # noqa: E402
 from liteattention_amd.calibration import calibrate_threshold, run_steps       # noqa: E402
-from liteattention_amd.selfcheck import DENOISE_THRESHOLDS, DenoiseWorkload    # noqa: E402
+from tools.selfcheck import DENOISE_THRESHOLDS, DenoiseWorkload    # noqa: E402
 
 out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "denoise50_calibration.json")
 dev = torch.device("cuda", 0)

@@ -6,7 +6,7 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import liteattention_amd as L
-from liteattention_amd import selfcheck as sc
+from tools import selfcheck as sc
 S, H, D = 75600, 40, 128
 F8 = torch.float8_e4m3fn
 thr = float(sys.argv[1]) if len(sys.argv) > 1 else -4.22

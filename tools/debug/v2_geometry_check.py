@@ -1,7 +1,7 @@
 import sys, torch
 sys.path.insert(0, "/root/repo")
 import liteattention_amd as L
-from liteattention_amd.selfcheck import DenoiseWorkload
+from tools.selfcheck import DenoiseWorkload
 wl = DenoiseWorkload(4, torch.device("cuda", 0))
 print("tiles", L.get_tile_sizes(128, 2))
 for thr in (-4.22, -2.46):

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import liteattention_amd as L
 from liteattention_amd import _cabi
-from liteattention_amd.selfcheck import DenoiseWorkload
+from tools.selfcheck import DenoiseWorkload
 lib = _cabi.load()
 lib.la_debug_phase_cycles.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 names = ["-", "ticket", "zero flags + expand list", "table + params + first DMA", "asm body (prologue + tiles + epilogue)", "-", "write list + barrier"]

@@ -2,7 +2,7 @@
 256 query rows x 64 keys, the reference's Hopper kernel over 128 x 176, the hipcc-scheduled A/B kernel over 128 x 64.)
 
 A torch restatement of the skip vote and the list evolution at an arbitrary (M, N) on the 50-step workload of BASELINE.json configs[2]
-(liteattention_amd.selfcheck.DenoiseWorkload, S = 75 600, a few heads): per step and head the full score matrix in q-tile slabs, per
+(tools.selfcheck.DenoiseWorkload, S = 75 600, a few heads): per step and head the full score matrix in q-tile slabs, per
 (row, k-tile) maxima, the running maximum over the LISTED tiles in descending order, flag = AND over the M rows of
 (m_loc - m_prev) c <= thr (softmax.h:190-194), next list = listed and (not flagged, or first flagged tile behind a kept one)
 (contiguous listed tiles are treated as one range, tile Kt - 1 is never dropped). No outputs are computed.
@@ -14,7 +14,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from liteattention_amd.selfcheck import DenoiseWorkload  # noqa: E402
+from tools.selfcheck import DenoiseWorkload  # noqa: E402
 
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 50

@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import liteattention_amd as L
-from liteattention_amd import selfcheck as sc
+from tools import selfcheck as sc
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--imposed", type=float, default=None)
