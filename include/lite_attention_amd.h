@@ -65,6 +65,16 @@ typedef enum la_status {
                                   * hand-scheduled kernel: bf16 / fp16 head_dim 128 (the skip lists then use 128-row q-tiles instead of
                                   * 256-row ones: take the tile sizes from la_get_tile_sizes_ex() with the same flags) and head_dim 256
                                   * (same tiles). head_dim 96 / 192 have no such instantiation: LA_ERR_HEAD_DIM. fp8: LA_ERR_UNSUPPORTED. */
+#define LA_FLAG_HALF_VOTE 64u    /* bf16 / fp16 head_dim 128 (no effect elsewhere; LA_FLAG_KERNEL_128ROW wins when both are set): the hand-scheduled
+                                  * kernel keeps its skip lists per 128-ROW HALF of its 256-row workgroup - the reference's own q-granularity for
+                                  * this head dim (kBlockM = 128, tile_size.h:35-39). la_get_tile_sizes_ex() reports (128, 64) with it. The
+                                  * workgroup walks the UNION of its two halves' lists (never longer than the 256-row list of the same votes), and
+                                  * the waves of a half sit out the tiles only the other half lists. Every half's output, LSE and write list are
+                                  * exactly those of an independent 128-row q-tile walking its own list. At a given THRESHOLD a 128-row vote drops
+                                  * more tiles than a 256-row one (13.7 % / 25 % fewer listed tiles at thr -4.22 / -2.46 on the 50-step workload).
+                                  * q-tile windows: q_tile_begin even, q_tile_count even unless the window reaches the last q-tile. Lists are read
+                                  * as SETS of tiles (identical to the literal walk for every well-formed list; a list with overlapping or
+                                  * ascending ranges walks each named tile once). */
 #define LA_FLAG_EXACT_RESCALE 8u /* A/B: the hand-scheduled kernels rescale O on EVERY growth of a row maximum (tau = 0) instead of lazily
                                   * (bf16: only after it grew by more than 2^8; results agree to rounding, lists are identical) */
 #define LA_FLAG_EXACT_ROWSUM 16u /* fp8: row sums l = sum of the UN-rounded fp32 P on the vector unit (the reference's form, softmax.h:275-296:
@@ -197,7 +207,7 @@ typedef struct la_fwd_args {
 /* Tile sizes (kBlockM, kBlockN) of the kernel that la_fwd will run for (head_dim, element size).
  * Skip-list geometry depends on them, so host code must take them from here. */
 int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n);
-/* The same for a launch that sets `flags` (only LA_FLAG_KERNEL_128ROW changes the answer). */
+/* The same for a launch that sets `flags` (LA_FLAG_KERNEL_128ROW and LA_FLAG_HALF_VOTE change the answer). */
 int la_get_tile_sizes_ex(int head_dim, int element_size, uint32_t flags, int* block_m, int* block_n);
 
 /* Bytes of `workspace` la_fwd wants for these arguments (fp8: required; bf16 / fp16: optional, see la_fwd_args;

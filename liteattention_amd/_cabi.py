@@ -63,17 +63,22 @@ LA_FLAG_KERNEL_128ROW = 4
 LA_FLAG_EXACT_RESCALE = 8
 LA_FLAG_EXACT_ROWSUM = 16
 LA_FLAG_EXACT_EXP = 32
+LA_FLAG_HALF_VOTE = 64
+GEOMETRY_FLAGS = LA_FLAG_KERNEL_128ROW | LA_FLAG_HALF_VOTE      # the flags that change the q-tile of the skip lists (la_get_tile_sizes_ex)
 
 
 def default_flags() -> int:
     """A/B switches of the HOST layer (the C library reads no environment): they only choose the default ``la_fwd_args.flags``.
-    LA_FWD_KERNEL=v2 -> the 128-row bf16 head_dim-128 kernel (lists then use 128-row q-tiles); LA_SCHED=static -> one
+    LA_FWD_KERNEL=v2 -> the 128-row bf16 head_dim-128 kernel (lists then use 128-row q-tiles); LA_VOTE=half -> LA_FLAG_HALF_VOTE (the
+    hand-scheduled head_dim-128 kernel with lists per 128-row half); LA_SCHED=static -> one
     workgroup per item instead of the ticket queues; LA_RESCALE_TAU=0 -> O rescaled on every growth of a row maximum; LA_FP8_ROWSUM=exact -> fp8 row sums of the un-rounded
     P on the vector unit (LA_FLAG_EXACT_ROWSUM: fp32-exact LSE); LA_FP8_EXP=exact -> fp8 P by v_exp_f32 + the hardware e4m3 rounding instead of
     the log-linear byte encoding (LA_FLAG_EXACT_EXP; implied by LA_FP8_ROWSUM=exact)."""
     f = 0
     if os.environ.get("LA_FWD_KERNEL", "").startswith("v2"):
         f |= LA_FLAG_KERNEL_128ROW
+    if os.environ.get("LA_VOTE", "").startswith("half"):        # skip lists per 128-row half of the 256-row workgroup (bf16 / fp16 head_dim 128)
+        f |= LA_FLAG_HALF_VOTE
     if os.environ.get("LA_SCHED", "").startswith("s"):
         f |= LA_FLAG_STATIC_SCHED
     if os.environ.get("LA_RESCALE_TAU", "") not in ("", "8", "8.0"):
@@ -177,7 +182,7 @@ def status_string(code: int) -> str:
 def is_instantiated(head_dim: int, element_size: int, flags: int = None) -> bool:
     """Does la_fwd have a kernel for exactly this head_dim (under the kernel-selection flags)? The library is the one table."""
     m, n = ctypes.c_int(0), ctypes.c_int(0)
-    f = 0 if element_size == 1 else (default_flags() if flags is None else flags) & LA_FLAG_KERNEL_128ROW
+    f = 0 if element_size == 1 else (default_flags() if flags is None else flags) & GEOMETRY_FLAGS
     return load().la_get_tile_sizes_ex(int(head_dim), int(element_size), f, ctypes.byref(m), ctypes.byref(n)) == LA_OK
 
 
@@ -188,7 +193,7 @@ def get_tile_sizes(head_dim: int, element_size: int, flags: int = None) -> Tuple
     """(kBlockM, kBlockN) of the kernel la_fwd runs for this head_dim / element size (and kernel-selection flags; default:
     ``default_flags()``, what ``mha_fwd`` passes). fp8 has no 128-row kernel: the flag is dropped for 1-byte elements."""
     m, n = ctypes.c_int(0), ctypes.c_int(0)
-    f = (default_flags() if flags is None else flags) & LA_FLAG_KERNEL_128ROW
+    f = (default_flags() if flags is None else flags) & GEOMETRY_FLAGS
     if element_size == 1:
         f = 0
     key = (int(head_dim), int(element_size), f)
@@ -206,7 +211,7 @@ def device_slots(head_dim: int, element_size: int, flags: int = None) -> Tuple[i
     """(compute units of the current device, resident workgroups per compute unit) for the kernel la_fwd runs: what a host that
     issues one attention as several q-tile windows sizes its windows with (``parallel.plan_q_windows``)."""
     cu, per = ctypes.c_int(0), ctypes.c_int(0)
-    f = (default_flags() if flags is None else flags) & LA_FLAG_KERNEL_128ROW
+    f = (default_flags() if flags is None else flags) & GEOMETRY_FLAGS
     if element_size == 1:
         f = 0
     rc = load().la_device_slots(int(head_dim), int(element_size), f, ctypes.byref(cu), ctypes.byref(per))

@@ -34,6 +34,7 @@ X64_GEN, X64_INC = "gen_fwd_x64.py", "la_fwd_x64_body.inc"      # the hand-sched
 X64_F16_INC = "la_fwd_x64_f16_body.inc"                        # the same generator with LA_X64_DTYPE=f16 (fp16 MFMA / conversions)
 X64_BODIES = [(128, "bf16", X64_INC), (128, "f16", X64_F16_INC)] + [
     (d, t, f"la_fwd_x64_d{d}_{'f16_' if t == 'f16' else ''}body.inc") for d in (64, 96, 192, 256) for t in ("bf16", "f16")]   # LA_X64_D / LA_X64_DTYPE
+X64_HALF_INC, X64_HALF_F16_INC = "la_fwd_x64_half_body.inc", "la_fwd_x64_half_f16_body.inc"      # LA_X64_FORM=half: the half-vote form of head_dim 128
 X64F8_GEN, X64F8_INC = "gen_fwd_x64_fp8.py", "la_fwd_x64_fp8_body.inc"     # fp8: the same structure on the block-scaled MFMA
 X64F8_EXP_INC = "la_fwd_x64_fp8_exp_body.inc"                               # LA_X64F8_OPT=exp: P = v_exp_f32 rounded by the hardware convert (LA_FLAG_EXACT_EXP)
 X64F8_LVALU_INC = "la_fwd_x64_fp8_lvalu_body.inc"                           # LA_X64F8_OPT=lvalu: that, and fp32 row sums on the VALU (LA_FLAG_EXACT_ROWSUM)
@@ -151,6 +152,11 @@ def generate_bodies(gen_dir: str, variant: bool, defines=(), quiet=subprocess.DE
         if variant and head_dim == 128 and any(d.replace(" ", "") == "LA_X64_M16=1" for d in defines):
             gen = X64_M16_GEN                       # -DLA_X64_M16=1 (A/B build): head_dim 128 on v_mfma_f32_16x16x32 (LA_X64_OPT tunes it)
         generate(gen, inc, env, body_macro(head_dim, dtype))
+    for dtype, inc, macro in (("bf16", X64_HALF_INC, "LA_X64_HALF_BODY_INC"), ("f16", X64_HALF_F16_INC, "LA_X64_HALF_F16_BODY_INC")):
+        env = dict(base_env, LA_X64_D="128", LA_X64_DTYPE=dtype, LA_X64_FORM="half")       # skip lists per 128-row half (LA_FLAG_HALF_VOTE)
+        if variant:
+            env["LA_X64_OPT"] = os.environ.get("LA_X64_HALF_OPT", "")
+        generate(X64_GEN, inc, env, macro)
     f8_default = os.environ.get("LA_X64F8_DEFAULT_OPT", "") if variant else ""      # a global LA_X64F8_OPT never reaches the default body
     generate(X64F8_GEN, X64F8_INC, dict(base_env, LA_X64F8_OPT=f8_default), "LA_X64F8_BODY_INC", "LA_X64F8_CONSTS_INC")
     for form, inc in (("exp", X64F8_EXP_INC), ("lvalu", X64F8_LVALU_INC)):       # LA_X64F8_<FORM>_OPT tunes that body alone (variants only)

@@ -87,6 +87,17 @@ W2 = "w2" in OPT
 D = int(os.environ.get("LA_X64_D", "128"))
 assert D in (64, 96, 128, 192, 256)
 assert not W2 or D == 64
+# LA_X64_FORM=half (round 6; LA_FLAG_HALF_VOTE, la_fwd_x64_half*_body.inc): the skip lists are kept per 128-ROW HALF of the 256-row
+# workgroup (waves 0-1 / waves 2-3; kBlockM = 128 as the reference's bf16 head_dim-128 tile, tile_size.h:35-39). The workgroup walks
+# the UNION of its two lists (the C++ shell merges them into one descending tile sequence and one activity bit per position and
+# half); a wave whose half does not list the tile at a position sits that tile out: no MFMA, no softmax, no fragment reads - it only
+# stages its DMA pieces, follows the tile-address table and meets the barrier. The software pipeline of a step mixes two tiles (QK,
+# statistics and the first part of softmax of tile i+1; the rest of softmax and PV of tile i), so a step comes in four forms by
+# (a(i), a(i+1)), dispatched at its top from a 64-bit activity window in SGPRs (ACT: bit k = a(i + k), shifted every step, refilled
+# from LDS when a vote word is flushed). Votes go to the half's own vote words. Results per half are exactly those of an independent
+# 128-row q-tile walking its own list (the oracle at block_m = 128).
+HALF = os.environ.get("LA_X64_FORM", "") == "half"
+assert not HALF or (D in (64, 96, 128) and not W2)
 DL = 64 if D == 64 else (128 if D <= 128 else 256)   # layout head dim: LDS row pitch, q-blocks per wave, DMA pieces
 NQB = 1 if W2 else (2 if DL <= 128 else 1)   # 32-row q-blocks per wave
 NW = 8 if W2 else 4                       # waves per workgroup
@@ -184,6 +195,7 @@ S_TB, S_VB, S_EXEC, S_T64, S_T64B = 42, 44, 46, 48, 50   # 64-bit temps
  S_FREE0, S_FREE1, S_FREE2, S_LDS, S_T0, S_T1, S_T2, S_T3, S_NM1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_PARAM, S_DOWORD, S_NEGC,
  S_FREE3, S_DMAW, S_FREE4, S_TAU, S_RESC, S_FREE5) = range(52, 87)
 S_FREE6, S_TB2, S_VB2, S_BIT = 87, 88, 90, 92
+S_ACT, S_ACTPTR, S_HSTRIDE = S_T64B, S_FREE1, S_FREE2    # HALF: s[50:51] = activity window (bit k = a(i + k)), LDS address of the next activity word, bytes between the halves' flag blocks
 S_ONES = S_FREE0                                 # packed (1.0, 1.0) of the element type: src0 of the row-sum dot (dotsum)    # second set of DMA bases (the loop is unrolled by two); the rotating vote bit
 S_CC = 94                                        # s[94:95] = (c, c): scalar operand of v_pk_fma_f32
 TBS, VBS = [S_TB, S_TB2], [S_VB, S_VB2]
@@ -442,6 +454,11 @@ def row_max_ops(sset):
     return [x for pair in zip(*per) for x in pair]
 
 
+def stats_bookkeeping(flush_label, flush_back):
+    """HALF, a(i + 1) = 0: what a step's statistics block does besides the statistics - the table pointer and the rotating vote bit."""
+    return [f"    v_add_u32 {v(TABV)}, 16, {v(TABV)}", f"    s_lshl_b32 {s(S_BIT)}, {s(S_BIT)}, 1", f"    s_cbranch_scc0 {flush_label}", flush_back + ":"]
+
+
 def stats_ops(rare_label, back_label, flush_label, flush_back, inval_label, inval_back):
     """Half-wave max exchange, skip vote (one bit per position, OR over both q-blocks), true running max, lazy-rescale test.
     The vote bit of the position rides in S_BIT (shifted left every step; when it falls off the word is flushed), so no
@@ -463,9 +480,10 @@ def stats_ops(rare_label, back_label, flush_label, flush_back, inval_label, inva
     # the step past the end of the walk (i == n - 1: tile i + 1 does not exist, S_nxt came from a clamped duplicate) must not
     # touch the state: its row max becomes -inf (no vote, no new max) and -m_ref*c becomes -inf (the part of P(i+1) computed in
     # this phase, added to the row sums, is 0)
-    a(f"    s_cmp_eq_u32 {s(S_I)}, {s(S_NM1)}")
-    a(f"    s_cbranch_scc1 {inval_label}")
-    o.append(inval_back + ":")
+    if inval_label is not None:             # (HALF: positions past the end of the walk have a = 0, the step form without statistics)
+        a(f"    s_cmp_eq_u32 {s(S_I)}, {s(S_NM1)}")
+        a(f"    s_cbranch_scc1 {inval_label}")
+        o.append(inval_back + ":")
     # vote: (m_loc - m_prev) * c > thr   (softmax.h:194), m_prev = the running max BEFORE this tile
     for qb in QBS:
         a(f"    v_sub_f32 {v(T[2 + qb])}, {v(MLOC[qb])}, {v(MTRUE[qb])}")
@@ -534,7 +552,20 @@ def flush_block(flush_label, back_label):
     flush_domask()
     emit(f"s_add_u32 {s(S_DOWORD)}, {s(S_DOWORD)}, 4")
     emit(f"s_mov_b32 {s(S_BIT)}, 1")
-    emit("s_waitcnt lgkmcnt(0)")
+    if HALF:
+        # the flush runs inside step i = 32 m + 30, before its end-of-step shift: the window holds a(i), a(i + 1) in bits 0..1 and the
+        # NEXT activity word (positions 32 (m + 1) ...) goes to bits 2..33
+        emit(f"v_mov_b32 {v(T[4])}, {s(S_ACTPTR)}")
+        emit(f"ds_read_b32 {v(T[4])}, {v(T[4])}")
+        emit(f"s_add_u32 {s(S_ACTPTR)}, {s(S_ACTPTR)}, 4")
+        emit("s_waitcnt lgkmcnt(0)")
+        emit(f"v_readfirstlane_b32 {s(S_T0)}, {v(T[4])}")
+        emit(f"s_and_b32 {s(S_ACT)}, {s(S_ACT)}, 3")
+        emit(f"s_lshl_b32 {s(S_T1)}, {s(S_T0)}, 2")
+        emit(f"s_lshr_b32 {s(S_ACT + 1)}, {s(S_T0)}, 30")
+        emit(f"s_or_b32 {s(S_ACT)}, {s(S_ACT)}, {s(S_T1)}")
+    else:
+        emit("s_waitcnt lgkmcnt(0)")
     emit(f"s_branch {back_label}")
 
 
@@ -654,7 +685,7 @@ def widen_last(n, since):
 HALFSKIP = int(opt_val("halfskip", "0"))     # PRICING ONLY: every wave sits out one step in HALFSKIP (no MFMA, no softmax, no fragment reads)
 
 
-def step(variant, light=False):
+def step(variant, light=False, a_cur=True, a_nxt=True):
     if light:                             # the step of a wave whose 128-row half does not list this tile: it still stages its DMA pieces,
         saved = set(OPT)                  # follows the tile-address table and meets the barrier
         OPT.update({"nomfma1", "nomfma2", "nosoftmax", "norowmax", "novread", "nokread", "nowaitv"})
@@ -663,13 +694,17 @@ def step(variant, light=False):
         finally:
             OPT.clear()
             OPT.update(saved)
-    return _step(variant)
+    return _step(variant, a_cur, a_nxt)
 
 
-def _step(variant):
+def _step(variant, a_cur=True, a_nxt=True):
     """One pipeline step; variant = parity of i: S_cur = S set `variant`, K(i+2)/V(i) in LDS buffer `variant`, DMA bases
     in SGPR set `variant` (computed during the previous step). Nothing but the drain, the barrier and the loop test sits
-    between the last MFMA of a step and the first of the next."""
+    between the last MFMA of a step and the first of the next.
+    HALF: a_cur / a_nxt = this wave's half lists tile i / tile i + 1. Tile i's work of the step (rest of softmax(i), V^T reads, PV(i))
+    is there iff a_cur; tile i + 1's (QK(i+1), row max / vote / running max, first part of softmax(i+1)) iff a_nxt. The DMA issue, the
+    table reads, the vote-bit / table-pointer bookkeeping, the drain and the barrier are in every form. K(i+2) fragments: read beside
+    the PV MFMAs when a_cur (whatever a(i+2): the gaps cannot branch), else in a block of their own iff a(i+2)."""
     cur, nxt = variant, variant ^ 1
     kbuf_read = cur * KV_TILE                # K(i+2)
     kbuf_stage = nxt * KV_TILE               # K(i+3) goes where K(i+1) was
@@ -677,27 +712,34 @@ def _step(variant):
     vbuf_stage = nxt * KV_TILE               # V(i+1)
     ord1 = [(f & 1) * KS + (f >> 1) for f in range(NKF)]     # K fragment order: alternate key blocks
     ord2 = [(f % DB) * 4 + (f // DB) for f in range(NVF)]    # V^T fragment order: kk outer, d-block inner
+    full = a_cur and a_nxt
 
     # ---- phase 1: QK^T(i+1) || rest of softmax(i), DMA issue (V(i+1), K(i+3)), first V^T fragments
     pre = [[] for _ in range(NG)]
     post = [[] for _ in range(NG)]
     mf = []
     for t in range(NG):
-        mf.append(mfma_qk(nxt, ord1[t // NQB], qb_of(t)) if "nomfma1" not in OPT else "    s_nop 0")
+        mf.append(mfma_qk(nxt, ord1[t // NQB], qb_of(t)) if ("nomfma1" not in OPT and a_nxt) else "    s_nop 0")
     for g, op in zip(DMA_GAPS, dma_ops(kbuf_stage, vbuf_stage, st=variant)):
         post[g].append(op)
     if K_EARLY and "nokread" not in OPT:
         for t in range(NG):
             if t % NQB == NQB - 1:                           # the last MFMA that reads fragment ord1[t // NQB] has issued
                 post[t].append(k_read(kbuf_read, ord1[t // NQB]))
-    if "novread" not in OPT:
+    if "novread" not in OPT and a_cur:
         for f in range(8):                                   # the first 8 V^T fragments, spread over the second half of the phase
             post[NG // 2 + f * (NG // 2) // 8] += v_read(f, vbuf_cur, ord2[f])
-    vq = softmax_stream(cur, list(range(XPAIRS, 16)))
+    vq = softmax_stream(cur, list(range(XPAIRS, 16))) if a_cur else []
     distribute(vq, post, 0, CAP1)
     mark = len(out)
     emit_gaps(pre, mf, post)
-    widen_last(int(opt_val("wp2", "0")) if variant == 0 else int(opt_val("wp2b", opt_val("wp2", "0"))), mark)      # shift phase 2 (copy 0 / copy 1 of the step)
+    if full:
+        widen_last(int(opt_val("wp2", "0")) if variant == 0 else int(opt_val("wp2b", opt_val("wp2", "0"))), mark)      # shift phase 2 (copy 0 / copy 1 of the step)
+    if a_nxt and not a_cur:
+        # no PV MFMAs stand between the QK MFMAs and the first VALU read of their results (the row max): the MFMA results are
+        # readable 18 wait states after the last one issued
+        emit("s_nop 15")
+        emit("s_nop 7")
 
     # ---- phase 2: PV(i) || K(i+2) fragments -> AGPRs, rest of the V^T fragments, next step's DMA bases,
     #               stats(i+1), first part of softmax(i+1)
@@ -706,12 +748,12 @@ def _step(variant):
     mf = []
     for t in range(NG):
         f, qb = t // NQB, t % NQB
-        if qb == 0 and "novread" not in OPT and "nowaitv" not in OPT:
+        if qb == 0 and "novread" not in OPT and "nowaitv" not in OPT and a_cur:
             pre[t].append(("WAIT", ("v", ord2[f], 1)))
-        mf.append(mfma_pv(cur, f % 8, ord2[f], qb_of(t)) if "nomfma2" not in OPT else "    s_nop 0")
-        if qb == NQB - 1 and f + 8 < NVF and "novread" not in OPT:
+        mf.append(mfma_pv(cur, f % 8, ord2[f], qb_of(t)) if ("nomfma2" not in OPT and a_cur) else "    s_nop 0")
+        if qb == NQB - 1 and f + 8 < NVF and "novread" not in OPT and a_cur:
             post[t] += v_read(f % 8, vbuf_cur, ord2[f + 8])
-        if "nokread" not in OPT and not K_EARLY and (t < NKF if "klate" not in OPT else (t & 1) == 0):
+        if "nokread" not in OPT and not K_EARLY and a_cur and (t < NKF if "klate" not in OPT else (t & 1) == 0):
             post[t].append(k_read(kbuf_read, ord1[t if "klate" not in OPT else f]))
     if "mfmasum" in OPT:
         # PRICING ONLY: the 64 v_add_f32 of the row sums are gone and one more MFMA per (q-block, 16-key group)
@@ -730,7 +772,7 @@ def _step(variant):
     vq = [("LDS", f"ds_read_b64 {vr(T[4], 2)}, {v(TABV)} offset:8", "tabv"),
           ("LDS", f"ds_read_b64 {vr(T[6], 2)}, {v(TABV)} offset:32", "tabk")]
     n_head = len(vq)
-    if "norowmax" not in OPT:
+    if "norowmax" not in OPT and a_nxt:
         rm = row_max_ops(nxt)
     else:
         rm = []
@@ -747,20 +789,34 @@ def _step(variant):
         if nb:
             mixed.append(nb.pop(0))
     vq += mixed
-    if "notail" not in OPT:
-        inv, invback = new_label("inval"), new_label("inval_back")
+    if not a_nxt:
+        vq += stats_bookkeeping(fl, flback)
+        deferred.append(lambda: flush_block(fl, flback))
+    elif "notail" not in OPT:
+        inv, invback = (None, None) if HALF else (new_label("inval"), new_label("inval_back"))
         vq += stats_ops(rare, back, fl, flback, inv, invback)
-        deferred.append(lambda: inval_block(inv, invback))
+        if not HALF:
+            deferred.append(lambda: inval_block(inv, invback))
         deferred.append(lambda: rare_rescale_block(rare, back))
         deferred.append(lambda: flush_block(fl, flback))
-    vq += softmax_stream(nxt, list(range(XPAIRS)))
+    if a_nxt:
+        vq += softmax_stream(nxt, list(range(XPAIRS)))
     # the first two gaps may only hold ops that do not read S_nxt (MFMA -> VALU read hazard): the SALU / seq part
     distribute(vq[:n_head], post, 0, CAP2 if CAP2 > 0 else 6)
     distribute(vq[n_head:], post, 2, CAP2)
     mark = len(out)
     emit_gaps(pre, mf, post)
-    if variant == 0:
+    if variant == 0 and full:
         widen_last(int(opt_val("wc2", "0")), mark)                 # shift the second copy of the step against the first
+    if HALF and not a_cur and "nokread" not in OPT:
+        # K(i+2) fragments iff this half lists tile i + 2 (bit 2 of the window). Behind every counted LDS wait of the step and in front
+        # of the drain: a conditional LDS operation between a counted wait and its target would break the count.
+        nok = new_label("nokfrag")
+        emit(f"s_bitcmp1_b32 {s(S_ACT)}, 2")
+        emit(f"s_cbranch_scc0 {nok}")
+        for j in range(NKF):
+            emit(k_read(kbuf_read, ord1[j]))
+        label(nok)
 
     # ---- tail: the rare O rescale, drain, barrier
     resc, resc_back = new_label("resc"), new_label("resc_back")
@@ -772,6 +828,8 @@ def _step(variant):
     if "nobarrier" not in OPT:
         emit("s_barrier")
     emit(f"s_add_u32 {s(S_I)}, {s(S_I)}, 1")
+    if HALF:
+        emit(f"s_lshr_b64 {sr(S_ACT)}, {sr(S_ACT)}, 1")
 
 
 def mask_first_tile_ops():
@@ -1001,9 +1059,23 @@ def prologue():
     emit("s_waitcnt lgkmcnt(0)")
     plist = [S_KBASE, S_KBASE + 1, S_VBASE, S_VBASE + 1, S_KRS, S_VRS, S_LASTROW, S_NTILES, S_C, S_THR, S_TAILVALID,
              S_FIRSTLAST, S_TAB, S_DOFLAGS, S_QBASE, S_QBASE + 1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_LDS, S_NEGC, S_TAU]
+    if HALF:
+        plist.append(S_HSTRIDE)            # [23]: bytes between the two halves' flag blocks; [19] (S_EXPORT) = LDS address of half 0's activity words
     for idx, sg in enumerate(plist):
         emit(f"v_readfirstlane_b32 {s(sg)}, {v(idx)}")
     emit("s_nop 4")
+    if HALF:
+        emit("; ---- half = wave >> 1: its vote words, its activity words; the window starts as positions [0, 64)")
+        emit(f"s_lshr_b32 {s(S_T0)}, {s(S_WAVE)}, 1")
+        emit(f"s_mul_i32 {s(S_T0)}, {s(S_T0)}, {s(S_HSTRIDE)}")
+        emit(f"s_add_u32 {s(S_DOFLAGS)}, {s(S_DOFLAGS)}, {s(S_T0)}")
+        emit(f"s_add_u32 {s(S_ACTPTR)}, {s(S_EXPORT)}, {s(S_T0)}")
+        emit(f"v_mov_b32 {v(T[0])}, {s(S_ACTPTR)}")
+        emit(f"ds_read_b64 {vr(T[4], 2)}, {v(T[0])}")
+        emit("s_waitcnt lgkmcnt(0)")
+        emit(f"v_readfirstlane_b32 {s(S_ACT)}, {v(T[4])}")
+        emit(f"v_readfirstlane_b32 {s(S_ACT + 1)}, {v(T[5])}")
+        emit(f"s_add_u32 {s(S_ACTPTR)}, {s(S_ACTPTR)}, 4")           # the first flush (step 30) brings word 1 to bits 2..33
     emit(f"s_mov_b32 {s(S_CC)}, {s(S_C)}")
     emit(f"s_mov_b32 {s(S_CC + 1)}, {s(S_C)}")
     emit(f"s_sub_u32 {s(S_NM1)}, {s(S_NTILES)}, 1")
@@ -1144,6 +1216,13 @@ def prologue():
         emit(f"v_mov_b32 {v(L0[qb])}, 0")
         emit(f"v_mov_b32 {v(L1[qb])}, 0")
         emit(f"v_mov_b32 {v(ALPHA[qb])}, 1.0")
+        if HALF:
+            # a half that does not list the first position starts from the empty state: its first tile's statistics see m_true =
+            # -inf (every row votes "do": +inf > thr) and m_true > m_ref + tau / c = -inf, so the rescale block sets m_ref, -m_ref c
+            # and the trigger level there (alpha = exp2(-inf) = 0 on l = 0 and O = 0)
+            emit(f"v_mov_b32 {v(MREF[qb])}, 0xff800000")
+            emit(f"v_mov_b32 {v(MTHR[qb])}, 0xff800000")
+            emit(f"v_mov_b32 {v(NMS[qb])}, 0")
 
     if W2:
         # step i reads tab[i + 1].v (V(i+1)) and tab[i + 2].k (K(i+2)): TABV = &tab[1]. K(0) fragments -> AGPRs; once every wave has
@@ -1171,8 +1250,14 @@ def prologue():
     emit(f"v_readfirstlane_b32 {s(TBS[0])}, {v(T[8])}")
     emit(f"v_readfirstlane_b32 {s(TBS[0] + 1)}, {v(T[9])}")
     ord1 = [(f & 1) * KS + (f >> 1) for f in range(NKF)]
+    if HALF:
+        noqk0 = new_label("noqk0")
+        emit(f"s_bitcmp1_b32 {s(S_ACT)}, 0")                   # this half lists the first position
+        emit(f"s_cbranch_scc0 {noqk0}")
     for t in range(NG):
         out.append(mfma_qk(0, ord1[t // NQB], qb_of(t)))
+    if HALF:
+        label(noqk0)
     for j in range(NKF):
         emit(k_read(KV_TILE, j))
     emit(("DRAIN",))
@@ -1185,6 +1270,11 @@ def prologue():
     for dst, src in ((TBS[0], T[10]), (TBS[0] + 1, T[11]), (VBS[0], T[12]), (VBS[0] + 1, T[13])):   # step 0 stages K(3), V(1)
         emit(f"v_readfirstlane_b32 {s(dst)}, {v(src)}")
     emit("s_nop 7")
+    if HALF:
+        nofirst = new_label("nofirst")
+        emit(f"s_mov_b32 {s(S_DOMASK)}, 0")
+        emit(f"s_bitcmp1_b32 {s(S_ACT)}, 0")
+        emit(f"s_cbranch_scc0 {nofirst}")
     # seqlen-k mask: only if n0 == k_tiles-1 and tail_valid < 64  (mask.h:44-78; first walked tile only, mainloop...:1626)
     nomask = new_label("nomask")
     emit(f"s_cmp_eq_u32 {s(S_FIRSTLAST)}, 1")                # the first walked tile is tile k_tiles - 1 (C++ shell)
@@ -1219,6 +1309,10 @@ def prologue():
     emit(f"s_mov_b32 {s(S_DOWORD)}, {s(S_DOFLAGS)}")
     for op in softmax_stream(0, list(range(XPAIRS))):
         out.append(op)
+    if HALF:
+        label(nofirst)                                         # (step 0 starts with the window as loaded: bit k = a(k))
+        emit(f"s_mov_b32 {s(S_BIT)}, 2")
+        emit(f"s_mov_b32 {s(S_DOWORD)}, {s(S_DOFLAGS)}")
 
     emit(("DRAIN",))
     emit("s_barrier")
@@ -1288,7 +1382,33 @@ def main():
                 emit("s_nop 0")
         emit(f"s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}")
         emit(f"s_cbranch_scc0 {done}")
-        if HALFSKIP:
+        if HALF:
+            # four forms of the step by (a(i), a(i+1)) = bits 0, 1 of the window; the full form stays inline (the hot path: three
+            # scalar instructions in front of it), the others are out of line
+            notfull, after = new_label("notfull"), new_label("after_step")
+            emit(f"s_and_b32 {s(S_T0)}, {s(S_ACT)}, 3")
+            emit(f"s_cmp_eq_u32 {s(S_T0)}, 3")
+            emit(f"s_cbranch_scc0 {notfull}")
+            step(variant)
+            label(after)
+
+            def partial_forms(notfull=notfull, after=after, variant=variant):
+                l10, l01 = new_label("step10"), new_label("step01")
+                label(notfull)
+                emit(f"s_cmp_eq_u32 {s(S_T0)}, 1")
+                emit(f"s_cbranch_scc1 {l10}")
+                emit(f"s_cmp_eq_u32 {s(S_T0)}, 2")
+                emit(f"s_cbranch_scc1 {l01}")
+                step(variant, a_cur=False, a_nxt=False)
+                emit(f"s_branch {after}")
+                label(l10)
+                step(variant, a_cur=True, a_nxt=False)
+                emit(f"s_branch {after}")
+                label(l01)
+                step(variant, a_cur=False, a_nxt=True)
+                emit(f"s_branch {after}")
+            deferred.append(partial_forms)
+        elif HALFSKIP:
             # waves 0-1 sit out the steps with i % HALFSKIP == 0, waves 2-3 those with i % HALFSKIP == HALFSKIP / 2: what a workgroup
             # walking the union of two per-128-row lists would do on the tiles only one half lists (HISTORY.md section 8.6 a)
             assert not W2
@@ -1326,7 +1446,8 @@ def write_out():
     text = "\n".join(lines)
     path = sys.argv[1] if len(sys.argv) > 1 else "la_fwd_x64_body.inc"
     with open(path, "w") as f:
-        f.write("// GENERATED by gen_fwd_x64.py — do not edit. Inline-asm body of la_fwd_x64_kernel.\n" if D == 128 else
+        f.write("// GENERATED by gen_fwd_x64.py — do not edit. Inline-asm body of la_fwd_x64_kernel.\n" if D == 128 and not HALF else
+                f"// GENERATED by gen_fwd_x64.py (LA_X64_D={D} LA_X64_FORM=half) — do not edit. Inline-asm body of la_fwd_x64_kernel<.., {D}, true>.\n" if HALF else
                 f"// GENERATED by gen_fwd_x64.py (LA_X64_D={D}) — do not edit. Inline-asm body of la_fwd_bf16_x64_kernel<.., {D}>.\n")
         f.write(option_tag() + "\n")
         f.write('R"ASM(\n' + text + '\n)ASM"\n')

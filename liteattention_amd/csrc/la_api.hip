@@ -25,9 +25,14 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 //   fp8 head_dim 128: x64-fp8. The skip lists are indexed by the selected kernel's tile, so
 //   la_get_tile_sizes_ex and la_fwd must agree on it: both call uses_128row().
 constexpr uint32_t kKnownFlags = LA_FLAG_V_PREPARED | LA_FLAG_STATIC_SCHED | LA_FLAG_KERNEL_128ROW | LA_FLAG_EXACT_RESCALE |
-                                LA_FLAG_EXACT_ROWSUM | LA_FLAG_EXACT_EXP;
+                                LA_FLAG_EXACT_ROWSUM | LA_FLAG_EXACT_EXP | LA_FLAG_HALF_VOTE;
 bool uses_128row(int head_dim, int element_size, uint32_t flags) {      // the flag changes the q-tile (256 -> 128 rows) at head dims 64 and 128
     return element_size == 2 && (head_dim == 128 || head_dim == 64) && (flags & LA_FLAG_KERNEL_128ROW) != 0;
+}
+// LA_FLAG_HALF_VOTE: the hand-scheduled kernel with skip lists per 128-row half of its 256-row workgroup (bf16 / fp16 head_dim 128; no
+// effect elsewhere, and LA_FLAG_KERNEL_128ROW - another kernel with the same list geometry - wins when both are set)
+bool uses_half_vote(int head_dim, int element_size, uint32_t flags) {
+    return element_size == 2 && head_dim == 128 && (flags & LA_FLAG_HALF_VOTE) != 0 && (flags & LA_FLAG_KERNEL_128ROW) == 0;
 }
 constexpr uint64_t kSchedWorkspaceBytes = 1024;   // 16 ticket / steal counters of 64 bytes, all of them zeroed by prepare_work_queue (no slack)
 constexpr float kRescaleTauBf16 = 8.0f;           // lazy-rescale slack of the x64 kernel, log2 units (HISTORY.md section 3.1)
@@ -61,7 +66,7 @@ const char* la_status_string(int status) {
         case LA_ERR_LAUNCH: return "HIP kernel launch failed (see la_last_hip_error)";
         case LA_ERR_SEQLEN: return "seqlen_k too long: expanded skip list does not fit in LDS";
         case LA_ERR_WORKSPACE: return "fp8 needs a 16-byte aligned workspace of la_fwd_workspace_bytes() bytes";
-        case LA_ERR_Q_WINDOW: return "q_tile_begin/q_tile_count outside the q-tiles of this problem";
+        case LA_ERR_Q_WINDOW: return "q_tile_begin/q_tile_count outside the q-tiles of this problem (LA_FLAG_HALF_VOTE: windows start on an even q-tile and hold an even number unless they reach the last)";
         default: return "unknown la_status";
     }
 }
@@ -73,6 +78,7 @@ int la_get_tile_sizes_ex(int head_dim, int element_size, uint32_t flags, int* bl
     if ((flags & LA_FLAG_KERNEL_128ROW) && element_size == 1) return LA_ERR_UNSUPPORTED;   // the 128-row fp8 kernel is not in this build
     if ((flags & LA_FLAG_KERNEL_128ROW) && (head_dim == 96 || head_dim == 192)) return LA_ERR_HEAD_DIM;   // the hipcc-scheduled template has 64 / 128 / 256
     if (uses_128row(head_dim, element_size, flags)) t.block_m = 128;                       // A/B kernel: 32 rows per wave
+    if (uses_half_vote(head_dim, element_size, flags)) t.block_m = 128;                    // lists per 128-row half of the 256-row workgroup
     if (block_m) *block_m = t.block_m;
     if (block_n) *block_n = t.block_n;
     return LA_OK;
@@ -174,13 +180,25 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     p.batch = a->batch; p.seqlen_q = a->seqlen_q; p.seqlen_k = a->seqlen_k; p.num_heads = a->num_heads;
     p.h_ratio = a->num_heads / a->num_heads_k;
     p.q_tiles = (a->seqlen_q + bm - 1) / bm;
+    p.list_q_tiles = p.q_tiles;
     p.k_tiles = (a->seqlen_k + bn - 1) / bn;
+    const bool half_vote = uses_half_vote(a->head_dim, esize, a->flags);
     if (a->q_tile_count == 0) {
         if (a->q_tile_begin != 0) return LA_ERR_Q_WINDOW;
         p.q_tile_begin = 0; p.q_tile_count = p.q_tiles;
     } else {
         if (a->q_tile_begin < 0 || a->q_tile_count < 0 || a->q_tile_begin > p.q_tiles - a->q_tile_count) return LA_ERR_Q_WINDOW;
+        // half-vote: q-tiles (list rows) are 128-row halves, the kernel's items are pairs of them: a window starts on an even q-tile
+        // and holds an even number of them unless it reaches the last one
+        if (half_vote && ((a->q_tile_begin & 1) || ((a->q_tile_count & 1) && a->q_tile_begin + a->q_tile_count != p.q_tiles)))
+            return LA_ERR_Q_WINDOW;
         p.q_tile_begin = a->q_tile_begin; p.q_tile_count = a->q_tile_count;
+    }
+    if (half_vote) {                                   // the kernel's geometry: items of 2 * bm rows; the lists keep bm-row rows
+        p.half_vote = 1;
+        p.q_tiles = (p.list_q_tiles + 1) / 2;
+        p.q_tile_count = (p.q_tile_begin + p.q_tile_count + 1) / 2 - p.q_tile_begin / 2;
+        p.q_tile_begin = p.q_tile_begin / 2;
     }
     p.scale_log2 = static_cast<float>(static_cast<double>(a->softmax_scale) * 1.4426950408889634);  // flash_api.cpp:125-126
     p.thr = a->thr;                                                                      // flash_api.cpp:930
@@ -223,7 +241,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         !(a->flags & LA_FLAG_STATIC_SCHED))
         p.work_counter = static_cast<unsigned*>(a->workspace);
     if (x64) {
-        if (la::fwd_lds_bytes_x64(p.k_tiles, nullptr, a->head_dim) > 160 * 1024) return LA_ERR_SEQLEN;
+        if (la::fwd_lds_bytes_x64(p.k_tiles, nullptr, a->head_dim, nullptr, half_vote && skipable) > 160 * 1024) return LA_ERR_SEQLEN;
         err = la::launch_fwd_x64(p, a->head_dim, skipable, f16, stream);
     } else {
         err = la::launch_fwd_bf16_v2(p, a->head_dim, skipable, f16, stream);

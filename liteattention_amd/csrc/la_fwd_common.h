@@ -105,6 +105,41 @@ __device__ __noinline__ void write_skip_list(const int* seq, const unsigned* end
     write_row[0] = min(w - 1, k_tiles);                                  // finalize :185-191
 }
 
+// The same over the positions `live` selects (half-vote kernels: bit p set = this list's walk holds position p of the union sequence;
+// the other positions belong to the other half's list only and do not exist for this writer; the first LIVE position is the list's
+// first walked tile).
+__device__ __forceinline__ void write_skip_list_live(const int* seq, const unsigned* endflags, const unsigned* doflags, const unsigned* live,
+                                                  int n_tiles, int* __restrict__ write_row,
+                                                  const int* __restrict__ must_do_row, int k_tiles) {
+    ListReader md;
+    const bool has_md = must_do_row != nullptr;
+    if (has_md) md.init(must_do_row);
+    int w = 1;
+    bool is_skipping = true, first = true;
+    for (int pos = 0; pos < n_tiles; ++pos) {
+        if (!((live[pos >> 5] >> (pos & 31)) & 1u)) continue;
+        const int n = seq[pos];
+        const bool raw_skip = !first && !((doflags[pos >> 5] >> (pos & 31)) & 1u);
+        first = false;
+        bool skip = raw_skip;
+        if (has_md && skip) {
+            if (md.end > n && md.has_more()) { md.advance(); md.load(k_tiles); }
+            const bool must_do = n <= md.start && n > md.end;
+            skip = skip && !must_do;
+        }
+        if (skip != is_skipping) {
+            if (w <= k_tiles) write_row[w] = n;
+            ++w;
+            is_skipping = skip;
+        }
+        if ((endflags[pos >> 5] >> (pos & 31)) & 1u) {
+            is_skipping = true;
+            if (!raw_skip) { if (w <= k_tiles) write_row[w] = n; ++w; }
+        }
+    }
+    write_row[0] = min(w - 1, k_tiles);
+}
+
 // Inclusive prefix sum over the 64 lanes of a wave on the DPP datapath (round 5): four row_shr steps scan each 16-lane row, then
 // row_bcast:15 adds lane 15 of rows 0 / 2 to rows 1 / 3 and row_bcast:31 adds lane 31 to rows 2 and 3 - six dependent VALU
 // instructions. The __shfl_up form it replaces is six ds_bpermute round trips through the LDS crossbar (~100 cycles each, and the
@@ -166,6 +201,55 @@ __device__ __forceinline__ void write_skip_list_wave(const int* seq, const unsig
         if (e2) { if (slot <= k_tiles) write_row[slot] = n; }
         w += __popcll(e1_b) + __popcll(e2_b);
         carry_skip = static_cast<int>((after_b >> 63) & 1ull);
+    }
+    if (lane == 0) write_row[0] = min(w - 1, k_tiles);
+}
+
+// The same for ONE HALF of a half-vote workgroup (LA_FLAG_HALF_VOTE): the walk was the union of two lists, `livebits` (bit p = this
+// half's list holds position p) selects this list's positions; the others do not exist for this writer: the state a position sees is
+// the one its nearest LIVE predecessor left, and the first live position is the list's first walked tile (never flagged, :1804-1805).
+__device__ __forceinline__ void write_skip_list_wave_live(const int* seq, const unsigned* endflags, const unsigned* doflags,
+                                                          const unsigned* livebits, int n_tiles, int* __restrict__ write_row,
+                                                          const int* __restrict__ must_do_row, int k_tiles, int lane) {
+    int md_start = 0, md_end = 0;
+    if (must_do_row != nullptr) {
+        if (must_do_row[0] > 2) {
+            if (lane == 0) write_skip_list_live(seq, endflags, doflags, livebits, n_tiles, write_row, must_do_row, k_tiles);
+            return;
+        }
+        md_start = must_do_row[1];
+        md_end = must_do_row[2];
+    }
+    int w = 1, carry_skip = 1;
+    bool seen = false;          // a live position came before this chunk (wave-uniform)
+    for (int base = 0; base < n_tiles; base += 64) {
+        const int pos = base + lane;
+        const bool live = pos < n_tiles && ((livebits[pos >> 5] >> (pos & 31)) & 1u);
+        const unsigned long long live_b = __ballot(live);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned long long lb = live_b & below;                                  // live lanes before this one
+        int n = 0;
+        bool raw = false, is_end = false;
+        if (live) {
+            n = seq[pos];
+            const bool first = !seen && lb == 0ull;
+            raw = !first && !((doflags[pos >> 5] >> (pos & 31)) & 1u);
+            is_end = (endflags[pos >> 5] >> (pos & 31)) & 1u;
+        }
+        const bool skip = raw && !(n <= md_start && n > md_end);
+        const unsigned long long after_b = __ballot(live && (is_end || skip));
+        const int before = lb != 0ull ? static_cast<int>((after_b >> (63 - __clzll(static_cast<long long>(lb)))) & 1ull) : carry_skip;
+        const bool e1 = live && (static_cast<int>(skip) != before);
+        const bool e2 = live && is_end && !raw;
+        const unsigned long long e1_b = __ballot(e1), e2_b = __ballot(e2);
+        int slot = w + __popcll(e1_b & below) + __popcll(e2_b & below);
+        if (e1) { if (slot <= k_tiles) write_row[slot] = n; ++slot; }
+        if (e2) { if (slot <= k_tiles) write_row[slot] = n; }
+        w += __popcll(e1_b) + __popcll(e2_b);
+        if (live_b != 0ull) {
+            carry_skip = static_cast<int>((after_b >> (63 - __clzll(static_cast<long long>(live_b)))) & 1ull);
+            seen = true;
+        }
     }
     if (lane == 0) write_row[0] = min(w - 1, k_tiles);
 }
@@ -384,6 +468,39 @@ __device__ __forceinline__ int expand_read_list(const int* __restrict__ row, int
         pos = min(pos + __shfl(incl, 63), k_tiles);
     }
     return pos;
+}
+
+// Half-vote kernels: one read-list row -> a bitmap over the key tiles (bit t = the list names tile t) and the bitmap of its range
+// ends. Same clamps as expand_read_list (indices into [0, k_tiles), at most (k_tiles + 1) / 2 ranges, the first tile of the first
+// range always walked); the list is read as a SET - a well-formed list (descending, disjoint ranges: everything a writer, the
+// initial list or a block mask produces) walks exactly its tiles in descending order either way, a malformed one (overlapping or
+// ascending ranges) walks each named tile once. One wave; `in_bits` / `end_bits` zeroed by the caller.
+__device__ __forceinline__ void expand_read_list_bits(const int* __restrict__ row, unsigned* in_bits, unsigned* end_bits, int k_tiles,
+                                                      int lane) {
+    const int len = max(row[0], 2);
+    const int n_ranges = min(len >> 1, (k_tiles + 1) >> 1);
+    for (int base = 0; base < n_ranges; base += 64) {
+        const int r = base + lane;
+        int hi = 0, cnt = 0;
+        if (r < n_ranges) {
+            const bool in_row = 2 + 2 * r <= k_tiles;
+            hi = (in_row || r == 0) ? min(max(row[1 + 2 * r], 0), k_tiles - 1) : 0;
+            const int end = in_row ? min(max(row[2 + 2 * r], 0), k_tiles - 1) : 0;
+            cnt = max(hi - end + 1, 0);
+            if (r == 0) cnt = max(cnt, 1);
+        }
+        const int lo = hi - cnt + 1;
+        const int w_lo = lo >> 5;
+        const int nw = cnt > 0 ? (hi >> 5) - w_lo + 1 : 0;
+        for (int j = 0; __any(j < nw); ++j) {                  // wave-uniform trip count, predicated body (la_fwd_kernel_x64.hip, "COMPILER HAZARD")
+            if (j < nw) {
+                const int wd = w_lo + j;
+                const int b_lo = max(lo - 32 * wd, 0), b_hi = min(hi - 32 * wd, 31);
+                atomicOr(&in_bits[wd], (0xffffffffu >> (31 - b_hi)) & (0xffffffffu << b_lo));
+            }
+        }
+        if (cnt > 0) atomicOr(&end_bits[lo >> 5], 1u << (lo & 31));
+    }
 }
 
 }  // namespace la

@@ -21,6 +21,10 @@ struct FwdParams {
     int q_tiles, k_tiles;
     int q_tile_begin;       // this launch covers q-tiles [q_tile_begin, q_tile_begin + q_tile_count) of every (batch, head):
     int q_tile_count;       // a window of the SAME problem (tensors, LSE and lists are indexed by the global q-tile)
+    int list_q_tiles;       // rows of the skip lists per (batch, head). == q_tiles, except under LA_FLAG_HALF_VOTE (x64 kernel, head_dim 128): the
+                            // lists are kept per 128-ROW HALF of a 256-row workgroup item: list_q_tiles = ceil(seqlen_q / 128), and item m
+                            // reads / writes rows 2 m and 2 m + 1 (q_tiles, q_tile_begin, q_tile_count stay in items of 256 rows)
+    int half_vote;          // 1 = that mode
     int seq_cap;            // int32 slots reserved in LDS for the expanded tile sequence
     int walk_buffers;       // x64 kernels: 2 = a second walk buffer (tile sequence + vote / range-end flags) fits in LDS beside the first: the next
                             // item's read list is expanded while this item's write list is serialised; 1 = serial (very long key sequences, head_dim > 128)
@@ -82,9 +86,9 @@ inline hipError_t prepare_work_queue(FwdParams& p, bool skipable, int total, int
 
 size_t fwd_lds_bytes_v2(int head_dim, int k_tiles, int* seq_cap_out);
 hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, bool f16, hipStream_t stream);   // 128-row hipcc-scheduled template: head_dim 64; 128 / 256 as the A/B kernels (LA_FLAG_KERNEL_128ROW)
-size_t fwd_lds_bytes_x64(int k_tiles, int* seq_cap_out, int head_dim, int* walk_buffers_out = nullptr);
+size_t fwd_lds_bytes_x64(int k_tiles, int* seq_cap_out, int head_dim, int* walk_buffers_out = nullptr, bool half_vote = false);
 int x64_workgroups_per_cu(int head_dim);      // resident workgroups per CU of the hand-scheduled kernels: 1
-hipError_t launch_fwd_x64(const FwdParams& p, int head_dim, bool skipable, bool f16, hipStream_t stream);  // 1 wave/SIMD; head_dim 128: 64 rows/wave, q-tile 256; 256: 32 rows/wave, q-tile 128
+hipError_t launch_fwd_x64(const FwdParams& p, int head_dim, bool skipable, bool f16, hipStream_t stream);  // p.half_vote: the half-vote form (head_dim 128, lists only)  // 1 wave/SIMD; head_dim 128: 64 rows/wave, q-tile 256; 256: 32 rows/wave, q-tile 128
 size_t fwd_lds_bytes_x64_fp8(int k_tiles, int* seq_cap_out, int* walk_buffers_out = nullptr);
 hipError_t launch_fwd_x64_fp8(const FwdParams& p, bool skipable, int p_mode, hipStream_t stream);   // 1 wave/SIMD, 64 rows/wave; p.v = V^T workspace
 size_t fp8_workspace_bytes(int batch, int num_heads_k, int k_tiles);

@@ -83,7 +83,7 @@ def kernel_head_dim(head_dim: int, element_size: int, flags: Optional[int] = Non
     asked (``la_get_tile_sizes_ex``), there is no second table here."""
     if head_dim <= 0 or head_dim % (16 if element_size == 1 else 8) != 0:
         return head_dim                                      # la_get_tile_sizes / mha_fwd report the error
-    flags = (_cabi.default_flags() if flags is None else flags) & _cabi.LA_FLAG_KERNEL_128ROW
+    flags = (_cabi.default_flags() if flags is None else flags) & _cabi.GEOMETRY_FLAGS
     key = (head_dim, element_size, flags)
     if key not in _KERNEL_HEAD_DIM:
         _KERNEL_HEAD_DIM[key] = next((d for d in (64, 96, 128, 192, 256)

@@ -16,7 +16,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "liteattention_amd")
 POISON = {"LA_X64_OPT": "nosoftmax,mfmasum", "LA_X64_D64_OPT": "w2", "LA_X64_D256_OPT": "nobarrier", "LA_X64F8_OPT": "nomx",
-          "LA_X64F8_DEFAULT_OPT": "nobarrier", "LA_X64F8_EXP_OPT": "halfbarrier", "LA_X64F8_LVALU_OPT": "nowaitvm"}
+          "LA_X64F8_DEFAULT_OPT": "nobarrier", "LA_X64F8_EXP_OPT": "halfbarrier", "LA_X64F8_LVALU_OPT": "nowaitvm", "LA_X64_FORM": "half", "LA_X64_HALF_OPT": "nosoftmax"}
 
 
 def _generate(tmp, variant, env):
@@ -37,7 +37,7 @@ def test_a_poisoned_environment_yields_the_clean_product_bodies(tmp_path):
     clean_dir.mkdir(); dirty_dir.mkdir()
     a = _generate(clean_dir, False, {})
     b = _generate(dirty_dir, False, POISON)
-    assert len(a["generated"]) == 13 and [os.path.basename(p) for p in a["generated"]] == [os.path.basename(p) for p in b["generated"]]
+    assert len(a["generated"]) == 15 and [os.path.basename(p) for p in a["generated"]] == [os.path.basename(p) for p in b["generated"]]
     for pa, pb in zip(a["generated"], b["generated"]):
         assert open(pa, "rb").read() == open(pb, "rb").read(), os.path.basename(pa)        # byte for byte
         head = open(pb).read(400)
@@ -132,4 +132,4 @@ def test_every_loop_head_sits_at_its_pinned_code_placement():
                 key = next(k for k in want if k in m.group(1))
                 assert int(heads[0], 16) % 32 == want[key], (m.group(1), int(heads[0], 16) % 32, want[key])
                 seen += 1
-    assert seen == 26, seen            # 5 head dims x 2 element types x 2 (lists / dense) + 3 fp8 forms x 2
+    assert seen == 28, seen            # 5 head dims x 2 element types x 2 (lists / dense) + the half-vote form of head_dim 128 x 2 element types + 3 fp8 forms x 2
