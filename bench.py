@@ -624,7 +624,7 @@ def main():
                 read_list = att.local._skip_list[att.local._phase].clone()
                 out, lse = local_call()
                 heads = sorted({0, Hl // 2, Hl - 1})
-                lse8 = 2e-4 if os.environ.get("LA_FP8_ROWSUM", "").startswith("exact") else 2.5e-3      # fp8 LSE by form of P: tests/test_gpu_headline.py
+                lse8 = 2e-4 if os.environ.get("LA_FP8_P", "") in ("", "reference") else 2.5e-3      # fp8 LSE by form of P: tests/test_gpu_headline.py
                 tol = dict(o_rtol=0.05, o_atol=1e-3, lse_atol=lse8) if fp8 else dict(o_rtol=2.0 ** -8, o_atol=1e-4)
                 ver = sampled_row_check(q, k, v, out, lse, read_list, bm, bn, heads, n_rows=256, **tol)
                 ver["finite"] = bool(torch.isfinite(out.float()).all().item())
@@ -715,21 +715,21 @@ def main():
             result["fp8"] = {"value": f8["value"], "unit": result["unit"], "ms_per_step": f8["ms_per_step"], "dtype": "fp8 (e4m3 in, fp32 accumulate, bf16 out)",
                              "steps": max(5, args.steps // 2), "sparsity": f8["sparsity"], "tiles": f8["tiles"],
                              "roofline": f8["roofline"], "verified": f8.get("verified"), "power": f8.get("power"),
-                             "p_form": "default: block-scaled log-linear e4m3 encoding of P (include/lite_attention_amd.h, LA_FLAG_EXACT_EXP)"}
-            result["fp8"]["p_form_of_value"] = "default"
-            # beside it, on the same lists and the same box, the two forms that keep the reference's arithmetic:
-            #   exact_exp    = LA_FLAG_EXACT_EXP: P by v_exp_f32 + hardware e4m3 rounding (softmax.h:85-87), row sums of the rounded P from the matrix pipe
-            #   exact_rowsum = LA_FLAG_EXACT_ROWSUM: that, plus fp32 row sums of the UN-rounded P on the vector unit - the reference's
-            #                  form in full (softmax.h:275-296; fp32-exact LSE): THE number to compare with a reference fp8 kernel
-            for key, var in (("exact_exp", "LA_FP8_EXP"), ("exact_rowsum", "LA_FP8_ROWSUM")):
-                os.environ[var] = "exact"
+                             "p_form": "default = the reference's arithmetic: P by v_exp_f32 + hardware e4m3 rounding (softmax.h:85-87), fp32 row sums of the "
+                                       "un-rounded P on the vector unit (softmax.h:275-296)"}
+            result["fp8"]["p_form_of_value"] = "reference_arithmetic (the default since round 6)"
+            # beside it, on the same lists and the same box, the two opt-in forms that trade the reference's arithmetic for throughput:
+            #   mfma_rowsum = LA_FLAG_FP8_MFMA_ROWSUM: the reference's P, row sums of the ROUNDED P from the matrix pipe
+            #   encoded_p   = LA_FLAG_FP8_ENCODED_P: the block-scaled log-linear e4m3 encoding of P (include/lite_attention_amd.h) - NOT the reference's arithmetic
+            for key, val in (("mfma_rowsum", "mfma_rowsum"), ("encoded_p", "encoded")):
+                os.environ["LA_FP8_P"] = val
                 try:
                     fx = run_dtype("fp8", max(5, args.steps // 2), 2, sweep=False, distributed=False)
                     result["fp8"][key] = {"value": fx["value"], "ms_per_step": fx["ms_per_step"], "frac": fx["roofline"]["frac"],
                                           "verified": {k: fx.get("verified", {}).get(k) for k in ("ok", "max_err", "max_err_lse", "tol")}}
                 finally:
-                    os.environ.pop(var, None)
-            result["fp8"]["reference_arithmetic"] = "exact_rowsum"
+                    os.environ.pop("LA_FP8_P", None)
+            result["fp8"]["reference_arithmetic"] = "value (the default form)"
         except Exception as e:  # noqa: BLE001
             result["fp8"] = {"value": None, "error": repr(e)}
 

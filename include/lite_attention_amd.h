@@ -39,8 +39,9 @@
 extern "C" {
 #endif
 
-#define LA_ABI_VERSION 7   /* 7 = 6 + la_build_info; 6 = 5 + la_blockmask_to_lists, la_device_slots (5 = 4 + skip lists and fp8 with cu_seqlens, LA_FLAG_EXACT_ROWSUM /
-                            * LA_FLAG_EXACT_EXP, LA_DTYPE_FP32 for la_combine); la_fwd_args unchanged since 4 */
+#define LA_ABI_VERSION 8   /* 8 = 7 with the sense of the two fp8 flags turned round (the reference's arithmetic is the default form of P) + LA_FLAG_HALF_VOTE;
+                            * 7 = 6 + la_build_info; 6 = 5 + la_blockmask_to_lists, la_device_slots (5 = 4 + skip lists and fp8 with cu_seqlens, LA_FLAG_EXACT_ROWSUM /
+                            * LA_FLAG_EXACT_EXP (renamed and inverted in 8), LA_DTYPE_FP32 for la_combine); la_fwd_args unchanged since 4 */
 
 typedef enum la_status {
     LA_OK = 0,
@@ -77,13 +78,15 @@ typedef enum la_status {
                                   * ascending ranges walks each named tile once). */
 #define LA_FLAG_EXACT_RESCALE 8u /* A/B: the hand-scheduled kernels rescale O on EVERY growth of a row maximum (tau = 0) instead of lazily
                                   * (bf16: only after it grew by more than 2^8; results agree to rounding, lists are identical) */
-#define LA_FLAG_EXACT_ROWSUM 16u /* fp8: row sums l = sum of the UN-rounded fp32 P on the vector unit (the reference's form, softmax.h:275-296:
-                                  * LSE exact to fp32) instead of the default l~ = sum of the e4m3-encoded P taken from the matrix pipe
+/* fp8 (e4m3) forms of P. DEFAULT = the reference's arithmetic in full: P = exp2(S c - m c + off) by the transcendental unit, rounded to e4m3 by the
+ * hardware convert (softmax.h:85-87 + mainloop...:1645-1647), row sums l = sum of the UN-rounded fp32 P on the vector unit (softmax.h:275-296: LSE
+ * exact to fp32). The two flags below trade that for throughput and are for callers who ask for it (round 6: until ABI 7 the encoded form was the
+ * default and the reference's arithmetic behind LA_FLAG_EXACT_ROWSUM / LA_FLAG_EXACT_EXP - a drop-in's default must be the reference's results). */
+#define LA_FLAG_FP8_MFMA_ROWSUM 16u /* fp8: row sums l~ = sum of the e4m3-ROUNDED P taken from the matrix pipe instead of the fp32 sum of the un-rounded P
                                   * (4-5 % faster; O = (sum P~ V) / (sum P~) is self-consistent, the LSE then carries the rounding of
                                   * P~: |LSE - exact| <= ln(1 + 2^-4), about 1e-2 on rows of a few keys, 1e-4 on long rows).
-                                  * Ignored for bf16 / fp16 (always exact). */
-#define LA_FLAG_EXACT_EXP 32u    /* fp8: P = exp2(S c - m c + off) by the transcendental unit, rounded to e4m3 by the hardware convert (the reference's
-                                  * form, softmax.h:85-87 + mainloop...:1645-1647) instead of the default BLOCK-SCALED LOG-LINEAR ENCODING:
+                                  * Ignored for bf16 / fp16. */
+#define LA_FLAG_FP8_ENCODED_P 32u /* fp8: the BLOCK-SCALED LOG-LINEAR ENCODING of P instead of exp2 + hardware rounding (implies the matrix-pipe row sums):
                                   *  - the e4m3 byte of P is computed directly, b = sat_u8(rne(8 y + 56 - 8 delta)), y = log2 P: one FMA + one byte
                                   *    convert per score and no transcendental (the fp8 kernel is bound by vector-unit issue, not by the matrix
                                   *    pipe). Reading byte / 8 - 7 as a base-2 logarithm is the linear-mantissa exponential (1 + f for 2^f; delta =
@@ -94,10 +97,10 @@ typedef enum la_status {
                                   *    of the byte grid hang below the TILE's maximum, so a diffuse tail far below the row maximum is kept with full
                                   *    relative precision (hardware rounding at the reference's offset drops P below 2^-17 of the row maximum), and
                                   *    P cannot overflow, so O is practically never rescaled.
-                                  * Measured on the reference-generated fp8 outputs the error of O is 1.0-1.3 x that of the exact form (rms) and well
-                                  * inside the reference's own fp8 rule; |LSE - exact| <= 0.084 (rows of one or two comparable keys), about 3e-4 of
-                                  * bias on long rows. +15 ... +22 % throughput at the headline shape over the reference's form, by box and session (the same-session table is
-                                  * generated into HISTORY.md section 3.4; bench.py reports all three forms in one line). Implied by LA_FLAG_EXACT_ROWSUM. Ignored for bf16 / fp16. */
+                                  * NOT the reference's arithmetic: on the reference-generated fp8 outputs the error of O is 1.6-2.1 x that of the default
+                                  * form (rms), inside the reference's own fp8 rule; |LSE - exact| <= 0.084 (rows of one or two comparable keys), about
+                                  * 3e-4 of bias on long rows. +20 ... +25 % throughput at the headline shape over the default (bench.py reports all
+                                  * three forms in one line). Ignored for bf16 / fp16. */
 #define LA_FLAG_STATIC_SCHED 2u  /* keep one workgroup per item (static XCD map) even when a workspace is given. For
                                   * launches that must share the GPU with another kernel while they run — e.g. an RCCL
                                   * collective on another stream: persistent workgroups would hold every CU until the

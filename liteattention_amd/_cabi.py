@@ -13,7 +13,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # LITEATTENTION_AMD_LIB overrides the in-tree location (deployment / tests of the failure path)
 LIB_PATH = os.environ.get("LITEATTENTION_AMD_LIB") or os.path.join(_PKG_DIR, "libliteattention_amd.so")
 
-LA_ABI_VERSION = 7
+LA_ABI_VERSION = 8
 LA_DTYPE_BF16, LA_DTYPE_FP16, LA_DTYPE_FP8_E4M3, LA_DTYPE_FP32 = 0, 1, 2, 3
 
 LA_OK = 0
@@ -61,8 +61,8 @@ LA_FLAG_V_PREPARED = 1
 LA_FLAG_STATIC_SCHED = 2
 LA_FLAG_KERNEL_128ROW = 4
 LA_FLAG_EXACT_RESCALE = 8
-LA_FLAG_EXACT_ROWSUM = 16
-LA_FLAG_EXACT_EXP = 32
+LA_FLAG_FP8_MFMA_ROWSUM = 16     # fp8: row sums of the ROUNDED P from the matrix pipe (default: fp32 sums of the un-rounded P, the reference's)
+LA_FLAG_FP8_ENCODED_P = 32       # fp8: the block-scaled log-linear byte encoding of P (default: exp2 + hardware e4m3 rounding, the reference's)
 LA_FLAG_HALF_VOTE = 64
 GEOMETRY_FLAGS = LA_FLAG_KERNEL_128ROW | LA_FLAG_HALF_VOTE      # the flags that change the q-tile of the skip lists (la_get_tile_sizes_ex)
 
@@ -71,9 +71,10 @@ def default_flags() -> int:
     """A/B switches of the HOST layer (the C library reads no environment): they only choose the default ``la_fwd_args.flags``.
     LA_FWD_KERNEL=v2 -> the 128-row bf16 head_dim-128 kernel (lists then use 128-row q-tiles); LA_VOTE=half -> LA_FLAG_HALF_VOTE (the
     hand-scheduled head_dim-128 kernel with lists per 128-row half); LA_SCHED=static -> one
-    workgroup per item instead of the ticket queues; LA_RESCALE_TAU=0 -> O rescaled on every growth of a row maximum; LA_FP8_ROWSUM=exact -> fp8 row sums of the un-rounded
-    P on the vector unit (LA_FLAG_EXACT_ROWSUM: fp32-exact LSE); LA_FP8_EXP=exact -> fp8 P by v_exp_f32 + the hardware e4m3 rounding instead of
-    the log-linear byte encoding (LA_FLAG_EXACT_EXP; implied by LA_FP8_ROWSUM=exact)."""
+    workgroup per item instead of the ticket queues; LA_RESCALE_TAU=0 -> O rescaled on every growth of a row maximum; LA_FP8_P selects
+    the fp8 form of P: unset / "reference" -> the reference's arithmetic (the default since round 6: exp2 + hardware e4m3 rounding, fp32 row sums of the
+    un-rounded P), "mfma_rowsum" -> LA_FLAG_FP8_MFMA_ROWSUM (row sums of the rounded P from the matrix pipe), "encoded" -> LA_FLAG_FP8_ENCODED_P (the
+    block-scaled log-linear byte encoding: the fast form, NOT the reference's arithmetic)."""
     f = 0
     if os.environ.get("LA_FWD_KERNEL", "").startswith("v2"):
         f |= LA_FLAG_KERNEL_128ROW
@@ -85,10 +86,13 @@ def default_flags() -> int:
         if float(os.environ["LA_RESCALE_TAU"]) != 0.0:
             raise ValueError("LA_RESCALE_TAU: only 0 (exact rescale, LA_FLAG_EXACT_RESCALE) or the default 8 are available")
         f |= LA_FLAG_EXACT_RESCALE
-    if os.environ.get("LA_FP8_ROWSUM", "").startswith("exact"):
-        f |= LA_FLAG_EXACT_ROWSUM
-    if os.environ.get("LA_FP8_EXP", "").startswith("exact"):
-        f |= LA_FLAG_EXACT_EXP
+    fp8_p = os.environ.get("LA_FP8_P", "")
+    if fp8_p not in ("", "reference", "mfma_rowsum", "encoded"):
+        raise ValueError("LA_FP8_P: reference (default), mfma_rowsum or encoded")
+    if fp8_p == "mfma_rowsum":
+        f |= LA_FLAG_FP8_MFMA_ROWSUM
+    if fp8_p == "encoded":
+        f |= LA_FLAG_FP8_ENCODED_P
     return f
 
 

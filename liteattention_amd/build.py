@@ -36,8 +36,8 @@ X64_BODIES = [(128, "bf16", X64_INC), (128, "f16", X64_F16_INC)] + [
     (d, t, f"la_fwd_x64_d{d}_{'f16_' if t == 'f16' else ''}body.inc") for d in (64, 96, 192, 256) for t in ("bf16", "f16")]   # LA_X64_D / LA_X64_DTYPE
 X64_HALF_INC, X64_HALF_F16_INC = "la_fwd_x64_half_body.inc", "la_fwd_x64_half_f16_body.inc"      # LA_X64_FORM=half: the half-vote form of head_dim 128
 X64F8_GEN, X64F8_INC = "gen_fwd_x64_fp8.py", "la_fwd_x64_fp8_body.inc"     # fp8: the same structure on the block-scaled MFMA
-X64F8_EXP_INC = "la_fwd_x64_fp8_exp_body.inc"                               # LA_X64F8_OPT=exp: P = v_exp_f32 rounded by the hardware convert (LA_FLAG_EXACT_EXP)
-X64F8_LVALU_INC = "la_fwd_x64_fp8_lvalu_body.inc"                           # LA_X64F8_OPT=lvalu: that, and fp32 row sums on the VALU (LA_FLAG_EXACT_ROWSUM)
+X64F8_EXP_INC = "la_fwd_x64_fp8_exp_body.inc"                               # LA_X64F8_OPT=exp: P = v_exp_f32 rounded by the hardware convert (LA_FLAG_FP8_MFMA_ROWSUM)
+X64F8_LVALU_INC = "la_fwd_x64_fp8_lvalu_body.inc"                           # LA_X64F8_OPT=lvalu: that, and fp32 row sums on the VALU (the DEFAULT fp8 form: the reference's arithmetic)
 
 
 def body_macro(head_dim: int, dtype: str) -> str:

@@ -70,7 +70,7 @@ NG = 8                                    # QK MFMAs (gaps) of phase 1
 # numerics under the lazy rescale: the weights sum to 1 exactly, so the e4m3 rounding of a row's dominant P (which is not 2^k
 # once m_ref lags m_true) cancels instead of scaling the whole row by up to 2^-4. The LSE inherits the rounding of P~ (HISTORY.md 3.4).
 LMFMA = "lvalu" not in OPT
-# P itself. "exp" (rounds 1-2; LA_FLAG_EXACT_EXP): P = v_exp_f32(S c - m_ref c + OFF), rounded to e4m3 by v_cvt_pk_fp8_f32 - per score one
+# P itself. "exp" (rounds 1-2; LA_FLAG_FP8_MFMA_ROWSUM; with `lvalu` the default form): P = v_exp_f32(S c - m_ref c + OFF), rounded to e4m3 by v_cvt_pk_fp8_f32 - per score one
 # FMA, one transcendental (2 issue slots) and half a convert (which also costs 2 slots: tools/valu_microbench.py) = 4 slots.
 # Default (round 3) "lin": the e4m3 BYTE is computed directly, b = sat_u8(rne(8 y + 56 - 8 delta)), y = S c - m_ref c + OFF - one FMA
 # and one v_cvt_pk_u8_f32 (RNE, saturating, NaN / -inf -> 0: probed on the hardware), 2 slots per score, no transcendental.

@@ -25,7 +25,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 //   fp8 head_dim 128: x64-fp8. The skip lists are indexed by the selected kernel's tile, so
 //   la_get_tile_sizes_ex and la_fwd must agree on it: both call uses_128row().
 constexpr uint32_t kKnownFlags = LA_FLAG_V_PREPARED | LA_FLAG_STATIC_SCHED | LA_FLAG_KERNEL_128ROW | LA_FLAG_EXACT_RESCALE |
-                                LA_FLAG_EXACT_ROWSUM | LA_FLAG_EXACT_EXP | LA_FLAG_HALF_VOTE;
+                                LA_FLAG_FP8_MFMA_ROWSUM | LA_FLAG_FP8_ENCODED_P | LA_FLAG_HALF_VOTE;
 bool uses_128row(int head_dim, int element_size, uint32_t flags) {      // the flag changes the q-tile (256 -> 128 rows) at head dims 64 and 128
     return element_size == 2 && (head_dim == 128 || head_dim == 64) && (flags & LA_FLAG_KERNEL_128ROW) != 0;
 }
@@ -226,7 +226,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         if (e8 == hipSuccess) {
             p.v = static_cast<const uint16_t*>(a->workspace);
             e8 = la::launch_fwd_x64_fp8(p, a->read_list != nullptr,
-                                             (a->flags & LA_FLAG_EXACT_ROWSUM) ? 2 : (a->flags & LA_FLAG_EXACT_EXP) ? 1 : 0, stream);
+                                             (a->flags & LA_FLAG_FP8_ENCODED_P) ? 0 : (a->flags & LA_FLAG_FP8_MFMA_ROWSUM) ? 1 : 2, stream);   // default: the reference's arithmetic
         }
         if (e8 != hipSuccess) { g_last_hip_error = static_cast<int>(e8); return LA_ERR_LAUNCH; }
         return LA_OK;

@@ -132,20 +132,27 @@ def _scoped_flags() -> int:
     return getattr(_tls, "flags", 0)
 
 
+def _scoped_clear() -> int:
+    return getattr(_tls, "clear", 0)
+
+
 @contextlib.contextmanager
-def fwd_flags(flags: int):
+def fwd_flags(flags: int, clear: int = 0):
     """Every forward call made by this thread inside the block carries these extra ``la_fwd_args.flags`` (LA_FLAG_EXACT_RESCALE,
-    LA_FLAG_EXACT_ROWSUM, LA_FLAG_EXACT_EXP) - whichever surface it goes through (``LiteAttention.__call__``, ``flash_attn_func``, the
-    registered op, the varlen adapters): the reference's signatures have no argument for them. ``SeqParallelLiteAttention`` uses it to
-    get the reference's fp32-exact LSE for e4m3 inputs whose partial results are merged by LSE."""
-    if flags & ~(_cabi.LA_FLAG_EXACT_RESCALE | _cabi.LA_FLAG_EXACT_ROWSUM | _cabi.LA_FLAG_EXACT_EXP):
-        raise ValueError("fwd_flags accepts LA_FLAG_EXACT_RESCALE, LA_FLAG_EXACT_ROWSUM and LA_FLAG_EXACT_EXP only")
-    prev = _scoped_flags()
-    _tls.flags = prev | flags
+    LA_FLAG_FP8_MFMA_ROWSUM, LA_FLAG_FP8_ENCODED_P) - whichever surface it goes through (``LiteAttention.__call__``, ``flash_attn_func``, the
+    registered op, the varlen adapters): the reference's signatures have no argument for them. ``clear``: flags taken OUT of whatever the
+    host default (``LA_FP8_P``) or an outer block set: ``SeqParallelLiteAttention`` clears the two fp8 flags to get the reference's
+    fp32-exact LSE for e4m3 inputs whose partial results are merged by LSE, whatever form of P the process runs with otherwise."""
+    ok = _cabi.LA_FLAG_EXACT_RESCALE | _cabi.LA_FLAG_FP8_MFMA_ROWSUM | _cabi.LA_FLAG_FP8_ENCODED_P
+    if (flags | clear) & ~ok:
+        raise ValueError("fwd_flags accepts LA_FLAG_EXACT_RESCALE, LA_FLAG_FP8_MFMA_ROWSUM and LA_FLAG_FP8_ENCODED_P only")
+    prev, prev_clear = _scoped_flags(), _scoped_clear()
+    _tls.flags = (prev | flags) & ~clear
+    _tls.clear = (prev_clear | clear) & ~flags
     try:
         yield
     finally:
-        _tls.flags = prev
+        _tls.flags, _tls.clear = prev, prev_clear
 
 
 def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=None, cu_seqlens_k=None,
@@ -166,10 +173,10 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     windows compute). ``_static_sched`` sets LA_FLAG_STATIC_SCHED (per-item workgroups instead of persistent ones: a
     collective running beside the launch gets CUs as items retire); "after_first" sets it on every window but the first
     (no collective is in flight beside window 0). ``_flags``: extra ``LA_FLAG_*`` bits ORed into ``la_fwd_args.flags`` (tests / A/B:
-    LA_FLAG_EXACT_RESCALE, LA_FLAG_EXACT_ROWSUM, LA_FLAG_EXACT_EXP); kernel-selection bits that change the tile geometry are not accepted here."""
+    LA_FLAG_EXACT_RESCALE, LA_FLAG_FP8_MFMA_ROWSUM, LA_FLAG_FP8_ENCODED_P); kernel-selection bits that change the tile geometry are not accepted here."""
     _flags |= _scoped_flags()
-    if _flags & ~(_cabi.LA_FLAG_EXACT_RESCALE | _cabi.LA_FLAG_EXACT_ROWSUM | _cabi.LA_FLAG_EXACT_EXP):
-        raise ValueError("_flags accepts LA_FLAG_EXACT_RESCALE, LA_FLAG_EXACT_ROWSUM and LA_FLAG_EXACT_EXP only")
+    if _flags & ~(_cabi.LA_FLAG_EXACT_RESCALE | _cabi.LA_FLAG_FP8_MFMA_ROWSUM | _cabi.LA_FLAG_FP8_ENCODED_P):
+        raise ValueError("_flags accepts LA_FLAG_EXACT_RESCALE, LA_FLAG_FP8_MFMA_ROWSUM and LA_FLAG_FP8_ENCODED_P only")
     if not q.is_cuda:
         raise RuntimeError("lite_attention::fwd has no CPU implementation (HIP device tensors required)")
     if q.dtype not in (torch.bfloat16, torch.float16, torch.float8_e4m3fn):
@@ -321,7 +328,7 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     # caller-owned scratch (the C side allocates nothing): fp8 = the pre-transposed V tiles; bf16 with lists = the ticket
     # counter of the dynamic work distribution. Freed after the launch by the caching allocator's stream-ordered reuse.
     workspace = None
-    base_flags = (host_flags & ~(_cabi.LA_FLAG_KERNEL_128ROW if is_fp8 else 0)) | _flags
+    base_flags = ((host_flags & ~(_cabi.LA_FLAG_KERNEL_128ROW if is_fp8 else 0)) | _flags) & ~_scoped_clear()
     a.flags = base_flags | (_cabi.LA_FLAG_STATIC_SCHED if _static_sched is True else 0)
     need = _cabi.load().la_fwd_workspace_bytes(ctypes.byref(a))
     if need < 0:
@@ -476,9 +483,9 @@ def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
     a.num_heads, a.num_heads_k, a.head_dim, a.head_dim_v = H, Hk, D, D
     a.softmax_scale = float(softmax_scale)
     a.block_m, a.block_n = block_m, block_n
-    flags |= _scoped_flags()
-    a.flags = flags & ((_cabi.LA_FLAG_EXACT_ROWSUM | _cabi.LA_FLAG_EXACT_EXP | _cabi.LA_FLAG_STATIC_SCHED) if is_fp8 else
-                       (_cabi.LA_FLAG_KERNEL_128ROW | _cabi.LA_FLAG_EXACT_RESCALE | _cabi.LA_FLAG_STATIC_SCHED))
+    flags = (flags | _scoped_flags()) & ~_scoped_clear()
+    a.flags = flags & ((_cabi.LA_FLAG_FP8_MFMA_ROWSUM | _cabi.LA_FLAG_FP8_ENCODED_P | _cabi.LA_FLAG_STATIC_SCHED) if is_fp8 else
+                       (_cabi.GEOMETRY_FLAGS | _cabi.LA_FLAG_EXACT_RESCALE | _cabi.LA_FLAG_STATIC_SCHED))
     a.cu_seqlens_q, a.cu_seqlens_k, a.total_q = cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), Tq
     if attn_read_list is not None or is_fp8:      # ticket counters of the dynamic work distribution (as in the fixed-length path); fp8: + the V^T tiles
         need = _cabi.load().la_fwd_workspace_bytes(ctypes.byref(a))

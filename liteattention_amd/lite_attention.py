@@ -291,8 +291,9 @@ class SeqParallelLiteAttention:
         self.lite_attention = [LiteAttention(enable_skipping, threshold, max_batch_size) for _ in range(num_nodes)]
         self.set_threshold(threshold)
         # e4m3 inputs with return_softmax_lse=True: the caller merges partial results by that LSE (README.md:222-250), so the split
-        # runs with the reference's row sums (LA_FLAG_EXACT_ROWSUM: fp32 sums of the un-rounded P, softmax.h:275-296; fp32-exact LSE)
-        # instead of the faster default whose LSE carries the 8-bit encoding of P. Set False to keep the default form.
+        # runs with the reference's form of P and its row sums (fp32 sums of the un-rounded P, softmax.h:275-296; fp32-exact LSE) even
+        # when the process opted into a faster form (LA_FP8_P / fwd_flags), whose LSE carries the 8-bit rounding of P. Set False to keep
+        # whatever form is selected.
         self.exact_fp8_lse = True
 
     def __call__(self, query: Tensor, key: Tensor, value: Tensor, split_idx: int, scale: Optional[float] = None,
@@ -304,8 +305,8 @@ class SeqParallelLiteAttention:
             kw = dict(q_descale=q_descale, k_descale=k_descale, v_descale=v_descale)
         if return_softmax_lse and self.exact_fp8_lse and query.dtype == torch.float8_e4m3fn:
             from .flash_attn_interface import fwd_flags
-            from ._cabi import LA_FLAG_EXACT_ROWSUM
-            with fwd_flags(LA_FLAG_EXACT_ROWSUM):
+            from ._cabi import LA_FLAG_FP8_ENCODED_P, LA_FLAG_FP8_MFMA_ROWSUM
+            with fwd_flags(0, clear=LA_FLAG_FP8_ENCODED_P | LA_FLAG_FP8_MFMA_ROWSUM):
                 return self.lite_attention[split_idx](query, key, value, scale, return_softmax_lse, **kw)
         return self.lite_attention[split_idx](query, key, value, scale, return_softmax_lse, **kw)
 

@@ -267,7 +267,7 @@ class RingSeqParallelLiteAttention:
         self.states = SeqParallelLiteAttention(self.world, enable_skipping, threshold, max_batch_size)
         # test seams (CPU/gloo): attention_fn(q, k, v, split_idx, scale) -> (out, lse); combine_fn(outs, lses) -> out
         # e4m3 inputs: SeqParallelLiteAttention asks the library for the reference's row sums when the LSE is returned
-        # (LA_FLAG_EXACT_ROWSUM): the partial results are merged by it
+        # (it clears the two fp8 fast-form flags): the partial results are merged by it
         self._attention = attention_fn if attention_fn is not None else (
             lambda q, k, v, j, scale, **kw: self.states(q, k, v, j, scale, return_softmax_lse=True, **kw))
         if combine_fn is None:

@@ -50,26 +50,32 @@ def ref_tolerance(out_ref, pt_maxerr):
 def fp8_lse_tol_vs_exact():
     """Bound on |LSE - EXACT LSE| (the oracle with un-rounded P) for the fp8 kernel, by the form of P that is selected
     (include/lite_attention_amd.h):
-    default - the block-scaled log-linear byte encoding of P, row sums of the ENCODED P from the matrix pipe: every P~ / P lies in
+    LA_FP8_P=encoded (LA_FLAG_FP8_ENCODED_P) - the block-scaled log-linear byte encoding of P, row sums of the ENCODED P from the matrix pipe: every P~ / P lies in
       [0.920, 1.065] (tests/test_oracle.py scans it), so |ln(sum P~ / sum P)| <= -ln 0.920 = 0.083, reached only by rows of one or two
       comparable keys; on long rows the noise averages out and a bias of about -3e-4 remains;
-    LA_FP8_EXP=exact (LA_FLAG_EXACT_EXP) - v_exp_f32 + hardware e4m3 rounding, row sums of the ROUNDED P: every P~ within 2^-4 of its
+    LA_FP8_P=mfma_rowsum (LA_FLAG_FP8_MFMA_ROWSUM) - v_exp_f32 + hardware e4m3 rounding, row sums of the ROUNDED P: every P~ within 2^-4 of its
       P, ln(1 + 2^-4) = 0.0606 (1e-2 typical for a few keys; about -7e-4 of bias on long rows);
-    LA_FP8_ROWSUM=exact (LA_FLAG_EXACT_ROWSUM) - fp32 sums of the un-rounded P as in the reference (softmax.h:275-296): 1e-3, the bf16 bound."""
-    if os.environ.get("LA_FP8_ROWSUM", "").startswith("exact"):
+    default (the reference's arithmetic since round 6) - fp32 sums of the un-rounded P (softmax.h:275-296): 1e-3, the bf16 bound."""
+    form = fp8_form()
+    if form == "reference":
         return 1e-3
-    if os.environ.get("LA_FP8_EXP", "").startswith("exact"):
+    if form == "mfma_rowsum":
         return math.log1p(2.0 ** -4) + 1e-3
     return -math.log(0.920) + 1e-3
 
 
+def fp8_form():
+    """The fp8 form of P the process runs with (liteattention_amd._cabi.default_flags): "reference" (default), "mfma_rowsum", "encoded"."""
+    return os.environ.get("LA_FP8_P", "") or "reference"
+
+
 def fp8_lse_tol():
-    """Bound on |LSE - oracle IN THE SAME FORM of P| (``fp8_p_round()``). The exact forms: as ``fp8_lse_tol_vs_exact``. The default form:
+    """Bound on |LSE - oracle IN THE SAME FORM of P| (``fp8_p_round()``). The reference forms: as ``fp8_lse_tol_vs_exact``. The encoded form:
     since round 5 the oracle encodes P~ on the kernel's own grid (relative to the lazy reference maximum), so the two agree to ~1e-4 on
     all but the rows where a score sits on a byte boundary and the last bits of S (MFMA accumulation order vs the CPU's) decide it; one
     byte of a row's dominant key is a factor of up to 1.125 (e4m3 mantissa step at M = 0) = 0.118 in the LSE. So: 0.118 + 1e-3 for the
     worst row - and ``fp8_rows_off_grid`` holds the NUMBER of such rows down, which is what says the grids are the same."""
-    if os.environ.get("LA_FP8_ROWSUM", "").startswith("exact") or os.environ.get("LA_FP8_EXP", "").startswith("exact"):
+    if fp8_form() != "encoded":
         return fp8_lse_tol_vs_exact()
     return math.log(1.125) + 1e-3
 
@@ -84,9 +90,8 @@ def fp8_rows_off_grid(lse, lse_same_form, atol=0.01):
 
 def fp8_p_round():
     """The oracle's `p_round` that restates the form of P the fp8 kernel is running with (see fp8_lse_tol): "fp8_lin" for the default
-    log-linear byte encoding, "fp8" (the reference's e4m3 rounding of exp2) under LA_FP8_EXP=exact / LA_FP8_ROWSUM=exact."""
-    exact = os.environ.get("LA_FP8_ROWSUM", "").startswith("exact") or os.environ.get("LA_FP8_EXP", "").startswith("exact")
-    return "fp8" if exact else "fp8_lin"
+    log-linear byte encoding (LA_FP8_P=encoded), "fp8" (the reference's e4m3 rounding of exp2) for the default and LA_FP8_P=mfma_rowsum."""
+    return "fp8_lin" if fp8_form() == "encoded" else "fp8"
 
 
 def host_golden():

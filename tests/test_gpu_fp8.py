@@ -6,7 +6,7 @@ these cases (|O| <= ~2). Against the tiled oracle, which rounds P to e4m3 exactl
 0.05 * max|O| + 2e-2: v_exp_f32 and libm exp2f differ in the last fp32 bits, so a P that sits on an e4m3 rounding
 boundary can land one e4m3 step (6-12 % of that P) apart; with few keys one P carries O(1) of a row's weight.
 Still 3-5x tighter than the reference's own fp8 rule. The same bound holds for the default block-scaled log-linear byte encoding of P (round 3: per element
-within [-8.0 %, +6.5 %] of P against +-6.25 % for the hardware rounding, include/lite_attention_amd.h LA_FLAG_EXACT_EXP), checked against the oracle's
+within [-8.0 %, +6.5 %] of P against +-6.25 % for the hardware rounding, include/lite_attention_amd.h LA_FLAG_FP8_ENCODED_P), checked against the oracle's
 restatement of that encoding (p_round="fp8_lin", itself pinned against the reference-generated outputs in tests/test_oracle.py). LSE: `helpers.fp8_lse_tol()`
 per form of P. Every test of this module runs in all three forms."""
 import math
@@ -30,15 +30,14 @@ BM, BN = _tiles()
 
 @pytest.fixture(params=["encoded", "exp", "exact"], autouse=True)
 def p_mode(request, monkeypatch):
-    """The three forms of P in the fp8 kernel: the default (log-linear byte encoding, row sums of the encoded P from the matrix pipe),
-    LA_FP8_EXP=exact -> LA_FLAG_EXACT_EXP (v_exp_f32 + hardware e4m3 rounding, row sums of the rounded P from the matrix pipe) and
-    LA_FP8_ROWSUM=exact -> LA_FLAG_EXACT_ROWSUM (that, with the fp32 sum of the un-rounded P on the vector unit: the reference's form)."""
-    monkeypatch.delenv("LA_FP8_ROWSUM", raising=False)
-    monkeypatch.delenv("LA_FP8_EXP", raising=False)
-    if request.param == "exact":
-        monkeypatch.setenv("LA_FP8_ROWSUM", "exact")
+    """The three forms of P in the fp8 kernel: LA_FP8_P=encoded -> LA_FLAG_FP8_ENCODED_P (log-linear byte encoding, row sums of the encoded
+    P from the matrix pipe), LA_FP8_P=mfma_rowsum -> LA_FLAG_FP8_MFMA_ROWSUM (v_exp_f32 + hardware e4m3 rounding, row sums of the rounded P
+    from the matrix pipe) and the DEFAULT (that, with the fp32 sum of the un-rounded P on the vector unit: the reference's form)."""
+    monkeypatch.delenv("LA_FP8_P", raising=False)
+    if request.param == "encoded":
+        monkeypatch.setenv("LA_FP8_P", "encoded")
     elif request.param == "exp":
-        monkeypatch.setenv("LA_FP8_EXP", "exact")
+        monkeypatch.setenv("LA_FP8_P", "mfma_rowsum")
     return request.param
 
 

@@ -243,8 +243,8 @@ def test_longest_supported_key_sequence_and_the_typed_error_beyond_it(dtype):
     tol = 0.05 * ref.abs().max().item() + 2e-2 if dtype == "fp8" else 2.0 ** -7 * ref.abs().max().item() + 1e-3
     assert (out.float()[0, :, 0] - ref).abs().max().item() <= tol
     # fp8 default: row sums of the encoded P. Over 288 k keys the noise averages out but its BIAS does not (log-linear encoding: about
-    # -3e-4; hardware rounding under LA_FLAG_EXACT_EXP: P is log-uniform inside an e4m3 rounding interval, so round-to-nearest loses
-    # (step / value)^2 / 12 ~ 7e-4 of the sum, every row low); LA_FLAG_EXACT_ROWSUM has neither (tests/test_gpu_fp8.py runs all three)
+    # -3e-4; hardware rounding under LA_FLAG_FP8_MFMA_ROWSUM: P is log-uniform inside an e4m3 rounding interval, so round-to-nearest loses
+    # (step / value)^2 / 12 ~ 7e-4 of the sum, every row low); the default form (fp32 row sums) has neither (tests/test_gpu_fp8.py runs all three)
     assert (lse[0, 0] - torch.logsumexp(sc, -1)).abs().max().item() <= (2.5e-3 if dtype == "fp8" else 1e-3)
     assert att.get_skip_fraction() == 0.0
     too_long = torch.zeros(1, 40000 * 64, H, D, dtype=q.dtype, device="cuda")

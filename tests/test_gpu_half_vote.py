@@ -85,8 +85,8 @@ def _rows_to_lists(rows, Kt):
 @pytest.mark.parametrize("thr", [-2.0, -5.0])
 def test_lists_over_steps_match_the_oracle_at_128_rows(half, S, thr):
     """Five denoising-like steps through LiteAttention: lists [2, B, H, ceil(S / 128), Kt + 1]; at every step the oracle gets the kernel's
-    read list. S = 1000 / 700: the last workgroup has a partial (1000: 3 x 256 + 232) or a MISSING second half (700 = 2 x 256 + 188: rows
-    640..699 are half 0 of item 2... and 5.47 -> 6 list rows, the sixth has 60 rows)."""
+    read list. S = 1000: the last workgroup's second half is partial (rows 896..999); S = 700: 6 list rows, the last one of 60 rows; S = 1536:
+    whole workgroups."""
     L, orc = half
     B, H = 1, 3
     att = L.LiteAttention(threshold=thr, max_batch_size=B)
@@ -102,9 +102,9 @@ def test_lists_over_steps_match_the_oracle_at_128_rows(half, S, thr):
         margins = torch.empty(B, H, Qt, Kt)
         o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN, read_list=rd, write_list=wr_orc, thr=thr, margins=margins,
                                            must_do_list=orc.expand_must_do_ref([0, 0], BN, Kt + 1))
-        assert (out.float().cpu() - o_ref).abs().max().item() <= _tol(o_ref)
-        assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
-        assert _bad_rows(rd, wr, wr_orc, margins, thr) == 0
+        assert (out.float().cpu() - o_ref).abs().max().item() <= 2.0 ** -7 * o_ref.abs().max().item() + 1e-3, step   # peaked rows: tests/test_gpu_fragmented.py
+        assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3, step
+        assert _bad_rows(rd, wr, wr_orc, margins, thr) == 0, step
         dropped = Qt * Kt * H - orc.listed_tiles(wr)
     assert dropped > 0                                 # the thresholds really skip on this data
     # and the two halves of a workgroup really differ somewhere (otherwise this test says nothing about the union walk)

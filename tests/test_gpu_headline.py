@@ -10,8 +10,8 @@ hopper/tests/test_flash_attn.py:152-177; property style of test_gpu_parity.py::t
   * dynamic (ticket queues, persistent workgroups) == static (one workgroup per item, XCD map) bit-exactly: O, LSE, lists;
   * >= 256 sampled query rows per checked head against an fp32 torch attention over exactly the listed keys:
         bf16: |O - ref| <= 2^-8 max|ref| + 1e-4      fp8: |O - ref| <= 0.05 max|ref| + 1e-3 (P is an 8-bit quantity)
-        LSE:  |LSE - ref| <= 2e-4 (bf16, and fp8 with LA_FLAG_EXACT_ROWSUM: one missing 64-key tile of a 43 k-key row moves the LSE
-              by 1.5e-3, so a skipped, doubled or mis-masked tile cannot hide); fp8 default and LA_FLAG_EXACT_EXP <= 2.5e-3: the row sums are those
+        LSE:  |LSE - ref| <= 2e-4 (bf16, and fp8 in its default form - the reference's fp32 row sums: one missing 64-key tile of a 43 k-key row moves the LSE
+              by 1.5e-3, so a skipped, doubled or mis-masked tile cannot hide); fp8 under LA_FLAG_FP8_ENCODED_P / LA_FLAG_FP8_MFMA_ROWSUM <= 2.5e-3: the row sums are those
               of the ENCODED P, whose noise averages out over a long row but whose bias (about -3e-4 / -7e-4) does not. The walk is
               the same code in all three fp8 forms.
 """
@@ -34,13 +34,15 @@ def qkv():
 @pytest.mark.parametrize("sparsity", [0.42, 0.77, None])
 def test_headline_shape(qkv, dtype, sparsity, monkeypatch):
     import liteattention_amd as L
-    exact_rowsum = dtype == "fp8-exact-rowsum"                            # LA_FLAG_EXACT_ROWSUM: the reference's fp32 row sums
+    monkeypatch.delenv("LA_FP8_P", raising=False)
+    exact_rowsum = dtype == "fp8-exact-rowsum"                            # the default form: the reference's arithmetic, fp32 row sums
     if exact_rowsum:
-        monkeypatch.setenv("LA_FP8_ROWSUM", "exact")
         dtype = "fp8"
-    if dtype == "fp8-exact-exp":                                          # LA_FLAG_EXACT_EXP: v_exp_f32 + hardware e4m3 rounding of P
-        monkeypatch.setenv("LA_FP8_EXP", "exact")
+    elif dtype == "fp8-exact-exp":                                        # LA_FLAG_FP8_MFMA_ROWSUM: v_exp_f32 + hardware e4m3 rounding of P, row sums of the rounded P
+        monkeypatch.setenv("LA_FP8_P", "mfma_rowsum")
         dtype = "fp8"
+    elif dtype == "fp8":                                                  # LA_FLAG_FP8_ENCODED_P: the block-scaled byte encoding
+        monkeypatch.setenv("LA_FP8_P", "encoded")
     from tools import selfcheck as sc
     from liteattention_amd.flash_attn_interface import mha_fwd
     fp8 = dtype == "fp8"

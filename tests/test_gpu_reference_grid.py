@@ -80,14 +80,13 @@ def test_lite_attn_output(seqlen_q, seqlen_k, d, dtype):
 @pytest.mark.parametrize("seqlen_q,seqlen_k", SEQLENS)
 def test_lite_attn_output_e4m3(seqlen_q, seqlen_k, form, monkeypatch):
     """The e4m3 column of the same grid at head_dim 128 (the fp8 kernels' head dim; fp8 is compiled out of the reference's default build,
-    hopper/setup.py:56): the default block-scaled encoding of P and the reference's arithmetic (LA_FLAG_EXACT_ROWSUM), against the C oracle
+    hopper/setup.py:56): the block-scaled encoding of P (LA_FLAG_FP8_ENCODED_P) and the default form (the reference's arithmetic), against the C oracle
     in the same form, with the fp8 tolerances of tests/test_gpu_fp8.py."""
     import liteattention_amd as L
     from oracle import oracle as orc
-    monkeypatch.delenv("LA_FP8_EXP", raising=False)
-    monkeypatch.delenv("LA_FP8_ROWSUM", raising=False)
-    if form == "exact":
-        monkeypatch.setenv("LA_FP8_ROWSUM", "exact")
+    monkeypatch.delenv("LA_FP8_P", raising=False)
+    if form == "encoded":
+        monkeypatch.setenv("LA_FP8_P", "encoded")
     B, H, q, k, v, _ = _inputs(seqlen_q, seqlen_k, 128, F8)
     att = L.LiteAttention(enable_skipping=True, threshold=THR, max_batch_size=B)
     out, lse = att(q, k, v, return_softmax_lse=True)
@@ -127,11 +126,10 @@ def test_flash_attn_output(seqlen_q, seqlen_k, d, mha_type, dtype):
 @pytest.mark.parametrize("seqlen_q,seqlen_k", SEQLENS)
 def test_flash_attn_output_e4m3(seqlen_q, seqlen_k, mha_type, monkeypatch):
     """The e4m3 column of that test (head_dim 128; descales drawn as at :214: rand(batch, K/V heads) * 2), in the reference's arithmetic
-    (LA_FLAG_EXACT_ROWSUM) against the C oracle with the same descales."""
+    (the default form) against the C oracle with the same descales."""
     import liteattention_amd as L
     from oracle import oracle as orc
-    monkeypatch.delenv("LA_FP8_EXP", raising=False)
-    monkeypatch.setenv("LA_FP8_ROWSUM", "exact")
+    monkeypatch.delenv("LA_FP8_P", raising=False)              # the default form IS the reference's arithmetic
     torch.random.manual_seed(0)
     B, H = (9 if seqlen_k <= 2048 else 2), 6
     Hk = H if mha_type == "mha" else (2 if mha_type == "gqa" else 1)

@@ -247,13 +247,12 @@ def test_fp8_four_split_merge_against_the_fp8_oracle_on_the_full_keys(form, monk
     each), partial results merged by their LSE (flash_attn_combine; oracle hopper/tests/test_flash_attn.py:1178-1187) - against the
     fp8 oracle (the reference's arithmetic, p_round='fp8', softmax.h:85-87,275-296) on the FULL K/V, under the stated fp8 bound
     (0.05 max|O| + 2e-2), in all three forms of P. `seq_parallel_default` is what the class does by itself for e4m3 inputs with
-    return_softmax_lse=True: LA_FLAG_EXACT_ROWSUM, so the merged LSE is fp32-exact (1e-3); the two forms whose row sums are those of the
+    return_softmax_lse=True even inside a block that opted into the encoded form: it clears the fast-form flags, so the merged LSE is fp32-exact (1e-3); the two forms whose row sums are those of the
     8-bit P carry that noise into the merge weights: their merged LSE is held to the per-form bound of tests/helpers.py and their
     merged O to the same fp8 bound."""
     from liteattention_amd import _cabi as C
     from liteattention_amd.flash_attn_interface import fwd_flags
-    for v_ in ("LA_FP8_EXP", "LA_FP8_ROWSUM"):
-        monkeypatch.delenv(v_, raising=False)
+    monkeypatch.delenv("LA_FP8_P", raising=False)
     F8 = torch.float8_e4m3fn
     B, Sq, Sk, H, Hk, D, G = 1, 700, 2048, 4, 2, 128, 4
     g = torch.Generator().manual_seed(33)
@@ -262,7 +261,7 @@ def test_fp8_four_split_merge_against_the_fp8_oracle_on_the_full_keys(form, monk
     v = torch.randn(B, Sk, Hk, D, generator=g).to(F8)
     qd, kd, vd = [(0.5 + torch.rand(B, Hk, generator=g)) for _ in range(3)]
     sp = L.SeqParallelLiteAttention(G, threshold=-30.0, max_batch_size=B)
-    flags = {"seq_parallel_default": 0, "encoded": 0, "exact_exp": C.LA_FLAG_EXACT_EXP, "exact_rowsum": C.LA_FLAG_EXACT_ROWSUM}[form]
+    flags = {"seq_parallel_default": C.LA_FLAG_FP8_ENCODED_P, "encoded": C.LA_FLAG_FP8_ENCODED_P, "exact_exp": C.LA_FLAG_FP8_MFMA_ROWSUM, "exact_rowsum": 0}[form]
     sp.exact_fp8_lse = form == "seq_parallel_default"
     outs, lses = [], []
     Sl = Sk // G

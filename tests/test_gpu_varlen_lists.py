@@ -141,10 +141,8 @@ def test_fp8_packed_batch_equals_the_fixed_length_path(with_lists, p_mode, monke
     thr = -2.5) the write list bit for bit; GQA, an empty query sequence, a sequence without keys, one shorter than a tile."""
     import liteattention_amd as L
     from liteattention_amd.flash_attn_interface import mha_fwd
-    monkeypatch.delenv("LA_FP8_ROWSUM", raising=False)
-    monkeypatch.delenv("LA_FP8_EXP", raising=False)
-    if p_mode == "exp":
-        monkeypatch.setenv("LA_FP8_EXP", "exact")
+    monkeypatch.delenv("LA_FP8_P", raising=False)
+    monkeypatch.setenv("LA_FP8_P", "mfma_rowsum" if p_mode == "exp" else "encoded")
     F8 = torch.float8_e4m3fn
     D, H, Hk, thr = 128, 4, 2, -2.5
     bm, bn = L.get_tile_sizes(D, 1)

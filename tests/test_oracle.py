@@ -195,7 +195,7 @@ def test_fp8_oracle_matches_reference_outputs(name):
 
 @pytest.mark.parametrize("name", FP8_CASES + ["gqa_fp8_b1_s260_h4_hk2_d128"])
 def test_fp8_log_linear_encoding_of_p_stays_inside_the_reference_rule(name):
-    """The build's default fp8 form of P (NOT the reference's: include/lite_attention_amd.h LA_FLAG_EXACT_EXP; oracle p_round="fp8_lin")
+    """The build's default fp8 form of P (NOT the reference's: include/lite_attention_amd.h LA_FLAG_FP8_ENCODED_P; oracle p_round="fp8_lin")
     against the reference-generated fp8 outputs: inside the reference's own rule with room to spare, LSE within the bound
     tests/helpers.py::fp8_lse_tol states for it.
 

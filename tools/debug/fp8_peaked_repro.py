@@ -21,4 +21,4 @@ for step in range(steps):
     o_exact, _, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=rd, write_list=torch.zeros_like(wr), must_do_list=md_row, thr=thr, p_round=False, softmax_scale=scale)
     eo = (out.float().cpu() - o_ref).abs().max().item()
     ex = (out.float().cpu() - o_exact).abs().max().item()
-    print(f"form {os.environ.get('LA_FP8_ROWSUM','') or os.environ.get('LA_FP8_EXP','') or 'default'} step {step}: |O - oracle(same form)| {eo:.4f}  |O - fp32-P oracle| {ex:.4f}  tol {0.05 * o_ref.abs().max().item() + 2e-2:.4f}  max|O| {o_ref.abs().max().item():.3f}")
+    print(f"form {os.environ.get('LA_FP8_P','') or 'reference (default)'} step {step}: |O - oracle(same form)| {eo:.4f}  |O - fp32-P oracle| {ex:.4f}  tol {0.05 * o_ref.abs().max().item() + 2e-2:.4f}  max|O| {o_ref.abs().max().item():.3f}")

@@ -1,6 +1,6 @@
 """GPU box: what the fp8 kernel's form of P costs in accuracy where the TAIL of the softmax carries mass: the step-49 tensors and READ lists
 of the 50-step run (S = 75 600, H = 40, anchor keys + diffuse frames: tests/test_gpu_denoise_lists.py) and a dense randn case, sampled rows
-against fp32 torch. One line per (library variant, LA_FP8_EXP / LA_FP8_ROWSUM setting): max |O - ref|, its tolerance, max |LSE - ref|, ms.
+against fp32 torch. One line per (library variant, LA_FP8_P setting): max |O - ref|, its tolerance, max |LSE - ref|, ms.
     LITEATTENTION_AMD_LIB=build_variants/f8_tau2.so python tools/debug/fp8_tail_probe.py [thr]"""
 import os, sys, time
 import torch
@@ -22,9 +22,9 @@ q8, k8, v8 = [x.to(F8) for x in (q, k, v)]
 must_do = torch.zeros(kt + 1, dtype=torch.int32, device="cuda"); must_do[0] = 2
 name = os.path.basename(os.environ.get("LITEATTENTION_AMD_LIB", "tree"))
 for mode in ("default", "exp", "rowsum"):
-    os.environ.pop("LA_FP8_EXP", None); os.environ.pop("LA_FP8_ROWSUM", None)
-    if mode == "exp": os.environ["LA_FP8_EXP"] = "exact"
-    if mode == "rowsum": os.environ["LA_FP8_ROWSUM"] = "exact"
+    os.environ.pop("LA_FP8_P", None)                      # "rowsum" = the default form (the reference's arithmetic)
+    if mode == "exp": os.environ["LA_FP8_P"] = "mfma_rowsum"
+    if mode not in ("exp", "rowsum"): os.environ["LA_FP8_P"] = "encoded"
     wr = torch.full_like(read, -7)
     f = lambda: L.flash_attn_func(q8, k8, v8, attn_read_list=read, attn_must_do_list=must_do, attn_write_list=wr, thr=float("-inf"), return_softmax_lse=True)
     out, lse = f(); torch.cuda.synchronize()

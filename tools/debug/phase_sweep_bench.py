@@ -19,8 +19,8 @@ for D in (64, 96, 128, 192, 256):
 S, H, D = 75600, 40, 128
 g = torch.Generator(device="cuda").manual_seed(0)
 q, k, v = [torch.randn(1, S, H, D, device="cuda", generator=g).bfloat16().to(torch.float8_e4m3fn) for _ in range(3)]
-for form, env in (("fp8", {}), ("fp8exp", {"LA_FP8_EXP": "exact"}), ("fp8exact", {"LA_FP8_ROWSUM": "exact"})):
-    os.environ.pop("LA_FP8_EXP", None); os.environ.pop("LA_FP8_ROWSUM", None); os.environ.update(env)
+for form, env in (("fp8", {"LA_FP8_P": "encoded"}), ("fp8exp", {"LA_FP8_P": "mfma_rowsum"}), ("fp8exact", {})):
+    os.environ.pop("LA_FP8_P", None); os.environ.update(env)
     att = L.LiteAttention(max_batch_size=1); att.threshold = float("-inf"); att(q, k, v)
     rows = banded_rows(-(-S // 256), -(-S // 64), 256, 64, 0.42); impose_lists(att, rows)
     ms, n = steady_state_ms(lambda: att(q, k, v), 27.0, timed_ms=400.0)

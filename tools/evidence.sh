@@ -49,13 +49,13 @@ for t in d64 d96 d128 d192 d256; do
 done
 # the hipcc-scheduled A/B kernels on the same box (head dims 192 / 96 zero-padded onto 256 / 128 by the host)
 want other && LA_FWD_KERNEL=v2 python $R/tools/d256_bench.py > $OUT/v2_bench.txt 2>&1
-# 5b. fp8: the three forms of P (default block-scaled log-linear encoding / LA_FP8_EXP=exact / LA_FP8_ROWSUM=exact) on the same box: banded
+# 5b. fp8: the three forms of P (LA_FP8_P=encoded / mfma_rowsum / the default = the reference's arithmetic; labelled default / exp / rowsum as in rounds 3-5) on the same box: banded
 #     headline lists (ms, TFLOP/s) and the real step-49 lists with the error against fp32 torch on sampled rows
 if want fp8forms; then
   { for m in default exp rowsum; do
-      unset LA_FP8_EXP LA_FP8_ROWSUM; [ $m = exp ] && export LA_FP8_EXP=exact; [ $m = rowsum ] && export LA_FP8_ROWSUM=exact
+      unset LA_FP8_P; [ $m = exp ] && export LA_FP8_P=mfma_rowsum; [ $m = default ] && export LA_FP8_P=encoded
       echo "P form $m: $(python $R/tools/fp8_quick.py 2>&1 | grep 's=')"
-    done; unset LA_FP8_EXP LA_FP8_ROWSUM
+    done; unset LA_FP8_P
     python $R/tools/debug/fp8_tail_probe.py -4.22 2>&1 | grep "real lists"
     python $R/tools/debug/fp8_tail_probe.py -2.462 2>&1 | grep "real lists"; } > $OUT/fp8_p_forms.txt 2>&1
 fi
