@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LA_ABI_VERSION 8   /* 8 = 7 with the sense of the two fp8 flags turned round (the reference's arithmetic is the default form of P) + LA_FLAG_HALF_VOTE;
+#define LA_ABI_VERSION 8   /* 8 = 7 with the sense of the two fp8 flags turned round (the reference's arithmetic is the default form of P) + LA_FLAG_HALF_VOTE + la_combine_list;
                             * 7 = 6 + la_build_info; 6 = 5 + la_blockmask_to_lists, la_device_slots (5 = 4 + skip lists and fp8 with cu_seqlens, LA_FLAG_EXACT_ROWSUM /
                             * LA_FLAG_EXACT_EXP (renamed and inverted in 8), LA_DTYPE_FP32 for la_combine); la_fwd_args unchanged since 4 */
 
@@ -235,6 +235,15 @@ int la_skip_list_stats(const int32_t* list, int32_t n_batch, int32_t num_heads, 
 int la_combine(const void* o_partial, int32_t partial_is_16bit, const float* lse_partial,
                void* o, int32_t o_dtype, float* lse, int32_t num_splits, int32_t batch, int32_t seqlen_q,
                int32_t num_heads, int32_t head_dim_v, void* stream);
+
+/* The same merge when the partials of the splits are SEPARATE tensors - what the calls of a split attention return, e.g. the t2t / t2v / v2t / v2v
+ * calls of the reference's text + video recipe (README.md:225-246), or a ring step: stacking them into one [num_splits, ...] tensor first would
+ * move every partial once more than the merge itself does. o_partials / lse_partials: HOST arrays of num_splits <= LA_COMBINE_LIST_MAX device
+ * pointers, each partial [B, Sq, H, Dv] contiguous (fp32, or the element type of o when partial_is_16bit), each LSE fp32 [B, H, Sq] contiguous. */
+#define LA_COMBINE_LIST_MAX 8
+int la_combine_list(const void* const* o_partials, int32_t partial_is_16bit, const float* const* lse_partials,
+                    void* o, int32_t o_dtype, float* lse, int32_t num_splits, int32_t batch, int32_t seqlen_q,
+                    int32_t num_heads, int32_t head_dim_v, void* stream);
 
 /* Static block mask -> read-list rows, on the device (one wave per row; no host round trip).
  *   blockmask      uint8 (0 = tile masked out, non-zero = computed), rows [q_tiles, k_tiles] contiguous; element strides between

@@ -16,7 +16,7 @@ if not _BUILDING:
     _cabi.load()
 
 if not _BUILDING:
-    from .flash_attn_interface import (flash_attn_combine, flash_attn_func, get_tile_sizes,  # noqa: E402
+    from .flash_attn_interface import (combine_partials, flash_attn_combine, flash_attn_func, get_tile_sizes,  # noqa: E402
                                        skip_list_stats)
     from .lite_attention import LiteAttention, SeqParallelLiteAttention  # noqa: E402
     from .compat import (blockmask_to_skip_lists, fa2_flash_attn_func, flash_attn_varlen_func,  # noqa: E402
@@ -25,7 +25,7 @@ if not _BUILDING:
     from .parallel import (HeadShardedLiteAttention, RingSeqParallelLiteAttention,  # noqa: E402
                            UlyssesLiteAttention)
 
-__all__ = ["LiteAttention", "SeqParallelLiteAttention", "flash_attn_func", "flash_attn_combine",
+__all__ = ["LiteAttention", "SeqParallelLiteAttention", "flash_attn_func", "flash_attn_combine", "combine_partials",
            "get_tile_sizes", "skip_list_stats", "fa2_flash_attn_func", "flash_attn_varlen_func",
            "flash_blocksparse_attn_func", "flash_blocksparse_attn_qkvpacked_func", "blockmask_to_skip_lists", "calibrate_threshold",
            "HeadShardedLiteAttention", "UlyssesLiteAttention", "RingSeqParallelLiteAttention", "__version__"]

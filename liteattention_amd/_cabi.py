@@ -25,7 +25,7 @@ LA_ERR_Q_WINDOW = -13
 
 EXPORTED_SYMBOLS = (
     "la_abi_version", "la_get_tile_sizes", "la_get_tile_sizes_ex", "la_fwd", "la_fwd_workspace_bytes", "la_skip_list_stats", "la_combine",
-    "la_status_string", "la_last_hip_error", "la_blockmask_to_lists", "la_device_slots", "la_build_info",
+    "la_status_string", "la_last_hip_error", "la_blockmask_to_lists", "la_device_slots", "la_build_info", "la_combine_list",
 )
 
 
@@ -140,6 +140,9 @@ def load() -> ctypes.CDLL:
                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                ctypes.c_void_p]
     lib.la_combine.restype = ctypes.c_int
+    lib.la_combine_list.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int32,
+                                    ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    lib.la_combine_list.restype = ctypes.c_int
     lib.la_blockmask_to_lists.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.la_blockmask_to_lists.restype = ctypes.c_int

@@ -307,4 +307,23 @@ int la_combine(const void* o_partial, int32_t partial_is_16bit, const float* lse
     return LA_OK;
 }
 
+int la_combine_list(const void* const* o_partials, int32_t partial_is_16bit, const float* const* lse_partials, void* o, int32_t o_dtype,
+                    float* lse, int32_t num_splits, int32_t batch, int32_t seqlen_q, int32_t num_heads, int32_t head_dim_v, void* stream_) {
+    if (!o_partials || !lse_partials || !o) return LA_ERR_NULL_ARG;
+    if (o_dtype != LA_DTYPE_BF16 && o_dtype != LA_DTYPE_FP16 && o_dtype != LA_DTYPE_FP32) return LA_ERR_DTYPE;
+    if (o_dtype == LA_DTYPE_FP32 && partial_is_16bit) return LA_ERR_DTYPE;
+    if (num_splits <= 0 || num_splits > LA_COMBINE_LIST_MAX || batch <= 0 || seqlen_q <= 0 || num_heads <= 0 || head_dim_v <= 0) return LA_ERR_SHAPE;
+    if (head_dim_v % 8 != 0) return LA_ERR_HEAD_DIM;
+    if (!aligned16(o)) return LA_ERR_STRIDE;
+    for (int i = 0; i < num_splits; ++i) {
+        if (!o_partials[i] || !lse_partials[i]) return LA_ERR_NULL_ARG;
+        if (!aligned16(o_partials[i])) return LA_ERR_STRIDE;
+    }
+    const hipError_t err = la::launch_combine_list(o_partials, partial_is_16bit != 0, o_dtype == LA_DTYPE_FP16, lse_partials, static_cast<uint16_t*>(o),
+                                                   lse, num_splits, batch, seqlen_q, num_heads, head_dim_v, static_cast<hipStream_t>(stream_),
+                                                   o_dtype == LA_DTYPE_FP32);
+    if (err != hipSuccess) { g_last_hip_error = static_cast<int>(err); return LA_ERR_LAUNCH; }
+    return LA_OK;
+}
+
 }  // extern "C"

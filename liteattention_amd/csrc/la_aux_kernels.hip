@@ -182,13 +182,21 @@ hipError_t launch_empty_k_fill(uint16_t* o, float* lse, int64_t o_batch_stride, 
     return hipGetLastError();
 }
 
+// la_combine_list: the partials of the splits are SEPARATE tensors (what the calls of a split attention return, e.g. the four calls of
+// the reference's text / video recipe, README.md:225-246): stacking them first would move every partial once more than the merge itself.
+constexpr int kCombineListMax = 8;
+struct CombineList {
+    const void* o[kCombineListMax];
+    const float* lse[kCombineListMax];
+};
+
 // One thread = 8 consecutive d of one (b, s, h) row. Memory-bound; 16-byte accesses.
-template <bool PARTIAL_16BIT, bool F16, bool OUT_F32 = false>     // 16-bit partials have the element type of o (bf16, or fp16 when F16); OUT_F32: o is fp32
+template <bool PARTIAL_16BIT, bool F16, bool OUT_F32 = false, bool LIST = false>     // 16-bit partials have the element type of o (bf16, or fp16 when F16); OUT_F32: o is fp32
 __global__ void __launch_bounds__(256) combine_kernel(const void* __restrict__ o_partial,
                                                        const float* __restrict__ lse_partial,
                                                        uint16_t* __restrict__ o, float* __restrict__ lse_out,
                                                        int num_splits, int batch, int seqlen_q, int num_heads,
-                                                       int dv) {
+                                                       int dv, const CombineList list = CombineList{}) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x8 __attribute__((ext_vector_type(8)));
     typedef typename Elem16<F16>::x8 ex8;
@@ -206,22 +214,23 @@ __global__ void __launch_bounds__(256) combine_kernel(const void* __restrict__ o
         const int b = static_cast<int>(bs / seqlen_q);
         const int64_t lse_idx = (static_cast<int64_t>(b) * num_heads + hh) * seqlen_q + s;
         float m = -INFINITY;
-        for (int sp = 0; sp < num_splits; ++sp) m = fmaxf(m, lse_partial[sp * split_rows + lse_idx]);
+        for (int sp = 0; sp < num_splits; ++sp) m = fmaxf(m, LIST ? list.lse[sp][lse_idx] : lse_partial[sp * split_rows + lse_idx]);
         float denom = 0.f;
         f32x8 acc = {0, 0, 0, 0, 0, 0, 0, 0};
         const float m_safe = (m == -INFINITY) ? 0.f : m;
         for (int sp = 0; sp < num_splits; ++sp) {
-            const float l = lse_partial[sp * split_rows + lse_idx];
+            const float l = LIST ? list.lse[sp][lse_idx] : lse_partial[sp * split_rows + lse_idx];
             const float w = (l == -INFINITY) ? 0.f : __expf(l - m_safe);
             denom += w;
-            const int64_t off = sp * split_elems + row * dv + ch * 8;
+            const int64_t off = (LIST ? 0 : sp * split_elems) + row * dv + ch * 8;
+            const void* const src = LIST ? list.o[sp] : o_partial;
             f32x8 x;
             if (PARTIAL_16BIT) {
-                const ex8 t = *reinterpret_cast<const ex8*>(static_cast<const uint16_t*>(o_partial) + off);
+                const ex8 t = *reinterpret_cast<const ex8*>(static_cast<const uint16_t*>(src) + off);
                 x = __builtin_convertvector(t, f32x8);
             } else {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(static_cast<const float*>(o_partial) + off);
-                const f32x4 c = *reinterpret_cast<const f32x4*>(static_cast<const float*>(o_partial) + off + 4);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(static_cast<const float*>(src) + off);
+                const f32x4 c = *reinterpret_cast<const f32x4*>(static_cast<const float*>(src) + off + 4);
                 x = __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7);
             }
             acc += x * w;
@@ -266,6 +275,30 @@ hipError_t launch_combine(const void* o_partial, bool partial_is_16bit, bool f16
         launch_combine_t<false, true>(g, stream, o_partial, lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v);
     else
         launch_combine_t<false, false>(g, stream, o_partial, lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v);
+    return hipGetLastError();
+}
+
+// The same merge over separately allocated partials (host arrays of num_splits <= 8 device pointers).
+hipError_t launch_combine_list(const void* const* o_partials, bool partial_is_16bit, bool f16, const float* const* lse_partials, uint16_t* o,
+                               float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v, hipStream_t stream,
+                               bool out_f32) {
+    if (num_splits < 1 || num_splits > kCombineListMax) return hipErrorInvalidValue;
+    CombineList list{};
+    for (int i = 0; i < num_splits; ++i) { list.o[i] = o_partials[i]; list.lse[i] = lse_partials[i]; }
+    const int64_t total = static_cast<int64_t>(batch) * seqlen_q * num_heads * (head_dim_v / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    (void)hipGetLastError();
+    const dim3 g(static_cast<unsigned>(blocks)), b(256);
+#define LA_COMBINE_LIST(P16, F16_, F32_) \
+    hipLaunchKernelGGL((combine_kernel<P16, F16_, F32_, true>), g, b, 0, stream, nullptr, nullptr, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v, list)
+    if (out_f32) LA_COMBINE_LIST(false, false, true);
+    else if (partial_is_16bit && f16) LA_COMBINE_LIST(true, true, false);
+    else if (partial_is_16bit) LA_COMBINE_LIST(true, false, false);
+    else if (f16) LA_COMBINE_LIST(false, true, false);
+    else LA_COMBINE_LIST(false, false, false);
+#undef LA_COMBINE_LIST
     return hipGetLastError();
 }
 

@@ -105,4 +105,8 @@ hipError_t launch_combine(const void* o_partial, bool partial_is_16bit, bool f16
                           float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v,
                           hipStream_t stream, bool out_f32 = false);
 
+hipError_t launch_combine_list(const void* const* o_partials, bool partial_is_16bit, bool f16, const float* const* lse_partials, uint16_t* o,
+                               float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v, hipStream_t stream,
+                               bool out_f32 = false);
+
 }  // namespace la

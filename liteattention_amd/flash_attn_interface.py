@@ -26,7 +26,7 @@ import torch
 
 from . import _cabi
 
-__all__ = ["flash_attn_func", "FlashAttnFunc", "flash_attn_combine", "mha_combine", "fwd_flags", "get_tile_sizes", "skip_list_stats"]
+__all__ = ["flash_attn_func", "FlashAttnFunc", "flash_attn_combine", "combine_partials", "mha_combine", "fwd_flags", "get_tile_sizes", "skip_list_stats"]
 
 _FWD_SCHEMA = (
     "fwd("
@@ -108,6 +108,16 @@ def device_slots(head_dim: int, element_size: int) -> Tuple[int, int]:
         element_size = 2
     flags = _cabi.default_flags()
     return _cabi.device_slots(kernel_head_dim(head_dim, element_size, flags), element_size, flags)
+
+
+def q_tiles_per_item(head_dim: int, element_size: int) -> int:
+    """q-tiles (rows of the skip lists) one workgroup item of the kernel covers: 2 under LA_FLAG_HALF_VOTE at bf16 / fp16 head_dim 128 (lists
+    per 128-row half of a 256-row workgroup: q-tile windows then start on an even q-tile and hold an even number unless they reach the
+    last one), else 1."""
+    flags = _cabi.default_flags()
+    half = (flags & _cabi.LA_FLAG_HALF_VOTE) and not (flags & _cabi.LA_FLAG_KERNEL_128ROW) and element_size == 2 \
+        and kernel_head_dim(head_dim, element_size, flags) == 128
+    return 2 if half else 1
 
 
 def _check_list(t: Optional[torch.Tensor], name: str, q: torch.Tensor) -> Optional[int]:
@@ -197,8 +207,10 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
                                   "(the reference's skip walk is non-causal only, mainloop:1757-1827)")
     if softcap != 0.0:
         raise NotImplementedError("softcap is compiled out (hopper/setup.py:52)")
-    if num_splits not in (0, 1):
-        raise NotImplementedError("split-KV is compiled out (hopper/setup.py:48)")
+    if num_splits < 0 or num_splits > 128:
+        raise RuntimeError("num_splits must be in [0, 128]")
+    if num_splits > 1 and (attn_read_list is not None or _q_windows is not None or cu_seqlens_q is not None or cu_seqlens_k is not None):
+        raise NotImplementedError("split-KV (num_splits > 1) serves dense fixed-length launches only: a skip list walks ITS tiles of the whole key range")
     if pack_gqa:
         raise NotImplementedError("pack_gqa is compiled out (hopper/setup.py:53)")
     if cu_seqlens_q is not None or cu_seqlens_k is not None:
@@ -231,6 +243,16 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
         raise NotImplementedError("head_dim_v != head_dim is outside the QK-Skip hot path in this build")
     if softmax_scale is None:
         softmax_scale = D ** -0.5
+    if num_splits != 1 and attn_read_list is None and _q_windows is None and not (is_fp8 and D > 128):
+        # split-KV on the host (round 6; the reference: get_num_splits / num_splits_heuristic, flash_api.cpp:437-465, heuristics.h:25-58,
+        # compiled out of its default build, hopper/setup.py:48): a dense launch with fewer (batch, head, q-tile) items than the device
+        # has workgroup slots leaves compute units idle (text queries against the video keys: 80 items on 256). num_splits = 0: decide
+        # here by the reference's rule; > 1: that many. ONE launch over the (batch x split) pairs as a packed batch, then la_combine.
+        n = _num_splits(B, H, Sq, Sk, D, q.element_size(), num_splits)
+        if n > 1:
+            res = _mha_fwd_split_kv(q, k, v, n, out, softmax_scale, descales)
+            if res is not None:
+                return res
 
     host_flags = _cabi.default_flags()                       # the environment is read ONCE per call
     if is_fp8 and D > 128:
@@ -358,6 +380,70 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
             if _window_hook is not None:
                 _window_hook(i, out, w_begin * block_m, min(Sq, (w_begin + w_count) * block_m) if w_count else Sq)
     return out, softmax_lse, empty, empty
+
+
+def num_splits_heuristic(total_mblocks: int, slots: int, num_n_blocks: int, max_splits: int = 128) -> int:
+    """The reference's ``num_splits_heuristic`` (hopper/_internal/cpp/heuristics.h:25-58) for the non-causal case, with the device's
+    resident-workgroup slots in the place of its SM count: 1 when the items almost fill the device (>= 0.8 slots) or the key range is at
+    most 4 tiles; else the smallest split count whose last-round efficiency is within 85 % of the best one. (Its other branch - split
+    a K/V head that does not fit a 50 MB L2 - belongs to Hopper's cache and is not restated.)"""
+    if total_mblocks >= 0.8 * slots or num_n_blocks <= 4:
+        return 1
+    max_splits = min(max_splits, slots, num_n_blocks)
+    eff = []
+    for s in range(1, max_splits + 1):
+        waves = total_mblocks * s / slots
+        eff.append(waves / -(-(total_mblocks * s) // slots))
+    best = max(eff)
+    return next(s for s, e in enumerate(eff, 1) if e >= 0.85 * best)
+
+
+def _num_splits(B, H, Sq, Sk, D, element_size, requested):
+    flags = _cabi.default_flags()
+    Dk = kernel_head_dim(D, element_size, flags)
+    block_m, block_n = _cabi.get_tile_sizes(Dk, element_size, flags)
+    block_m *= q_tiles_per_item(D, element_size)            # the half-vote form reports its 128-row LIST tile; a workgroup item is 256 rows
+    k_tiles = -(-Sk // block_n)
+    if requested > 1:
+        return min(requested, k_tiles)
+    cus, per = _cabi.device_slots(Dk, element_size, flags)
+    return num_splits_heuristic(B * H * -(-Sq // block_m), cus * per, k_tiles)
+
+
+_SPLIT_CU = {}      # (B, n, Sq, Sk, chunk, device) -> (cu_seqlens_q, cu_seqlens_k): tiny device tensors, built once per shape
+
+
+def _mha_fwd_split_kv(q, k, v, n, out, softmax_scale, descales):
+    """Dense attention with the key range cut into ``n`` tile-aligned chunks: sequence (b, s) of a packed batch = the queries of batch b
+    against chunk s of its keys - q is replicated per split (it is the small operand whenever splitting pays), K / V are the caller's
+    tensors seen as packed rows (no copy) - one launch of the packed-batch kernel, then the LSE merge (la_combine). Returns None when K / V
+    cannot be seen as packed rows (batch > 1 with a padded batch stride): the caller then runs the unsplit launch."""
+    B, Sq, H, D = q.shape
+    Sk, Hk = k.shape[1], k.shape[2]
+    for t in (k, v):
+        if B > 1 and t.stride(0) != Sk * t.stride(1):
+            return None
+    _, block_n = get_tile_sizes(D, q.element_size())
+    chunk = -(-(-(-Sk // block_n)) // n) * block_n            # keys per split: whole tiles
+    n = -(-Sk // chunk)                                         # (no empty trailing split)
+    if n <= 1:
+        return None
+    key = (B, n, Sq, Sk, chunk, str(q.device))
+    cu = _SPLIT_CU.get(key)
+    if cu is None:
+        cu_q = torch.arange(0, B * n + 1, dtype=torch.int32) * Sq
+        cu_k = torch.tensor([b * Sk + min(s * chunk, Sk) for b in range(B) for s in range(n)] + [B * Sk], dtype=torch.int32)
+        cu = _SPLIT_CU[key] = (cu_q.to(q.device), cu_k.to(q.device))
+    q_rep = q.unsqueeze(1).expand(B, n, Sq, H, D).reshape(B * n * Sq, H, D)
+    k_p = k.as_strided((B * Sk, Hk, D), (k.stride(1), k.stride(2), 1))
+    v_p = v.as_strided((B * Sk, Hk, D), (v.stride(1), v.stride(2), 1))
+    ds = [None if t is None else t.repeat_interleave(n, dim=0) for t in descales]
+    o_p, lse_p, *_ = _mha_fwd_varlen(q_rep, k_p, v_p, None, cu[0], cu[1], Sq, chunk, ds[0], ds[1], ds[2], softmax_scale, None, None)
+    o_part = o_p.view(B, n, Sq, H, D).transpose(0, 1)          # (n, B, Sq, H, D) view; mha_combine makes it contiguous (q-sized copies)
+    lse_part = lse_p.view(H, B, n, Sq).permute(2, 1, 3, 0)     # logical (n, B, Sq, H), seqlen contiguous: the layout fwd_combine takes
+    res, lse = mha_combine(o_part, lse_part, out=out)
+    empty = torch.empty(0, dtype=torch.float32, device=q.device)
+    return res, lse.transpose(1, 2).contiguous(), empty, empty
 
 
 def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, q_descale, k_descale, v_descale,
@@ -685,6 +771,52 @@ _COMBINE_SCHEMA = "fwd_combine(Tensor out_partial, Tensor lse_partial, Tensor(ou
 _register_combine_op()
 
 
+def combine_partials(outs, lses, out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, return_lse: bool = True):
+    """LSE-weighted merge of SEPARATE partial results - the ``(out, lse)`` pairs that ``flash_attn_func`` / ``LiteAttention.__call__`` return
+    with ``return_softmax_lse=True``, e.g. the v2t and v2v calls of the reference's text + video recipe (/root/reference/README.md:225-246,
+    which leaves the merge to the caller): ``outs`` = sequence of (batch, seqlen, nheads, headdim) tensors of one dtype (bf16 / fp16 / fp32),
+    ``lses`` = sequence of fp32 (batch, nheads, seqlen). C-ABI ``la_combine_list``: the partials are read where they are (no stacking copy),
+    at most 8 of them. Returns ``out`` or ``(out, lse (batch, nheads, seqlen))``."""
+    outs, lses = list(outs), list(lses)
+    if len(outs) != len(lses) or not 1 <= len(outs) <= 8:
+        raise RuntimeError("combine_partials takes 1..8 (out, lse) pairs")
+    o0 = outs[0]
+    if not o0.is_cuda:
+        raise RuntimeError("combine_partials has no CPU implementation")
+    if o0.dim() != 4 or o0.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise RuntimeError("partials must be (batch, seqlen, nheads, headdim) fp32, bf16 or fp16 tensors")
+    B, S, H, Dv = o0.shape
+    if Dv % 8 != 0:
+        raise RuntimeError("head_size should be a multiple of 8")
+    outs = [o if o.is_contiguous() else o.contiguous() for o in outs]
+    lses = [x if x.is_contiguous() else x.contiguous() for x in lses]
+    for o, x in zip(outs, lses):
+        if tuple(o.shape) != (B, S, H, Dv) or o.dtype != o0.dtype or o.device != o0.device:
+            raise RuntimeError("all partial outputs must have one shape, dtype and device")
+        if tuple(x.shape) != (B, H, S) or x.dtype != torch.float32 or x.device != o0.device:
+            raise RuntimeError("every lse must be fp32 (batch, nheads, seqlen) on the device of the partials")
+    if out_dtype is None:
+        out_dtype = out.dtype if out is not None else o0.dtype
+    if o0.dtype != torch.float32 and o0.dtype != out_dtype:
+        raise RuntimeError("16-bit partial results must have the output dtype")
+    if out is None:
+        out = torch.empty((B, S, H, Dv), dtype=out_dtype, device=o0.device)
+    elif out.dtype != out_dtype or tuple(out.shape) != (B, S, H, Dv) or not out.is_contiguous():
+        raise RuntimeError("out must be a contiguous (batch, seqlen, nheads, headdim) tensor of the output dtype")
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=o0.device) if return_lse else None
+    n = len(outs)
+    o_ptrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    l_ptrs = (ctypes.c_void_p * n)(*[x.data_ptr() for x in lses])
+    with torch.cuda.device(o0.device):
+        stream = torch.cuda.current_stream(o0.device).cuda_stream
+        rc = _cabi.load().la_combine_list(o_ptrs, int(o0.dtype != torch.float32), l_ptrs, out.data_ptr(),
+                                          {torch.float16: _cabi.LA_DTYPE_FP16, torch.float32: _cabi.LA_DTYPE_FP32}.get(out_dtype, _cabi.LA_DTYPE_BF16),
+                                          None if lse is None else lse.data_ptr(), n, B, S, H, Dv, ctypes.c_void_p(stream))
+    if rc != _cabi.LA_OK:
+        raise RuntimeError(f"la_combine_list: {_cabi.status_string(rc)}")
+    return (out, lse) if return_lse else out
+
+
 def flash_attn_combine(out_partial: torch.Tensor, lse_partial: torch.Tensor, out: Optional[torch.Tensor] = None,
                        out_dtype: Optional[torch.dtype] = None, return_lse: bool = True):
     """LSE-weighted merge of per-split partial results (sequence-parallel K/V splits): the reference's flash_attn_combine
@@ -697,6 +829,8 @@ def flash_attn_combine(out_partial: torch.Tensor, lse_partial: torch.Tensor, out
         (batch, nheads, seqlen). (When seqlen == nheads the strides tell them apart.)
     ``out_dtype``: default = the dtype of the partials, as in the reference (fp32 partials -> fp32 result); fp32 partials may also be merged
     into bf16 / fp16."""
+    if isinstance(out_partial, (list, tuple)):               # separate partial tensors (extension): merged where they are, la_combine_list
+        return combine_partials(out_partial, lse_partial, out, out_dtype, return_lse)
     if not out_partial.is_cuda:
         raise RuntimeError("flash_attn_combine has no CPU implementation")
     if out_dtype is None and out is not None:

@@ -103,12 +103,17 @@ class HeadShardedLiteAttention:
         if self._q_tile_rows is not None:              # test seam (CPU stand-in): no kernel, no device
             bm, slots = self._q_tile_rows, self._slots if self._slots is not None else 256
         else:
-            from .flash_attn_interface import device_slots, get_tile_sizes
+            from .flash_attn_interface import device_slots, get_tile_sizes, q_tiles_per_item
             bm, _ = get_tile_sizes(q.shape[-1], q.element_size())
             # the library knows the device and the kernel it would run; both calls map the head dim / element size the same way
             # (80 -> the 96 kernel, e4m3 above 128 -> the bf16 kernel of that head dim: ADVICE r4)
             cus, per_cu = device_slots(q.shape[-1], q.element_size())
             slots = cus * per_cu
+            unit = q_tiles_per_item(q.shape[-1], q.element_size())
+            if unit > 1:       # LA_FLAG_HALF_VOTE: a workgroup item is `unit` q-tiles; windows are planned in items and hold whole items
+                q_tiles = -(-q.shape[1] // bm)
+                items = plan_q_windows(-(-q_tiles // unit), q.shape[0] * q.shape[2], self.overlap_windows, slots)
+                return [(b0 * unit, min(c0 * unit, q_tiles - b0 * unit)) for b0, c0 in items]
         return plan_q_windows(-(-q.shape[1] // bm), q.shape[0] * q.shape[2], self.overlap_windows, slots)
 
     def preflight_overlapped(self, q, k, v, scale: Optional[float] = None, **kw) -> None:

@@ -64,7 +64,10 @@ def test_step49_bf16(run49):
     assert torch.equal(read[..., 1], torch.full_like(read[..., 1], kt - 1)) and torch.equal(write[..., 1], read[..., 1])
     assert int(read[..., 0].max()) > 128, "no row with more than 64 ranges: these lists are not fragmented"
     frac = sc.lists_to_bitmap(read).float().mean().item()
-    assert (0.50 < frac < 0.62) if r["thr"] < -4 else (0.18 < frac < 0.28), frac      # ~44 % / ~78 % sparsity (profiles/r01e)
+    if bm == 256:
+        assert (0.50 < frac < 0.62) if r["thr"] < -4 else (0.18 < frac < 0.28), frac      # ~44 % / ~78 % sparsity (profiles/r01e)
+    else:          # the 128-row vote (LA_VOTE=half / LA_FWD_KERNEL=v2) drops more at a threshold: 52.5 % / 83.7 % here
+        assert (0.42 < frac < 0.54) if r["thr"] < -4 else (0.12 < frac < 0.22), frac
     # a skipped tile is never revisited
     bm_r, bm_w = sc.lists_to_bitmap(read), sc.lists_to_bitmap(write)
     assert int((bm_w & ~bm_r).sum()) == 0
@@ -95,7 +98,8 @@ def test_step49_fp8_on_the_same_lists(run49):
     from tools import selfcheck as sc
     from liteattention_amd.flash_attn_interface import mha_fwd
     r = run49
-    assert L.get_tile_sizes(D, 1) == L.get_tile_sizes(D, 2)
+    if L.get_tile_sizes(D, 1) != L.get_tile_sizes(D, 2):
+        pytest.skip("the bf16 lists of this run use another q-tile than the fp8 kernel's (LA_VOTE=half / LA_FWD_KERNEL=v2)")
     bm, bn = L.get_tile_sizes(D, 1)
     qt, kt = -(-S // bm), -(-S // bn)
     q, k, v = [x.to(F8) for x in (r["q"], r["k"], r["v"])]

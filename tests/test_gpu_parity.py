@@ -387,6 +387,7 @@ def test_raw_cabi_call_with_plain_pointers():
     a.batch, a.seqlen_q, a.seqlen_k, a.num_heads, a.num_heads_k, a.head_dim, a.head_dim_v = 1, 384, 384, 2, 2, 128, 128
     a.softmax_scale = 128 ** -0.5
     a.block_m, a.block_n = BM, BN
+    a.flags = _cabi.default_flags() & _cabi.GEOMETRY_FLAGS           # (BM, BN) is the tile of the kernel the environment selects
     rc = _cabi.load().la_fwd(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, _cabi.status_string(rc)
     torch.cuda.synchronize()

@@ -359,6 +359,7 @@ def test_empty_key_sequence_is_handled_inside_the_library():
     a = _raw_args(q, k, k, out, lse)
     a.k = a.v = q.data_ptr()                                  # any non-NULL aligned pointer: never dereferenced
     a.block_m, a.block_n = BM, BN
+    a.flags = _cabi.default_flags() & _cabi.GEOMETRY_FLAGS     # (BM, BN) is the tile of the kernel the environment selects
     rc = lib.la_fwd(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == _cabi.LA_OK, _cabi.status_string(rc)
     torch.cuda.synchronize()
