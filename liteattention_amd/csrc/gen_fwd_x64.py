@@ -195,6 +195,7 @@ S_TB, S_VB, S_EXEC, S_T64, S_T64B = 42, 44, 46, 48, 50   # 64-bit temps
  S_FREE0, S_FREE1, S_FREE2, S_LDS, S_T0, S_T1, S_T2, S_T3, S_NM1, S_QRS, S_QROW0, S_SEQLENQ, S_EXPORT, S_PARAM, S_DOWORD, S_NEGC,
  S_FREE3, S_DMAW, S_FREE4, S_TAU, S_RESC, S_FREE5) = range(52, 87)
 S_FREE6, S_TB2, S_VB2, S_BIT = 87, 88, 90, 92
+S_STATE = S_FREE3         # HALF: the form of the NEXT step, computed in front of the drain: (a(i), a(i+1)) as bits 0, 1, or 4 = the walk is over
 S_ACT, S_ACTPTR, S_HSTRIDE = S_T64B, S_FREE1, S_FREE2    # HALF: s[50:51] = activity window (bit k = a(i + k)), LDS address of the next activity word, bytes between the halves' flag blocks
 S_ONES = S_FREE0                                 # packed (1.0, 1.0) of the element type: src0 of the row-sum dot (dotsum)    # second set of DMA bases (the loop is unrolled by two); the rotating vote bit
 S_CC = 94                                        # s[94:95] = (c, c): scalar operand of v_pk_fma_f32
@@ -824,12 +825,24 @@ def _step(variant, a_cur=True, a_nxt=True):
     emit(f"s_cbranch_scc1 {resc}")
     label(resc_back)
     deferred.append(lambda: rescale_o_block(resc, resc_back))
+    if HALF:
+        # the loop test and the form of the next step, in front of the drain (the scalar unit works under the wait for the LDS-DMA): behind
+        # the barrier a step starts with one compare and one branch, like the form without activity bits
+        emit(f"s_add_u32 {s(S_I)}, {s(S_I)}, 1")
+        next_state()
     emit(("DRAIN",))
     if "nobarrier" not in OPT:
         emit("s_barrier")
-    emit(f"s_add_u32 {s(S_I)}, {s(S_I)}, 1")
-    if HALF:
+    if not HALF:
+        emit(f"s_add_u32 {s(S_I)}, {s(S_I)}, 1")
+
+
+def next_state(shift=True):
+    if shift:
         emit(f"s_lshr_b64 {sr(S_ACT)}, {sr(S_ACT)}, 1")
+    emit(f"s_and_b32 {s(S_STATE)}, {s(S_ACT)}, 3")
+    emit(f"s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}")
+    emit(f"s_cselect_b32 {s(S_STATE)}, {s(S_STATE)}, 4")
 
 
 def mask_first_tile_ops():
@@ -1313,6 +1326,7 @@ def prologue():
         label(nofirst)                                         # (step 0 starts with the window as loaded: bit k = a(k))
         emit(f"s_mov_b32 {s(S_BIT)}, 2")
         emit(f"s_mov_b32 {s(S_DOWORD)}, {s(S_DOFLAGS)}")
+        next_state(shift=False)
 
     emit(("DRAIN",))
     emit("s_barrier")
@@ -1380,14 +1394,15 @@ def main():
         if variant == 1:
             for _ in range(int(opt_val("pad4b", "0"))):        # code-placement experiments: the second copy of the step against the first
                 emit("s_nop 0")
-        emit(f"s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}")
-        emit(f"s_cbranch_scc0 {done}")
+        if not HALF:
+            emit(f"s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}")
+            emit(f"s_cbranch_scc0 {done}")
         if HALF:
-            # four forms of the step by (a(i), a(i+1)) = bits 0, 1 of the window; the full form stays inline (the hot path: three
-            # scalar instructions in front of it), the others are out of line
+            # four forms of the step by (a(i), a(i+1)); S_STATE was computed in front of the previous drain (4 = the walk is over). The
+            # full form stays inline (the hot path: one compare and one branch in front of it, as in the form without activity bits),
+            # the others are out of line
             notfull, after = new_label("notfull"), new_label("after_step")
-            emit(f"s_and_b32 {s(S_T0)}, {s(S_ACT)}, 3")
-            emit(f"s_cmp_eq_u32 {s(S_T0)}, 3")
+            emit(f"s_cmp_eq_u32 {s(S_STATE)}, 3")
             emit(f"s_cbranch_scc0 {notfull}")
             step(variant)
             label(after)
@@ -1395,9 +1410,11 @@ def main():
             def partial_forms(notfull=notfull, after=after, variant=variant):
                 l10, l01 = new_label("step10"), new_label("step01")
                 label(notfull)
-                emit(f"s_cmp_eq_u32 {s(S_T0)}, 1")
+                emit(f"s_cmp_eq_u32 {s(S_STATE)}, 4")
+                emit(f"s_cbranch_scc1 {done}")
+                emit(f"s_cmp_eq_u32 {s(S_STATE)}, 1")
                 emit(f"s_cbranch_scc1 {l10}")
-                emit(f"s_cmp_eq_u32 {s(S_T0)}, 2")
+                emit(f"s_cmp_eq_u32 {s(S_STATE)}, 2")
                 emit(f"s_cbranch_scc1 {l01}")
                 step(variant, a_cur=False, a_nxt=False)
                 emit(f"s_branch {after}")

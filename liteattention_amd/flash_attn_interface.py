@@ -382,13 +382,16 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
     return out, softmax_lse, empty, empty
 
 
-def num_splits_heuristic(total_mblocks: int, slots: int, num_n_blocks: int, max_splits: int = 128) -> int:
+def num_splits_heuristic(total_mblocks: int, slots: int, num_n_blocks: int, max_splits: int = 128, keys: Optional[int] = None) -> int:
     """The reference's ``num_splits_heuristic`` (hopper/_internal/cpp/heuristics.h:25-58) for the non-causal case, with the device's
     resident-workgroup slots in the place of its SM count: 1 when the items almost fill the device (>= 0.8 slots) or the key range is at
     most 4 tiles; else the smallest split count whose last-round efficiency is within 85 % of the best one. (Its other branch - split
     a K/V head that does not fit a 50 MB L2 - belongs to Hopper's cache and is not restated.)"""
     if total_mblocks >= 0.8 * slots or num_n_blocks <= 4:
         return 1
+    if keys is not None and keys <= 4 * 176:
+        return 1              # the reference's "num_n_blocks <= 4" is in ITS key tiles (176 keys at bf16 head_dim 128: "we never split for hdim = 128 and
+                              # seqlen_k = 512", heuristics.h:39): below that many keys a split costs more launches than it fills compute units
     max_splits = min(max_splits, slots, num_n_blocks)
     eff = []
     for s in range(1, max_splits + 1):
@@ -407,7 +410,56 @@ def _num_splits(B, H, Sq, Sk, D, element_size, requested):
     if requested > 1:
         return min(requested, k_tiles)
     cus, per = _cabi.device_slots(Dk, element_size, flags)
-    return num_splits_heuristic(B * H * -(-Sq // block_m), cus * per, k_tiles)
+    return num_splits_heuristic(B * H * -(-Sq // block_m), cus * per, k_tiles, keys=Sk)
+
+
+def _split_kv_one_sequence(q, k, v, n, chunk, out, softmax_scale):
+    """batch == 1 (the diffusion-inference case): the splits ARE the batch of a fixed-length launch - q with batch stride 0 (every split
+    reads the same query rows: no replication), K / V with batch stride = one chunk of rows, partial O (n, Sq, H, D) and partial LSE
+    (n, H, Sq) written in exactly the layout la_combine reads; a ragged last chunk is a second launch of batch 1. Two or three library
+    calls and three allocations in all (the packed-batch form above costs a dozen tensor ops, which is what a 0.3 ms kernel notices)."""
+    _, Sq, H, D = q.shape
+    Sk, Hk = k.shape[1], k.shape[2]
+    es = q.element_size()
+    flags = _cabi.default_flags()
+    block_m, block_n = _cabi.get_tile_sizes(D, es, flags)
+    o_dtype = q.dtype
+    if out is None:
+        out = torch.empty((1, Sq, H, D), dtype=o_dtype, device=q.device)
+    elif out.dtype != o_dtype or tuple(out.shape) != (1, Sq, H, D) or not out.is_contiguous():
+        return None                                             # (a strided `out`: the unsplit launch writes it in place)
+    o_part = torch.empty((n, Sq, H, D), dtype=o_dtype, device=q.device)
+    lse_part = torch.empty((n, H, Sq), dtype=torch.float32, device=q.device)
+    lse = torch.empty((1, H, Sq), dtype=torch.float32, device=q.device)
+    a = _cabi.LaFwdArgs()
+    a.struct_size = ctypes.sizeof(_cabi.LaFwdArgs)
+    a.dtype = _cabi.LA_DTYPE_FP16 if q.dtype == torch.float16 else _cabi.LA_DTYPE_BF16
+    a.q, a.q_batch_stride, a.q_row_stride, a.q_head_stride = q.data_ptr(), 0, q.stride(1), q.stride(2)
+    a.k_row_stride, a.k_head_stride, a.k_batch_stride = k.stride(1), k.stride(2), chunk * k.stride(1)
+    a.v_row_stride, a.v_head_stride, a.v_batch_stride = v.stride(1), v.stride(2), chunk * v.stride(1)
+    a.o_batch_stride, a.o_row_stride, a.o_head_stride = Sq * H * D, H * D, D
+    a.seqlen_q, a.num_heads, a.num_heads_k, a.head_dim, a.head_dim_v = Sq, H, Hk, D, D
+    a.softmax_scale = float(softmax_scale)
+    a.block_m, a.block_n = block_m, block_n
+    a.flags = ((flags & (_cabi.GEOMETRY_FLAGS | _cabi.LA_FLAG_EXACT_RESCALE)) | (_scoped_flags() & _cabi.LA_FLAG_EXACT_RESCALE)) | _cabi.LA_FLAG_STATIC_SCHED
+    full = n if Sk == n * chunk else n - 1                      # equal chunks; then the ragged one
+    lib = _cabi.load()
+    with torch.cuda.device(q.device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
+        for first, count, keys in ((0, full, chunk), (full, n - full, Sk - full * chunk)):
+            if count == 0:
+                continue
+            a.batch, a.seqlen_k = count, keys
+            a.k, a.v = k.data_ptr() + first * chunk * k.stride(1) * es, v.data_ptr() + first * chunk * v.stride(1) * es
+            a.o, a.lse = o_part.data_ptr() + first * Sq * H * D * es, lse_part.data_ptr() + first * H * Sq * 4
+            rc = lib.la_fwd(ctypes.byref(a), stream)
+            if rc != _cabi.LA_OK:
+                raise RuntimeError(f"lite_attention::fwd (split-KV): {_cabi.status_string(rc)}")
+        rc = lib.la_combine(o_part.data_ptr(), 1, lse_part.data_ptr(), out.data_ptr(), a.dtype, lse.data_ptr(), n, 1, Sq, H, D, stream)
+    if rc != _cabi.LA_OK:
+        raise RuntimeError(f"la_combine (split-KV): {_cabi.status_string(rc)}")
+    empty = torch.empty(0, dtype=torch.float32, device=q.device)
+    return out, lse, empty, empty
 
 
 _SPLIT_CU = {}      # (B, n, Sq, Sk, chunk, device) -> (cu_seqlens_q, cu_seqlens_k): tiny device tensors, built once per shape
@@ -428,6 +480,8 @@ def _mha_fwd_split_kv(q, k, v, n, out, softmax_scale, descales):
     n = -(-Sk // chunk)                                         # (no empty trailing split)
     if n <= 1:
         return None
+    if B == 1 and q.dtype != torch.float8_e4m3fn and kernel_head_dim(D, q.element_size()) == D and all(t is None for t in descales):
+        return _split_kv_one_sequence(q, k, v, n, chunk, out, softmax_scale)
     key = (B, n, Sq, Sk, chunk, str(q.device))
     cu = _SPLIT_CU.get(key)
     if cu is None:

@@ -127,6 +127,8 @@ def test_every_loop_head_sits_at_its_pinned_code_placement():
                 nxt = re.search(r"^[0-9a-f]+ <", seg, re.M)
                 seg = seg[:nxt.start()] if nxt else seg
                 heads = re.findall(r"s_cmp_lt_u32 s63, s55\s+// ([0-9A-Fa-f]+):", seg)          # the loop test: S_I < S_NTILES
+                if "Li128ELb1E" in m.group(1):          # the half-vote form: its loop head is the test of the step form (the loop test sits in front of the drain)
+                    heads = re.findall(r"s_cmp_eq_u32 s81, 3\s+// ([0-9A-Fa-f]+):", seg)
                 if not heads:
                     continue
                 key = next(k for k in want if k in m.group(1))
