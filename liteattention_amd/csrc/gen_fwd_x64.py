@@ -794,10 +794,12 @@ def _step(variant, a_cur=True, a_nxt=True):
         vq += stats_bookkeeping(fl, flback)
         deferred.append(lambda: flush_block(fl, flback))
     elif "notail" not in OPT:
-        inv, invback = (None, None) if HALF else (new_label("inval"), new_label("inval_back"))
+        # (HALF: positions past the end of the walk have a = 0, so a form with statistics never runs at i == n - 1 and the test below never
+        # fires there; it stays so that the hot loop is instruction for instruction - gap for gap - the tuned schedule of the form
+        # without activity bits)
+        inv, invback = new_label("inval"), new_label("inval_back")
         vq += stats_ops(rare, back, fl, flback, inv, invback)
-        if not HALF:
-            deferred.append(lambda: inval_block(inv, invback))
+        deferred.append(lambda: inval_block(inv, invback))
         deferred.append(lambda: rare_rescale_block(rare, back))
         deferred.append(lambda: flush_block(fl, flback))
     if a_nxt:
@@ -808,7 +810,10 @@ def _step(variant, a_cur=True, a_nxt=True):
     mark = len(out)
     emit_gaps(pre, mf, post)
     if variant == 0 and full:
-        widen_last(int(opt_val("wc2", "0")), mark)                 # shift the second copy of the step against the first
+        # shift the second copy of the step against the first (code-placement experiments). HALF: the tail in front of the drain is four
+        # scalar instructions (16 bytes) longer than the tuned form's; four widened encodings more put the second copy of the step back at
+        # the fetch phase it was tuned at (profiles/r05_code_placement.md: period 32 bytes)
+        widen_last(int(opt_val("wc2", "4" if HALF else "0")), mark)
     if HALF and not a_cur and "nokread" not in OPT:
         # K(i+2) fragments iff this half lists tile i + 2 (bit 2 of the window). Behind every counted LDS wait of the step and in front
         # of the drain: a conditional LDS operation between a counted wait and its target would break the count.
