@@ -807,12 +807,23 @@ def _step(variant, a_cur=True, a_nxt=True):
     # the first two gaps may only hold ops that do not read S_nxt (MFMA -> VALU read hazard): the SALU / seq part
     distribute(vq[:n_head], post, 0, CAP2 if CAP2 > 0 else 6)
     distribute(vq[n_head:], post, 2, CAP2)
+    if HALF and a_cur:
+        # the loop count and the form of the NEXT step: ADDED to the PV gaps behind the statistics (which read S_I and may refill the
+        # window) - on top of the tuned filling, which stays as it is. In front of the drain they were a dependent scalar chain on the
+        # critical path: +30 cycles per step, measured.
+        t_stats = max(t for t in range(NG) if any(isinstance(it, str) and it.startswith(flback) for it in post[t]))
+        ops = state_ops()
+        assert t_stats + 4 < NG
+        post[t_stats + 1].append(ops[0])
+        post[t_stats + 2].append(ops[1])
+        post[t_stats + 3].append(ops[2])
+        post[t_stats + 4] += ops[3:]               # the compare and the select that reads its SCC: adjacent
     mark = len(out)
     emit_gaps(pre, mf, post)
     if variant == 0 and full:
-        # shift the second copy of the step against the first (code-placement experiments). HALF: the tail in front of the drain is four
-        # scalar instructions (16 bytes) longer than the tuned form's; four widened encodings more put the second copy of the step back at
-        # the fetch phase it was tuned at (profiles/r05_code_placement.md: period 32 bytes)
+        # shift the second copy of the step against the first (code-placement experiments). HALF: a step is four scalar instructions (16
+        # bytes: five in the PV gaps, one fewer behind the barrier) longer than the tuned form's; four widened encodings more put the second
+        # copy of the step back at the fetch phase it was tuned at (profiles/r05_code_placement.md: period 32 bytes)
         widen_last(int(opt_val("wc2", "4" if HALF else "0")), mark)
     if HALF and not a_cur and "nokread" not in OPT:
         # K(i+2) fragments iff this half lists tile i + 2 (bit 2 of the window). Behind every counted LDS wait of the step and in front
@@ -830,16 +841,22 @@ def _step(variant, a_cur=True, a_nxt=True):
     emit(f"s_cbranch_scc1 {resc}")
     label(resc_back)
     deferred.append(lambda: rescale_o_block(resc, resc_back))
-    if HALF:
-        # the loop test and the form of the next step, in front of the drain (the scalar unit works under the wait for the LDS-DMA): behind
-        # the barrier a step starts with one compare and one branch, like the form without activity bits
-        emit(f"s_add_u32 {s(S_I)}, {s(S_I)}, 1")
-        next_state()
+    if HALF and not a_cur:
+        # (the forms without PV: behind the conditional K-fragment block, which reads bit 2 of the window)
+        for op in state_ops():
+            out.append(op)
     emit(("DRAIN",))
     if "nobarrier" not in OPT:
         emit("s_barrier")
     if not HALF:
         emit(f"s_add_u32 {s(S_I)}, {s(S_I)}, 1")
+
+
+def state_ops():
+    """HALF: i += 1, the window moves on, S_STATE = the form of the next step - (a(i), a(i+1)) as bits 0, 1, or 4 when the walk is over.
+    Behind the barrier a step then starts with one compare and one branch, like the form without activity bits."""
+    return [f"    s_add_u32 {s(S_I)}, {s(S_I)}, 1", f"    s_lshr_b64 {sr(S_ACT)}, {sr(S_ACT)}, 1", f"    s_and_b32 {s(S_STATE)}, {s(S_ACT)}, 3",
+            f"    s_cmp_lt_u32 {s(S_I)}, {s(S_NTILES)}", f"    s_cselect_b32 {s(S_STATE)}, {s(S_STATE)}, 4"]
 
 
 def next_state(shift=True):
