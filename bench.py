@@ -337,7 +337,7 @@ def config1_dense(L, dev, S=32768, H=40, D=128):
 
 
 def denoise50(L, dev, thresholds=None, sweep0_ms=None, dense_steps=(5, 15, 25, 35, 45, 49), random_qkv=None, headline_launch=None,
-              headline_ms=None):
+              headline_ms=None, generator="anchored"):
     """BASELINE.json configs[2]. Per threshold: 50 calls of LiteAttention.__call__ on the slowly varying workload; kernel time per
     step by HIP events on the launch stream. Reports the sparsity of the list the LAST step read, its time against the DENSE kernel on
     the same tensors, the 50-step total, and the error the skipping itself introduces at the last step (sparse vs dense kernel
@@ -359,7 +359,7 @@ def denoise50(L, dev, thresholds=None, sweep0_ms=None, dense_steps=(5, 15, 25, 3
     top-level `ms_per_step` is the cool number, this is the same work inside a pipeline-like loop."""
     from tools.selfcheck import DENOISE_THRESHOLDS, REFERENCE_T_OVER_T0, DenoiseWorkload, lists_to_bitmap, vote_writer_check
     thresholds = DENOISE_THRESHOLDS if thresholds is None else thresholds
-    wl = DenoiseWorkload(40, dev)
+    wl = DenoiseWorkload(40, dev, generator=generator)
     ev = lambda: torch.cuda.Event(enable_timing=True)                                           # noqa: E731
     all_dense, all_dense_random, all_headline = [], [], []
 
