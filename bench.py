@@ -437,8 +437,10 @@ def denoise50(L, dev, thresholds=None, sweep0_ms=None, dense_steps=(5, 15, 25, 3
         del att, out, d, ref
     dense_all = sorted(all_dense)[len(all_dense) // 2]
     res = {"what": "50 synthetic denoising steps, B=1 S=75600 H=40 D=128 bf16, real skip lists at fixed thresholds "
-                   "(tools.selfcheck.DenoiseWorkload, generator 'anchored'; thresholds bisected for 21 / 42 / 57 / 77 % +- 1 % at "
-                   "step 49: profiles/r04_denoise50_calibration.json)",
+                   f"(tools.selfcheck.DenoiseWorkload, generator '{generator}'; thresholds bisected for 21 / 42 / 57 / 77 % +- 1 % at "
+                   "step 49: " + ("profiles/r04_denoise50_calibration.json)" if generator == "anchored" else
+                                  "profiles/r06_denoise50_survey_calibration.json; the generator SURVEY.md 8(d) pins)"),
+           "tiles": list(L.get_tile_sizes(128, 2)),
            "dense_ms_per_step": round(dense_all, 3),
            "dense_how": f"median of {len(all_dense)} warmed dense launches interleaved with the sparse runs (steps {list(dense_steps)} of each "
                         "threshold's loop, 1 untimed + 3 timed each)",
@@ -465,6 +467,80 @@ def denoise50(L, dev, thresholds=None, sweep0_ms=None, dense_steps=(5, 15, 25, 3
         else:
             res["dense_vs_sweep0"]["launch_context_effect_pct"] = round(100.0 * (dense_all / sweep0_ms - 1.0), 2)
     return res
+
+
+def denoise50_brief(L, dev, thresholds, generator="anchored", env=None):
+    """The 50-step run at fixed thresholds without the interleaved dense samples of `denoise50`: per threshold the total kernel time of
+    the 50 calls, the last step, the sparsity of the list the last step read, and the error against the DENSE kernel at the last step.
+    `env`: environment of the host layer for the run (LA_VOTE=half: the 128-row vote)."""
+    from tools.selfcheck import DenoiseWorkload
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        wl = DenoiseWorkload(40, dev, generator=generator)
+        ev = lambda: torch.cuda.Event(enable_timing=True)                                       # noqa: E731
+        runs = []
+        for name, thr in thresholds:
+            att = L.LiteAttention(threshold=thr, max_batch_size=1)
+            ms, sp = [], 0.0
+            for t in range(wl.steps):
+                q, k, v = wl.qkv(t)
+                if t == wl.steps - 1:
+                    sp = att.get_skip_fraction(batch=1)
+                a, b = ev(), ev()
+                a.record(); out = att(q, k, v); b.record(); torch.cuda.synchronize()
+                ms.append(a.elapsed_time(b))
+            ref = L.flash_attn_func(q, k, v)
+            d = (out.float() - ref.float()).abs()
+            runs.append({"target": name, "thr": thr, "total_ms_50_steps": round(sum(ms), 1), "ms_last_step": round(ms[-1], 3),
+                         "sparsity_last_step": round(sp, 4), "mean_abs_err_vs_dense": float(f"{d.mean().item():.3e}"),
+                         "max_abs_err_vs_dense": float(f"{d.max().item():.3e}")})
+            del att, out, ref, d
+        return {"tiles": list(L.get_tile_sizes(128, 2)), "generator": generator, "runs": runs}
+    finally:
+        for k, v_ in saved.items():
+            if v_ is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v_
+
+
+def half_vote_record(L, dev, qkv, tile_runs, S=75600, H=40, D=128):
+    """LA_FLAG_HALF_VOTE (skip lists per 128-row half of the 256-row workgroup; LA_VOTE=half) beside the default 256-row vote, same box, same
+    process: (1) the imposed lists at 42 % and 77 % in the 128-row geometry - at a given SPARSITY the form may cost nothing (the union walk of
+    two banded halves is two tiles longer); (2) the 50-step run at the SAME FIXED thresholds as `denoise50` - a 128-row vote drops more
+    tiles at a threshold, and the error against the dense kernel says what that costs."""
+    from tools.selfcheck import DENOISE_THRESHOLDS
+    q, k, v = qkv
+    os.environ["LA_VOTE"] = "half"
+    try:
+        bm, bn = L.get_tile_sizes(D, 2)
+        qt, kt = -(-S // bm), -(-S // bn)
+        att = L.LiteAttention(threshold=-10.0, max_batch_size=1)
+        att.threshold = float("-inf")
+        att._get_read_write_lists(q, k)
+        att._phase = 0
+        imposed = []
+        for s_ in (0.42, 0.77):
+            rows = banded_rows(qt, kt, bm, bn, s_)
+            impose_lists(att, rows)
+            ms, reps = steady_state_ms(lambda: att(q, k, v), est_ms=50.0, min_reps=8)
+            fl = executed_flops(rows, H, 1, S, S, bm, bn, D)
+            imposed.append({"sparsity": round(1 - listed_tiles_of_rows(rows) / (qt * kt), 4), "ms": round(ms, 3), "executed_tflops": round(fl / ms / 1e9, 1),
+                            "frac_of_mfma_peak": round(fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)})
+        del att
+    finally:
+        os.environ.pop("LA_VOTE", None)
+    brief = denoise50_brief(L, dev, DENOISE_THRESHOLDS, env={"LA_VOTE": "half"})
+    ratio = {}
+    for r in brief["runs"]:
+        base = next((x for x in tile_runs if x["target"] == r["target"]), None)
+        if base:
+            ratio[r["target"]] = {"thr": r["thr"], "total_ms_half_over_tile256": round(r["total_ms_50_steps"] / base["total_ms_50_steps"], 4),
+                                  "sparsity_last_step": [base["sparsity_last_step"], r["sparsity_last_step"]],
+                                  "mean_abs_err_vs_dense": [base["mean_abs_err_vs_dense"], r["mean_abs_err_vs_dense"]]}
+    return {"what": "LA_FLAG_HALF_VOTE (LA_VOTE=half): lists per 128-row half, tiles (128, 64); pairs are [256-row vote, 128-row vote]",
+            "imposed_lists": imposed, "denoise50": brief, "at_fixed_thresholds": ratio}
 
 
 def main():
@@ -759,6 +835,54 @@ def main():
                 result["ms_per_step_in_denoise_loop"] = hil["ms"]
         except Exception as e:  # noqa: BLE001
             result["denoise50"] = {"error": repr(e)}
+
+    # ---- round 6 sub-records: the 128-row vote beside the default, the generator SURVEY.md 8(d) pins, the reference's text + video recipe
+    extra = world == 1 and seam is None and args.dtype == "bf16" and S == 75600 and H == 40
+    if extra and not args.no_denoise and "runs" in result.get("denoise50", {}):
+        try:
+            result["half_vote"] = half_vote_record(L, dev, qkv_bf16, result["denoise50"]["runs"])
+        except Exception as e:  # noqa: BLE001
+            result["half_vote"] = {"error": repr(e)}
+        try:
+            from tools.selfcheck import SURVEY_DENOISE_THRESHOLDS
+            result["denoise50_survey"] = denoise50_brief(L, dev, SURVEY_DENOISE_THRESHOLDS, generator="survey")
+        except Exception as e:  # noqa: BLE001
+            result["denoise50_survey"] = {"error": repr(e)}
+    if extra and not args.no_head_dims:
+        try:
+            from tools.joint_recipe_bench import joint_recipe
+            result["joint_recipe"] = joint_recipe(L, dev, qkv_bf16)
+        except Exception as e:  # noqa: BLE001
+            result["joint_recipe"] = {"error": repr(e)}
+    # ---- the numbers of the sub-records that are meant to be read, where the driver keeps them: roofline / config
+    try:
+        rf, cf = result["roofline"], result["config"]
+        if "sweep" in result:
+            cf["t_over_t0"] = [e["t_over_t0"] for e in result["sweep"]]
+            cf["reference_t_over_t0"] = [e["reference_t_over_t0"] for e in result["sweep"]]
+            cf["sweep_sparsities"] = [e["sparsity"] for e in result["sweep"]]
+        if result.get("fp8", {}).get("roofline"):
+            rf["fp8_reference_frac"] = result["fp8"]["roofline"]["frac"]          # the default fp8 form = the reference's arithmetic
+            for key in ("mfma_rowsum", "encoded_p"):
+                if key in result["fp8"]:
+                    rf[f"fp8_{key}_frac"] = result["fp8"][key]["frac"]
+        if "runs" in result.get("other_head_dims", {}):
+            rf["other_head_dims"] = {str(r["head_dim"]): r["frac_of_mfma_peak"] for r in result["other_head_dims"]["runs"]}
+        if "frac_of_mfma_peak" in result.get("config1_dense_s32768", {}):
+            rf["config1_dense_s32768_frac"] = result["config1_dense_s32768"]["frac_of_mfma_peak"]
+        if "runs" in result.get("denoise50", {}):
+            cf["denoise50_total_ms"] = {r["target"]: r["total_ms_50_steps"] for r in result["denoise50"]["runs"]}
+            cf["denoise50_t_last_over_dense"] = {r["target"]: r["t_last_over_dense"] for r in result["denoise50"]["runs"]}
+        if "at_fixed_thresholds" in result.get("half_vote", {}):
+            cf["half_vote_total_ms_over_tile256"] = {k_: v_["total_ms_half_over_tile256"] for k_, v_ in result["half_vote"]["at_fixed_thresholds"].items()}
+            cf["half_vote_imposed_ms"] = {str(e["sparsity"]): e["ms"] for e in result["half_vote"]["imposed_lists"]}
+        if "runs" in result.get("denoise50_survey", {}):
+            cf["denoise50_survey_total_ms"] = {r["target"]: [r["thr"], r["sparsity_last_step"], r["total_ms_50_steps"]] for r in result["denoise50_survey"]["runs"]}
+        if "everything_but_v2v_over_v2v" in result.get("joint_recipe", {}):
+            cf["joint_recipe_small_calls_over_v2v"] = result["joint_recipe"]["everything_but_v2v_over_v2v"]
+            rf["joint_recipe_frac"] = {n: result["joint_recipe"][n]["frac_of_mfma_peak"] for n in ("t2t", "t2v", "v2t", "v2v")}
+    except Exception as e:  # noqa: BLE001
+        result["summary_keys_error"] = repr(e)
 
     if world == 1 and seam is None and rank == 0 and not args.no_cpu_baseline and args.dtype == "bf16":
         try:

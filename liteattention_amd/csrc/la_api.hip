@@ -34,6 +34,29 @@ bool uses_128row(int head_dim, int element_size, uint32_t flags) {      // the f
 bool uses_half_vote(int head_dim, int element_size, uint32_t flags) {
     return element_size == 2 && head_dim == 128 && (flags & LA_FLAG_HALF_VOTE) != 0 && (flags & LA_FLAG_KERNEL_128ROW) == 0;
 }
+// Long DENSE key ranges (bf16 / fp16, hand-scheduled kernels). A workgroup keeps the tile-address table of its walk in LDS, which bounds the key
+// tiles of ONE launch (~4 800 at head_dim <= 128, ~1 600 at 192 / 256). A skip list names its tiles over the whole key range and keeps that
+// bound (LA_ERR_SEQLEN); a dense launch does not need it: with the workspace la_fwd_workspace_bytes() asks for, la_fwd cuts the keys into
+// the fewest equal runs of tiles that fit, runs them as launches on partial O / LSE buffers in the workspace and merges them by LSE
+// (la_combine's kernel) - the reference has no such bound (its producer reads the list from global memory, mainloop...:47-115).
+int dense_tiles_per_launch(int head_dim) {
+    int lo = 1, hi = 1 << 20;                         // largest k_tiles whose walk fits (the LDS bytes grow with k_tiles)
+    while (lo < hi) {
+        const int mid = lo + (hi - lo + 1) / 2;
+        if (la::fwd_lds_bytes_x64(mid, nullptr, head_dim) <= 160 * 1024) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+struct DenseSplit { int n, chunk_tiles; uint64_t o_bytes, lse_bytes; };
+DenseSplit dense_split(int k_tiles, int head_dim, int64_t batch, int64_t seqlen_q, int64_t num_heads, int64_t head_dim_v) {
+    const int per = dense_tiles_per_launch(head_dim);
+    DenseSplit d{};
+    d.n = (k_tiles + per - 1) / per;
+    d.chunk_tiles = (k_tiles + d.n - 1) / d.n;
+    d.o_bytes = ((static_cast<uint64_t>(batch) * seqlen_q * num_heads * head_dim_v * 2) + 15) & ~15ull;
+    d.lse_bytes = ((static_cast<uint64_t>(batch) * num_heads * seqlen_q * 4) + 15) & ~15ull;
+    return d;
+}
 constexpr uint64_t kSchedWorkspaceBytes = 1024;   // 16 ticket / steal counters of 64 bytes, all of them zeroed by prepare_work_queue (no slack)
 constexpr float kRescaleTauBf16 = 8.0f;           // lazy-rescale slack of the x64 kernel, log2 units (HISTORY.md section 3.1)
 }  // namespace
@@ -64,7 +87,7 @@ const char* la_status_string(int status) {
         case LA_ERR_LISTS: return "attn_read_list and attn_write_list must be given together";
         case LA_ERR_UNSUPPORTED: return "feature outside the QK-Skip hot path (head_dim_v != head_dim, unknown flags, skip lists with cu_seqlens on the 128-row kernels or above head_dim 128)";
         case LA_ERR_LAUNCH: return "HIP kernel launch failed (see la_last_hip_error)";
-        case LA_ERR_SEQLEN: return "seqlen_k too long: expanded skip list does not fit in LDS";
+        case LA_ERR_SEQLEN: return "seqlen_k too long: the expanded skip list does not fit in LDS (dense bf16 / fp16 launches are cut into runs and merged when the workspace of la_fwd_workspace_bytes() is given)";
         case LA_ERR_WORKSPACE: return "fp8 needs a 16-byte aligned workspace of la_fwd_workspace_bytes() bytes";
         case LA_ERR_Q_WINDOW: return "q_tile_begin/q_tile_count outside the q-tiles of this problem (LA_FLAG_HALF_VOTE: windows start on an even q-tile and hold an even number unless they reach the last)";
         default: return "unknown la_status";
@@ -91,10 +114,21 @@ int la_get_tile_sizes(int head_dim, int element_size, int* block_m, int* block_n
 int64_t la_fwd_workspace_bytes(const la_fwd_args* a) {
     if (a == nullptr) return LA_ERR_NULL_ARG;
     if (a->struct_size != sizeof(la_fwd_args)) return LA_ERR_STRUCT_SIZE;
-    if (a->dtype == LA_DTYPE_BF16 || a->dtype == LA_DTYPE_FP16)      // ticket counters of the dynamic work distribution: launches with lists, and
+    if (a->dtype == LA_DTYPE_BF16 || a->dtype == LA_DTYPE_FP16) {    // ticket counters of the dynamic work distribution: launches with lists, and
         // (round 5) dense launches of the hand-scheduled kernels; the 128-row template keeps the static map for dense
-        return ((a->read_list != nullptr || !(a->flags & LA_FLAG_KERNEL_128ROW)) && !(a->flags & LA_FLAG_STATIC_SCHED))
-                   ? static_cast<int64_t>(kSchedWorkspaceBytes) : 0;
+        int64_t need = ((a->read_list != nullptr || !(a->flags & LA_FLAG_KERNEL_128ROW)) && !(a->flags & LA_FLAG_STATIC_SCHED))
+                           ? static_cast<int64_t>(kSchedWorkspaceBytes) : 0;
+        // (round 6) a dense key range longer than one launch's walk: + the partial O / LSE of its runs (see dense_split)
+        if (a->read_list == nullptr && !(a->flags & LA_FLAG_KERNEL_128ROW) && a->cu_seqlens_q == nullptr && a->seqlen_k > 0 && a->batch > 0 &&
+            a->seqlen_q > 0 && a->num_heads > 0 && la::tile_shape(a->head_dim, 2).block_m != 0) {
+            const int k_tiles = (a->seqlen_k + 63) / 64;
+            if (la::fwd_lds_bytes_x64(k_tiles, nullptr, a->head_dim) > 160 * 1024) {
+                const DenseSplit d = dense_split(k_tiles, a->head_dim, a->batch, a->seqlen_q, a->num_heads, a->head_dim_v);
+                need = static_cast<int64_t>(kSchedWorkspaceBytes + d.n * (d.o_bytes + d.lse_bytes));
+            }
+        }
+        return need;
+    }
     if (a->dtype != LA_DTYPE_FP8_E4M3) return LA_ERR_DTYPE;
     int bm = 0, bn = 0;
     const int trc = la_get_tile_sizes_ex(a->head_dim, 1, a->flags, &bm, &bn);
@@ -213,7 +247,8 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     p.k_descale_batch_stride = a->k_descale_batch_stride; p.k_descale_head_stride = a->k_descale_head_stride;
     p.v_descale_batch_stride = a->v_descale_batch_stride; p.v_descale_head_stride = a->v_descale_head_stride;
 
-    if (!fp8 && la::fwd_lds_bytes_v2(a->head_dim <= 128 ? a->head_dim : 256, p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
+    if (!fp8 && (a->flags & LA_FLAG_KERNEL_128ROW) &&
+        la::fwd_lds_bytes_v2(a->head_dim <= 128 ? a->head_dim : 256, p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
     if (static_cast<int64_t>(p.batch) * p.num_heads * p.q_tiles > 0x7fffffffLL) return LA_ERR_SHAPE;
 
     if (fp8) {
@@ -240,8 +275,35 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     if ((skipable || x64) && a->workspace != nullptr && a->workspace_bytes >= kSchedWorkspaceBytes && aligned16(a->workspace) &&
         !(a->flags & LA_FLAG_STATIC_SCHED))
         p.work_counter = static_cast<unsigned*>(a->workspace);
-    if (x64) {
-        if (la::fwd_lds_bytes_x64(p.k_tiles, nullptr, a->head_dim, nullptr, half_vote && skipable) > 160 * 1024) return LA_ERR_SEQLEN;
+    if (x64 && la::fwd_lds_bytes_x64(p.k_tiles, nullptr, a->head_dim, nullptr, half_vote && skipable) > 160 * 1024) {
+        // lists keep the bound; a dense launch is cut into runs of tiles that fit (dense_split) when the caller gave the workspace for it
+        if (skipable || varlen || p.q_tile_count != p.q_tiles) return LA_ERR_SEQLEN;
+        const DenseSplit d = dense_split(p.k_tiles, a->head_dim, p.batch, p.seqlen_q, p.num_heads, a->head_dim_v);
+        if (a->workspace == nullptr || !aligned16(a->workspace) || a->workspace_bytes < kSchedWorkspaceBytes + d.n * (d.o_bytes + d.lse_bytes))
+            return LA_ERR_SEQLEN;
+        unsigned char* const ws = static_cast<unsigned char*>(a->workspace);
+        uint16_t* const o_part = reinterpret_cast<uint16_t*>(ws + kSchedWorkspaceBytes);
+        float* const lse_part = reinterpret_cast<float*>(ws + kSchedWorkspaceBytes + d.n * d.o_bytes);
+        for (int s = 0; s < d.n; ++s) {
+            la::FwdParams ps = p;
+            const int64_t row0 = static_cast<int64_t>(s) * d.chunk_tiles * bn;
+            ps.k = p.k + row0 * p.k_row_stride;
+            ps.v = p.v + row0 * p.v_row_stride;
+            ps.seqlen_k = static_cast<int>(a->seqlen_k - row0 < static_cast<int64_t>(d.chunk_tiles) * bn ? a->seqlen_k - row0 : static_cast<int64_t>(d.chunk_tiles) * bn);
+            ps.k_tiles = (ps.seqlen_k + bn - 1) / bn;
+            ps.o = o_part + s * (d.o_bytes / 2);
+            ps.o_head_stride = a->head_dim_v; ps.o_row_stride = static_cast<int64_t>(p.num_heads) * a->head_dim_v;
+            ps.o_batch_stride = static_cast<int64_t>(p.seqlen_q) * ps.o_row_stride;
+            ps.lse = lse_part + s * (d.lse_bytes / 4);
+            err = la::launch_fwd_x64(ps, a->head_dim, false, f16, stream);
+            if (err != hipSuccess) { g_last_hip_error = static_cast<int>(err); return LA_ERR_LAUNCH; }
+        }
+        // the partial buffers are 16-byte padded per run: la_combine's kernel reads run s at s * (elements of one partial), so the padding must be 0
+        if (d.o_bytes != static_cast<uint64_t>(p.batch) * p.seqlen_q * p.num_heads * a->head_dim_v * 2 ||
+            d.lse_bytes != static_cast<uint64_t>(p.batch) * p.num_heads * p.seqlen_q * 4) return LA_ERR_SEQLEN;      // (head_dim_v % 8 == 0: only an odd batch * heads * rows of LSE could pad)
+        err = la::launch_combine(o_part, true, f16, lse_part, p.o, a->lse, d.n, p.batch, p.seqlen_q, p.num_heads, a->head_dim_v, stream, false,
+                                 p.o_batch_stride, p.o_row_stride, p.o_head_stride);
+    } else if (x64) {
         err = la::launch_fwd_x64(p, a->head_dim, skipable, f16, stream);
     } else {
         err = la::launch_fwd_bf16_v2(p, a->head_dim, skipable, f16, stream);

@@ -196,7 +196,8 @@ __global__ void __launch_bounds__(256) combine_kernel(const void* __restrict__ o
                                                        const float* __restrict__ lse_partial,
                                                        uint16_t* __restrict__ o, float* __restrict__ lse_out,
                                                        int num_splits, int batch, int seqlen_q, int num_heads,
-                                                       int dv, const CombineList list = CombineList{}) {
+                                                       int dv, const CombineList list = CombineList{}, int64_t o_batch_stride = 0,
+                                                       int64_t o_row_stride = 0, int64_t o_head_stride = 0) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x8 __attribute__((ext_vector_type(8)));
     typedef typename Elem16<F16>::x8 ex8;
@@ -237,12 +238,14 @@ __global__ void __launch_bounds__(256) combine_kernel(const void* __restrict__ o
         }
         const float inv = denom > 0.f ? 1.f / denom : 0.f;
         acc *= inv;
+        // the result: contiguous (b, s, h, d), or the caller's strided tensor (element strides; la_fwd's internal split of long dense walks)
+        const int64_t o_off = o_row_stride != 0 ? b * o_batch_stride + s * o_row_stride + hh * o_head_stride + ch * 8 : row * dv + ch * 8;
         if constexpr (OUT_F32) {
-            float* const of = reinterpret_cast<float*>(o) + row * dv + ch * 8;
+            float* const of = reinterpret_cast<float*>(o) + o_off;
             *reinterpret_cast<f32x4*>(of) = __builtin_shufflevector(acc, acc, 0, 1, 2, 3);
             *reinterpret_cast<f32x4*>(of + 4) = __builtin_shufflevector(acc, acc, 4, 5, 6, 7);
         } else {
-            *reinterpret_cast<ex8*>(o + row * dv + ch * 8) = __builtin_convertvector(acc, ex8);
+            *reinterpret_cast<ex8*>(o + o_off) = __builtin_convertvector(acc, ex8);
         }
         if (lse_out != nullptr && ch == 0) lse_out[lse_idx] = denom > 0.f ? m_safe + __logf(denom) : -INFINITY;
     }
@@ -250,14 +253,15 @@ __global__ void __launch_bounds__(256) combine_kernel(const void* __restrict__ o
 
 template <bool P16, bool F16>
 static void launch_combine_t(unsigned blocks, hipStream_t stream, const void* o_partial, const float* lse_partial, uint16_t* o,
-                             float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v) {
+                             float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v, int64_t o_bs = 0,
+                             int64_t o_rs = 0, int64_t o_hs = 0) {
     hipLaunchKernelGGL((combine_kernel<P16, F16>), dim3(blocks), dim3(256), 0, stream, o_partial, lse_partial, o, lse, num_splits,
-                       batch, seqlen_q, num_heads, head_dim_v);
+                       batch, seqlen_q, num_heads, head_dim_v, CombineList{}, o_bs, o_rs, o_hs);
 }
 
 hipError_t launch_combine(const void* o_partial, bool partial_is_16bit, bool f16, const float* lse_partial, uint16_t* o,
                           float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v,
-                          hipStream_t stream, bool out_f32) {
+                          hipStream_t stream, bool out_f32, int64_t o_bs, int64_t o_rs, int64_t o_hs) {
     const int64_t total = static_cast<int64_t>(batch) * seqlen_q * num_heads * (head_dim_v / 8);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -268,9 +272,9 @@ hipError_t launch_combine(const void* o_partial, bool partial_is_16bit, bool f16
         hipLaunchKernelGGL((combine_kernel<false, false, true>), dim3(g), dim3(256), 0, stream, o_partial, lse_partial, o, lse, num_splits,
                            batch, seqlen_q, num_heads, head_dim_v);
     else if (partial_is_16bit && f16)
-        launch_combine_t<true, true>(g, stream, o_partial, lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v);
+        launch_combine_t<true, true>(g, stream, o_partial, lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v, o_bs, o_rs, o_hs);
     else if (partial_is_16bit)
-        launch_combine_t<true, false>(g, stream, o_partial, lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v);
+        launch_combine_t<true, false>(g, stream, o_partial, lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v, o_bs, o_rs, o_hs);
     else if (f16)
         launch_combine_t<false, true>(g, stream, o_partial, lse_partial, o, lse, num_splits, batch, seqlen_q, num_heads, head_dim_v);
     else

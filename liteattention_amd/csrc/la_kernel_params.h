@@ -103,7 +103,8 @@ hipError_t launch_blockmask_to_lists(const uint8_t* mask, int64_t mask_batch_str
                                      const int32_t* k_tiles_valid, int32_t* lists, int32_t* empty_rows, hipStream_t stream);
 hipError_t launch_combine(const void* o_partial, bool partial_is_16bit, bool f16, const float* lse_partial, uint16_t* o,
                           float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v,
-                          hipStream_t stream, bool out_f32 = false);
+                          hipStream_t stream, bool out_f32 = false, int64_t o_batch_stride = 0, int64_t o_row_stride = 0,
+                          int64_t o_head_stride = 0);      // strides (elements) of a strided 16-bit result; 0 = contiguous
 
 hipError_t launch_combine_list(const void* const* o_partials, bool partial_is_16bit, bool f16, const float* const* lse_partials, uint16_t* o,
                                float* lse, int num_splits, int batch, int seqlen_q, int num_heads, int head_dim_v, hipStream_t stream,

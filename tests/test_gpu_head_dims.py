@@ -172,9 +172,20 @@ def test_longest_key_sequence(D):
     out, lse = L.flash_attn_func(q, k, v, return_softmax_lse=True)
     ref = torch.nn.functional.scaled_dot_product_attention(q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2))
     assert (out.float() - ref.transpose(1, 2)).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-3
-    k2 = torch.zeros(1, 2000 * 64, 1, D, device="cuda", dtype=torch.bfloat16)
+    # beyond one launch's walk (round 6): a DENSE call is cut into runs of tiles inside la_fwd and merged by LSE; a call with skip lists
+    # keeps the bound and its typed error
+    Sk2 = 2048 * 64 - 5                                     # S = 131 072: two runs
+    k2 = torch.randn(1, Sk2, 1, D, device="cuda", generator=g).bfloat16()
+    v2 = torch.randn(1, Sk2, 1, D, device="cuda", generator=g).bfloat16()
+    out2, lse2 = L.flash_attn_func(q, k2, v2, return_softmax_lse=True)
+    sc = q.float()[0, :, 0] @ k2.float()[0, :, 0].T / D ** 0.5
+    ref2 = torch.softmax(sc, -1) @ v2.float()[0, :, 0]
+    assert (out2.float()[0, :, 0] - ref2).abs().max().item() <= 2.0 ** -7 * ref2.abs().max().item() + 1e-3      # two bf16 roundings: partials, merge
+    assert (lse2[0, 0] - torch.logsumexp(sc, -1)).abs().max().item() <= 1e-3
+    bm, bn = L.get_tile_sizes(D, 2)
+    lists = torch.zeros(2, 1, 1, 1, -(-Sk2 // bn) + 1, dtype=torch.int32, device="cuda")
     with pytest.raises(RuntimeError, match=_cabi.status_string(_cabi.LA_ERR_SEQLEN)[:20]):
-        L.flash_attn_func(q, k2, k2)
+        L.flash_attn_func(q, k2, v2, attn_read_list=lists[0], attn_write_list=lists[1])
 
 
 @pytest.mark.parametrize("D", DIMS)

@@ -239,6 +239,9 @@ def vote_writer_check(q: torch.Tensor, k: torch.Tensor, read_list: torch.Tensor,
 # build's 256 x 64 tile on DenoiseWorkload(40 heads): bisected on all 40 heads by tools/calibrate_denoise.py, trace and result in
 # profiles/r04_denoise50_calibration.json (they give 21.0 / 42.2 / 57.1 / 77.3 %; round 1's constants -5.157 / -4.22 / -3.399 / -2.462, bisected on 4 heads, gave 24.5 / 44.0 / 61.1 / 77.9 %).
 DENOISE_THRESHOLDS = (("21%", -5.3438), ("42%", -4.3), ("57%", -3.6), ("77%", -2.5))
+# generator="survey" (the one SURVEY.md 8(d) pins), bisected over [-20, 0) on all 40 heads: tools/calibrate_survey.py ->
+# profiles/r06_denoise50_survey_calibration.json: all four targets reached within 1 % (step-49 sparsity 21.0 / 41.9 / 57.3 / 77.2 %).
+SURVEY_DENOISE_THRESHOLDS = (("21%", -0.9726), ("42%", -0.7529), ("57%", -0.5478), ("77%", -0.1963))
 REFERENCE_T_OVER_T0 = {"21%": 0.824, "42%": 0.601, "57%": 0.443, "77%": 0.235}     # /root/reference/README.md:81-87
 
 
