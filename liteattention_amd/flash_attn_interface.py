@@ -207,8 +207,8 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
                                   "(the reference's skip walk is non-causal only, mainloop:1757-1827)")
     if softcap != 0.0:
         raise NotImplementedError("softcap is compiled out (hopper/setup.py:52)")
-    if num_splits < 0 or num_splits > 128:
-        raise RuntimeError("num_splits must be in [0, 128]")
+    if num_splits < -1 or num_splits > 128:
+        raise RuntimeError("num_splits must be in [-1, 128]")
     if num_splits > 1 and (attn_read_list is not None or _q_windows is not None or cu_seqlens_q is not None or cu_seqlens_k is not None):
         raise NotImplementedError("split-KV (num_splits > 1) serves dense fixed-length launches only: a skip list walks ITS tiles of the whole key range")
     if pack_gqa:
@@ -243,12 +243,13 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
         raise NotImplementedError("head_dim_v != head_dim is outside the QK-Skip hot path in this build")
     if softmax_scale is None:
         softmax_scale = D ** -0.5
-    if num_splits != 1 and attn_read_list is None and _q_windows is None and not (is_fp8 and D > 128):
+    if (num_splits > 1 or num_splits == -1) and attn_read_list is None and _q_windows is None and not (is_fp8 and D > 128):
         # split-KV on the host (round 6; the reference: get_num_splits / num_splits_heuristic, flash_api.cpp:437-465, heuristics.h:25-58,
-        # compiled out of its default build, hopper/setup.py:48): a dense launch with fewer (batch, head, q-tile) items than the device
-        # has workgroup slots leaves compute units idle (text queries against the video keys: 80 items on 256). num_splits = 0: decide
-        # here by the reference's rule; > 1: that many. ONE launch over the (batch x split) pairs as a packed batch, then la_combine.
-        n = _num_splits(B, H, Sq, Sk, D, q.element_size(), num_splits)
+        # compiled out of its default build, hopper/setup.py:48 - where num_splits = 0 therefore means 1, as it does here): a dense launch
+        # with fewer (batch, head, q-tile) items than the device has workgroup slots leaves compute units idle (text queries against the
+        # video keys: 80 items on 256). num_splits > 1: that many; -1 (extension): decide here by the reference's rule. One launch
+        # over the splits (batch 1: the splits are the batch of a fixed-length launch; else a packed batch), then la_combine.
+        n = _num_splits(B, H, Sq, Sk, D, q.element_size(), max(num_splits, 0))
         if n > 1:
             res = _mha_fwd_split_kv(q, k, v, n, out, softmax_scale, descales)
             if res is not None:

@@ -91,10 +91,11 @@ def test_recipe_at_a_threshold_that_skips_nothing_is_one_full_attention():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("B,Sq,Sk,H,Hk,n", [(1, 512, 9000, 8, 8, 0), (2, 300, 5000, 4, 2, 0), (1, 100, 3000, 2, 2, 5), (3, 64, 700, 2, 1, 3)])
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk,n", [(1, 512, 9000, 8, 8, -1), (2, 300, 5000, 4, 2, -1), (1, 100, 3000, 2, 2, 5), (3, 64, 700, 2, 1, 3)])
 def test_split_kv_of_dense_launches_with_few_items(B, Sq, Sk, H, Hk, n, dtype):
-    """Host-side split-KV (reference: get_num_splits, flash_api.cpp:437-465; heuristics.h:25-58): ``num_splits=0`` decides by the
-    reference's rule, ``num_splits=n`` forces n; the result is the unsplit launch's up to the merge's rounding, and matches the oracle."""
+    """Host-side split-KV (reference: get_num_splits, flash_api.cpp:437-465; heuristics.h:25-58): ``num_splits=-1`` decides by the
+    reference's rule, ``num_splits=n`` forces n (0 and 1: no split, as in the reference's default build); the result is the unsplit
+    launch's up to the merge's rounding, and matches the oracle."""
     import liteattention_amd as L
     from liteattention_amd.flash_attn_interface import _num_splits
     from oracle import oracle as orc
@@ -103,7 +104,7 @@ def test_split_kv_of_dense_launches_with_few_items(B, Sq, Sk, H, Hk, n, dtype):
     k = torch.randn(B, Sk, Hk, 128, generator=g).to(dtype)
     v = torch.randn(B, Sk, Hk, 128, generator=g).to(dtype)
     qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
-    chosen = _num_splits(B, H, Sq, Sk, 128, 2, n)
+    chosen = _num_splits(B, H, Sq, Sk, 128, 2, max(n, 0))
     assert chosen > 1                                           # these shapes leave most of the device idle unsplit
     o1, l1 = L.flash_attn_func(qd, kd, vd, return_softmax_lse=True)                     # num_splits = 1: the reference's default
     o2, l2 = L.flash_attn_func(qd, kd, vd, num_splits=n, return_softmax_lse=True)
@@ -113,13 +114,14 @@ def test_split_kv_of_dense_launches_with_few_items(B, Sq, Sk, H, Hk, n, dtype):
         assert o.shape == q.shape and o.dtype == dtype and l.shape == (B, H, Sq) and l.is_contiguous()
         assert (o.float().cpu() - o_ref).abs().max().item() <= (2.0 ** -8 + extra) * o_ref.abs().max().item() + 1e-3
         assert (l.cpu() - lse_ref).abs().max().item() <= 1e-3
-    o3 = L.flash_attn_func(qd, kd, vd, num_splits=n if n else chosen)
+    o3 = L.flash_attn_func(qd, kd, vd, num_splits=n if n > 0 else chosen)
     assert torch.equal(o3, o2)
+    assert torch.equal(L.flash_attn_func(qd, kd, vd, num_splits=0), o1)
     # K / V with a padded batch stride cannot be seen as packed rows: the unsplit launch runs instead, same result as num_splits = 1
     if B > 1:
         kp = torch.empty(B, Sk + 8, Hk, 128, dtype=dtype, device="cuda")[:, :Sk]
         kp.copy_(kd)
-        o4 = L.flash_attn_func(qd, kp, vd, num_splits=0)
+        o4 = L.flash_attn_func(qd, kp, vd, num_splits=-1)
         assert torch.equal(o4, o1)
     with pytest.raises(NotImplementedError):
         rd = orc.init_skip_list_ref(B, -(-Sq // bm), -(-Sk // bn), H)

@@ -61,7 +61,7 @@ def joint_recipe(L, dev, qkv=None, text_len=512, S=75600, H=40, D=128, sparsity=
         res[name] = {"ms": round(ms, 4), "launches_timed": reps, "tflops": round(flops / ms / 1e9, 1),
                      "frac_of_mfma_peak": round(flops / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)}
     from liteattention_amd.flash_attn_interface import _num_splits
-    res["t2v"]["num_splits"] = _num_splits(1, H, text_len, video, D, 2, 0)
+    res["t2v"]["num_splits"] = _num_splits(1, H, text_len, video, D, 2, 0)      # what num_splits = -1 (LiteAttention's dense calls) resolves to
     res["t2t"]["num_splits"] = _num_splits(1, H, text_len, text_len, D, 2, 0)
     merges = {"merge_text": (lambda: L.flash_attn_combine([outs["t2t"][0], outs["t2v"][0]], [outs["t2t"][1], outs["t2v"][1]]), text_len),
               "merge_video": (lambda: L.flash_attn_combine([outs["v2t"][0], outs["v2v"][0]], [outs["v2t"][1], outs["v2v"][1]]), video)}
