@@ -28,6 +28,10 @@ def _library():
     code = ("import os, ctypes, torch; lib = ctypes.CDLL(%r); lib.la_build_info.restype = ctypes.c_char_p; print(lib.la_build_info().decode())" % M16)
     info = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300).stdout
     assert "variant=1" in info and "wrong_results=0" in info and "m16" in info, info
+    sys.path.insert(0, ROOT)
+    from liteattention_amd import _buildinfo
+    if _buildinfo.parse(info.strip()).get("src") != _buildinfo.source_hash():
+        pytest.skip("build_variants/m16.so was built from other sources than this tree (stale): python -m liteattention_amd.build --m16")
 
 
 def test_parity_suite_on_the_16x16x32_body():
