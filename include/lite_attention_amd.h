@@ -66,7 +66,7 @@ typedef enum la_status {
                                   * hand-scheduled kernel: bf16 / fp16 head_dim 128 (the skip lists then use 128-row q-tiles instead of
                                   * 256-row ones: take the tile sizes from la_get_tile_sizes_ex() with the same flags) and head_dim 256
                                   * (same tiles). head_dim 96 / 192 have no such instantiation: LA_ERR_HEAD_DIM. fp8: LA_ERR_UNSUPPORTED. */
-#define LA_FLAG_HALF_VOTE 64u    /* bf16 / fp16 head_dim 128 (no effect elsewhere; LA_FLAG_KERNEL_128ROW wins when both are set): the hand-scheduled
+#define LA_FLAG_HALF_VOTE 64u    /* bf16 / fp16 head dims 64 / 96 / 128 - the kernels with a 256-row q-tile (no effect elsewhere; LA_FLAG_KERNEL_128ROW wins when both are set): the hand-scheduled
                                   * kernel keeps its skip lists per 128-ROW HALF of its 256-row workgroup - the reference's own q-granularity for
                                   * this head dim (kBlockM = 128, tile_size.h:35-39). la_get_tile_sizes_ex() reports (128, 64) with it. The
                                   * workgroup walks the UNION of its two halves' lists (never longer than the 256-row list of the same votes), and

@@ -152,11 +152,13 @@ def generate_bodies(gen_dir: str, variant: bool, defines=(), quiet=subprocess.DE
         if variant and head_dim == 128 and any(d.replace(" ", "") == "LA_X64_M16=1" for d in defines):
             gen = X64_M16_GEN                       # -DLA_X64_M16=1 (A/B build): head_dim 128 on v_mfma_f32_16x16x32 (LA_X64_OPT tunes it)
         generate(gen, inc, env, body_macro(head_dim, dtype))
-    for dtype, inc, macro in (("bf16", X64_HALF_INC, "LA_X64_HALF_BODY_INC"), ("f16", X64_HALF_F16_INC, "LA_X64_HALF_F16_BODY_INC")):
-        env = dict(base_env, LA_X64_D="128", LA_X64_DTYPE=dtype, LA_X64_FORM="half")       # skip lists per 128-row half (LA_FLAG_HALF_VOTE)
-        if variant:
-            env["LA_X64_OPT"] = os.environ.get("LA_X64_HALF_OPT", "")
-        generate(X64_GEN, inc, env, macro)
+    for head_dim in (128, 64, 96):                         # skip lists per 128-row half (LA_FLAG_HALF_VOTE): the 256-row kernels
+        for dtype in ("bf16", "f16"):
+            stem = ("" if head_dim == 128 else f"d{head_dim}_") + "half_" + ("f16_" if dtype == "f16" else "")
+            env = dict(base_env, LA_X64_D=str(head_dim), LA_X64_DTYPE=dtype, LA_X64_FORM="half")
+            if variant:
+                env["LA_X64_OPT"] = os.environ.get("LA_X64_HALF_OPT" if head_dim == 128 else f"LA_X64_D{head_dim}_HALF_OPT", "")
+            generate(X64_GEN, f"la_fwd_x64_{stem}body.inc", env, "LA_X64_" + stem.upper() + "BODY_INC")
     f8_default = os.environ.get("LA_X64F8_DEFAULT_OPT", "") if variant else ""      # a global LA_X64F8_OPT never reaches the default body
     generate(X64F8_GEN, X64F8_INC, dict(base_env, LA_X64F8_OPT=f8_default), "LA_X64F8_BODY_INC", "LA_X64F8_CONSTS_INC")
     for form, inc in (("exp", X64F8_EXP_INC), ("lvalu", X64F8_LVALU_INC)):       # LA_X64F8_<FORM>_OPT tunes that body alone (variants only)

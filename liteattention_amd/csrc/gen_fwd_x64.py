@@ -813,11 +813,9 @@ def _step(variant, a_cur=True, a_nxt=True):
         # critical path: +30 cycles per step, measured.
         t_stats = max(t for t in range(NG) if any(isinstance(it, str) and it.startswith(flback) for it in post[t]))
         ops = state_ops()
-        assert t_stats + 4 < NG
-        post[t_stats + 1].append(ops[0])
-        post[t_stats + 2].append(ops[1])
-        post[t_stats + 3].append(ops[2])
-        post[t_stats + 4] += ops[3:]               # the compare and the select that reads its SCC: adjacent
+        groups = [ops[0:1], ops[1:2], ops[2:3], ops[3:]]           # (the compare and the select that reads its SCC: adjacent)
+        for g_, grp in enumerate(groups):                           # one group per gap behind the statistics; what does not fit: the last gap
+            post[min(t_stats + 1 + g_, NG - 1)] += grp
     mark = len(out)
     emit_gaps(pre, mf, post)
     if variant == 0 and full:

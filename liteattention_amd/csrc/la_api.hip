@@ -29,10 +29,12 @@ constexpr uint32_t kKnownFlags = LA_FLAG_V_PREPARED | LA_FLAG_STATIC_SCHED | LA_
 bool uses_128row(int head_dim, int element_size, uint32_t flags) {      // the flag changes the q-tile (256 -> 128 rows) at head dims 64 and 128
     return element_size == 2 && (head_dim == 128 || head_dim == 64) && (flags & LA_FLAG_KERNEL_128ROW) != 0;
 }
-// LA_FLAG_HALF_VOTE: the hand-scheduled kernel with skip lists per 128-row half of its 256-row workgroup (bf16 / fp16 head_dim 128; no
-// effect elsewhere, and LA_FLAG_KERNEL_128ROW - another kernel with the same list geometry - wins when both are set)
+// LA_FLAG_HALF_VOTE: the hand-scheduled kernel with skip lists per 128-row half of its 256-row workgroup (bf16 / fp16 head dims 64 / 96 / 128,
+// the kernels with a 256-row q-tile; no effect elsewhere, and LA_FLAG_KERNEL_128ROW - another kernel with the same list geometry - wins
+// when both are set)
 bool uses_half_vote(int head_dim, int element_size, uint32_t flags) {
-    return element_size == 2 && head_dim == 128 && (flags & LA_FLAG_HALF_VOTE) != 0 && (flags & LA_FLAG_KERNEL_128ROW) == 0;
+    return element_size == 2 && (head_dim == 128 || head_dim == 96 || head_dim == 64) && (flags & LA_FLAG_HALF_VOTE) != 0 &&
+           (flags & LA_FLAG_KERNEL_128ROW) == 0;
 }
 // Long DENSE key ranges (bf16 / fp16, hand-scheduled kernels). A workgroup keeps the tile-address table of its walk in LDS, which bounds the key
 // tiles of ONE launch (~4 800 at head_dim <= 128, ~1 600 at 192 / 256). A skip list names its tiles over the whole key range and keeps that

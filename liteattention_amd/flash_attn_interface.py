@@ -111,12 +111,12 @@ def device_slots(head_dim: int, element_size: int) -> Tuple[int, int]:
 
 
 def q_tiles_per_item(head_dim: int, element_size: int) -> int:
-    """q-tiles (rows of the skip lists) one workgroup item of the kernel covers: 2 under LA_FLAG_HALF_VOTE at bf16 / fp16 head_dim 128 (lists
+    """q-tiles (rows of the skip lists) one workgroup item of the kernel covers: 2 under LA_FLAG_HALF_VOTE at bf16 / fp16 head dims <= 128 (lists
     per 128-row half of a 256-row workgroup: q-tile windows then start on an even q-tile and hold an even number unless they reach the
     last one), else 1."""
     flags = _cabi.default_flags()
     half = (flags & _cabi.LA_FLAG_HALF_VOTE) and not (flags & _cabi.LA_FLAG_KERNEL_128ROW) and element_size == 2 \
-        and kernel_head_dim(head_dim, element_size, flags) == 128
+        and kernel_head_dim(head_dim, element_size, flags) in (64, 96, 128)
     return 2 if half else 1
 
 
@@ -399,7 +399,11 @@ def num_splits_heuristic(total_mblocks: int, slots: int, num_n_blocks: int, max_
         waves = total_mblocks * s / slots
         eff.append(waves / -(-(total_mblocks * s) // slots))
     best = max(eff)
-    return next(s for s, e in enumerate(eff, 1) if e >= 0.85 * best)
+    n = next(s for s, e in enumerate(eff, 1) if e >= 0.85 * best)
+    # this device, measured (tools/debug/split_kv_probe.py, Sq = 512 against 75 088 keys, 80 items on 256 compute units): 2.70 ms unsplit,
+    # 0.97 / 0.84 / 0.82 / 0.84 ms with 3 / 4 / 6 / 8 splits - an item that streams K / V alone pays the cold-HBM latency per tile, so a
+    # few more items than slots (a short second round) still pays: at least 1.25 rounds of items, where the reference's rule stops at one
+    return min(max_splits, max(n, -(-(5 * slots) // (4 * total_mblocks))))
 
 
 def _num_splits(B, H, Sq, Sk, D, element_size, requested):

@@ -37,7 +37,7 @@ def test_a_poisoned_environment_yields_the_clean_product_bodies(tmp_path):
     clean_dir.mkdir(); dirty_dir.mkdir()
     a = _generate(clean_dir, False, {})
     b = _generate(dirty_dir, False, POISON)
-    assert len(a["generated"]) == 15 and [os.path.basename(p) for p in a["generated"]] == [os.path.basename(p) for p in b["generated"]]
+    assert len(a["generated"]) == 19 and [os.path.basename(p) for p in a["generated"]] == [os.path.basename(p) for p in b["generated"]]
     for pa, pb in zip(a["generated"], b["generated"]):
         assert open(pa, "rb").read() == open(pb, "rb").read(), os.path.basename(pa)        # byte for byte
         head = open(pb).read(400)
@@ -127,11 +127,11 @@ def test_every_loop_head_sits_at_its_pinned_code_placement():
                 nxt = re.search(r"^[0-9a-f]+ <", seg, re.M)
                 seg = seg[:nxt.start()] if nxt else seg
                 heads = re.findall(r"s_cmp_lt_u32 s63, s55\s+// ([0-9A-Fa-f]+):", seg)          # the loop test: S_I < S_NTILES
-                if "Li128ELb1E" in m.group(1):          # the half-vote form: its loop head is the test of the step form (the loop test sits in front of the drain)
+                if re.search(r"Li\d+ELb1E", m.group(1)):          # the half-vote form: its loop head is the test of the step form (the loop test sits in front of the drain)
                     heads = re.findall(r"s_cmp_eq_u32 s81, 3\s+// ([0-9A-Fa-f]+):", seg)
                 if not heads:
                     continue
                 key = next(k for k in want if k in m.group(1))
                 assert int(heads[0], 16) % 32 == want[key], (m.group(1), int(heads[0], 16) % 32, want[key])
                 seen += 1
-    assert seen == 28, seen            # 5 head dims x 2 element types x 2 (lists / dense) + the half-vote form of head_dim 128 x 2 element types + 3 fp8 forms x 2
+    assert seen == 32, seen            # 5 head dims x 2 element types x 2 (lists / dense) + the half-vote form of head dims 64 / 96 / 128 x 2 element types + 3 fp8 forms x 2

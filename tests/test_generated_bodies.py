@@ -11,6 +11,7 @@ import pytest
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "liteattention_amd", "csrc")
 CASES = [("gen_fwd_x64.py", {"LA_X64_D": str(d), "LA_X64_DTYPE": t}) for d in (96, 128, 192, 256) for t in ("bf16", "f16")] + \
+        [("gen_fwd_x64.py", {"LA_X64_D": str(d), "LA_X64_DTYPE": "bf16", "LA_X64_FORM": "half"}) for d in (64, 96, 128)] + \
         [("gen_fwd_x64_fp8.py", {})]
 
 

@@ -81,9 +81,10 @@ def _rows_to_lists(rows, Kt):
     return out
 
 
+@pytest.mark.parametrize("D", [128, 64, 96])
 @pytest.mark.parametrize("S", [1000, 1536, 700])
 @pytest.mark.parametrize("thr", [-2.0, -5.0])
-def test_lists_over_steps_match_the_oracle_at_128_rows(half, S, thr):
+def test_lists_over_steps_match_the_oracle_at_128_rows(half, S, thr, D):
     """Five denoising-like steps through LiteAttention: lists [2, B, H, ceil(S / 128), Kt + 1]; at every step the oracle gets the kernel's
     read list. S = 1000: the last workgroup's second half is partial (rows 896..999); S = 700: 6 list rows, the last one of 60 rows; S = 1536:
     whole workgroups."""
@@ -93,7 +94,7 @@ def test_lists_over_steps_match_the_oracle_at_128_rows(half, S, thr):
     Qt, Kt = -(-S // BM), -(-S // BN)
     dropped = 0
     for step in range(5):
-        q, k, v = fragmented_qkv(B, S, H, 128, seed=4, step=step)
+        q, k, v = fragmented_qkv(B, S, H, D, seed=4, step=step)
         rd_idx = att._phase if att._skip_list is not None else 0
         out, lse = att(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
         assert att._skip_list.shape == (2, B, H, Qt, Kt + 1)
@@ -112,14 +113,15 @@ def test_lists_over_steps_match_the_oracle_at_128_rows(half, S, thr):
     assert any(not torch.equal(fin[0, h, 2 * m], fin[0, h, 2 * m + 1]) for h in range(H) for m in range(Qt // 2))
 
 
-def test_halves_with_different_first_tiles_ranges_and_lengths(half):
+@pytest.mark.parametrize("D", [128, 64, 96])
+def test_halves_with_different_first_tiles_ranges_and_lengths(half, D):
     """Imposed read lists in which the halves of a workgroup share nothing but the kernel: different first tiles (a half that is NOT active
     at the first union position starts from the empty state and masks nothing), ranges that interleave, a half listing one tile, a
     half listing everything, range ends of one half in the middle of the other's ranges; thr = -3 so that write lists are non-trivial."""
     L, orc = half
     B, S, H = 1, 1024 + 77, 2                          # ragged last key tile (Kt = 18: tile 17 holds 13 keys)
     Kt, Qt = -(-S // BN), -(-S // BM)
-    q, k, v = structured_qkv(B, S, H, 128, seed=21)
+    q, k, v = structured_qkv(B, S, H, D, seed=21)
     assert Qt == 9 and Kt == 18
     even = [17, 12, 9, 9, 6, 2]
     odd = [14, 13, 11, 10, 8, 7, 5, 5, 1, 0]
@@ -193,7 +195,8 @@ def test_q_tile_windows_in_pairs_of_halves(half):
 
 def test_dense_launches_and_other_head_dims_ignore_the_flag(half):
     L, orc = half
-    assert L.get_tile_sizes(64, 2) == (256, 64) and L.get_tile_sizes(256, 2) == (128, 64) and L.get_tile_sizes(128, 1) == (256, 64)
+    assert L.get_tile_sizes(64, 2) == (128, 64) and L.get_tile_sizes(96, 2) == (128, 64)          # the 256-row kernels all have the form
+    assert L.get_tile_sizes(256, 2) == (128, 64) and L.get_tile_sizes(192, 2) == (128, 64) and L.get_tile_sizes(128, 1) == (256, 64)
     q, k, v = structured_qkv(1, 700, 2, 128, seed=3)
     o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=BM, block_n=BN)
     out, lse = L.flash_attn_func(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
@@ -208,8 +211,9 @@ def _suite(args, timeout=1500):
 
 @pytest.mark.parametrize("files", [["tests/test_gpu_parity.py", "tests/test_gpu_headline.py"],
                                    ["tests/test_gpu_fragmented.py", "tests/test_gpu_fp16.py", "tests/test_gpu_gqa_windows.py"],
-                                   ["tests/test_gpu_varlen_lists.py", "tests/test_gpu_denoise_lists.py", "tests/test_gpu_round2.py"]],
-                         ids=["parity+headline", "fragmented+fp16+gqa_windows", "varlen+denoise+round2"])
+                                   ["tests/test_gpu_varlen_lists.py", "tests/test_gpu_denoise_lists.py", "tests/test_gpu_round2.py"],
+                                   ["tests/test_gpu_head_dims.py", "tests/test_gpu_round4.py", "tests/test_gpu_reference_grid.py"]],
+                         ids=["parity+headline", "fragmented+fp16+gqa_windows", "varlen+denoise+round2"] + ["head_dims+round4+reference_grid"])
 def test_the_parity_suite_under_the_half_vote_geometry(files):
     r = _suite(files)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -19,7 +19,9 @@ def test_wan_style_block_runs_and_skipping_stays_close_to_dense():
     assert all(r[2] < 2e-2 for r in rows)                  # thr = -6: contributions below 2^-6 of the running max dropped
     # threshold very negative: nothing may be skipped and the block equals the dense block to bf16 round-off
     rows = demo.run(frames=4, height=16, width=20, heads=3, steps=2, threshold=-60.0, verbose=False)
-    assert rows[-1][1] == 0.0 and rows[-1][2] < 1e-6
+    # (2^-7: the dense block's attention has few items here - 15 on 256 compute units - and is split over the keys on the host, so its
+    # result went through one more bf16 rounding, the merge's, than the list-walking launch it is compared with)
+    assert rows[-1][1] == 0.0 and rows[-1][2] < 2.0 ** -7
 
 
 def test_wan_cross_attention_through_the_flash_attn_import_names():
