@@ -106,7 +106,8 @@ def test_q_tile_windows_equal_one_launch_bit_exactly(dtype, D):
     if dtype == "fp8":
         q, k, v = [x.float().to(F8) for x in (q, k, v)]
     q, k, v = q.cuda(), k.cuda(), v.cuda()
-    u = 2 if (bm, D, es) == (128, 128, 2) and os.environ.get("LA_VOTE", "").startswith("half") else 1     # LA_FLAG_HALF_VOTE: windows are pairs of 128-row q-tiles
+    from liteattention_amd.flash_attn_interface import q_tiles_per_item
+    u = q_tiles_per_item(D, es)                                  # LA_FLAG_HALF_VOTE (LA_VOTE=half): windows are pairs of 128-row q-tiles
     cuts = sorted({0, u, (Qt // 2) // u * u, Qt})
     windows = [(a, b - a) for a, b in zip(cuts[:-1], cuts[1:])]
     assert len(windows) >= 2

@@ -315,7 +315,10 @@ def test_windowed_launches_are_bit_identical_under_a_co_running_copy_stream():
     peers = torch.empty_like(ref_o)
     for n, sched in ((3, False), (3, "after_first"), (5, "after_first")):
         att = fresh()
-        w = plan_q_windows(-(-S // bm), H, n, slots=16)               # small "machine": several rounds per window at this size
+        from liteattention_amd.flash_attn_interface import q_tiles_per_item
+        u = q_tiles_per_item(D, 2)                                    # LA_VOTE=half: a workgroup item is two 128-row q-tiles; windows hold whole items
+        qt_all = -(-S // bm)
+        w = [(b0 * u, min(c0 * u, qt_all - b0 * u)) for b0, c0 in plan_q_windows(-(-qt_all // u), H, n, slots=16)]   # small "machine": several rounds per window
         assert len(w) >= 2
 
         def hook(i, out, r0, r1):
