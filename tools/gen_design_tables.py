@@ -51,12 +51,18 @@ def blocks(tag):
         if f8.get("value"):
             p8 = f8.get("power") or {}
             note = f"{p8.get('socket_w', 'n/a')} W at {f((p8.get('sclk_mhz') or 0) / 1000, 2)} GHz; verified {f8.get('verified', {}).get('ok')} (max err {f8.get('verified', {}).get('max_err')})"
-            if f8.get("exact_exp"):
+            if f8.get("exact_exp"):                    # lines of rounds 3-5: the encoded form was the default, the reference's arithmetic behind a flag
                 note += f"; LA_FLAG_EXACT_EXP on the same box: {f(f8['exact_exp']['value'])} TFLOP/s"
             if f8.get("exact_rowsum"):
                 note += (f"; **LA_FLAG_EXACT_ROWSUM (the reference's arithmetic): {f(f8['exact_rowsum']['value'])} TFLOP/s = {f(f8['exact_rowsum']['frac'], 3)}**, "
                          f"verified {(f8['exact_rowsum'].get('verified') or {}).get('ok')}")
-            rows.append(f"| **fp8 C3 imposed 42 %** (default block-scaled encoding of P) | {f8['ms_per_step']} | **{f(f8['value'])}** | **{f(f8['roofline']['frac'], 3)}** of 5 PF | {note} |")
+            if f8.get("mfma_rowsum"):                  # round 6: the default IS the reference's arithmetic; the two opt-in forms beside it
+                note += f"; opt-in LA_FLAG_FP8_MFMA_ROWSUM on the same box: {f(f8['mfma_rowsum']['value'])} TFLOP/s = {f(f8['mfma_rowsum']['frac'], 3)}"
+            if f8.get("encoded_p"):
+                note += (f"; opt-in LA_FLAG_FP8_ENCODED_P (block-scaled encoding of P, not the reference's arithmetic): {f(f8['encoded_p']['value'])} TFLOP/s = "
+                         f"{f(f8['encoded_p']['frac'], 3)}, verified {(f8['encoded_p'].get('verified') or {}).get('ok')}")
+            form = "default: the reference's arithmetic" if f8.get("mfma_rowsum") or f8.get("encoded_p") else "default block-scaled encoding of P"
+            rows.append(f"| **fp8 C3 imposed 42 %** ({form}) | {f8['ms_per_step']} | **{f(f8['value'])}** | **{f(f8['roofline']['frac'], 3)}** of 5 PF | {note} |")
         for run in (b.get("other_head_dims") or {}).get("runs", []):
             rows.append(f"| bf16 head_dim {run['head_dim']}, dense S = 16 384 H = 40, tiles {run['tiles'][0]} x {run['tiles'][1]} | {run['ms']} | {f(run['tflops'])} | "
                         f"{f(run['frac_of_mfma_peak'], 3)} | verified {run['verified']['ok']} |")
@@ -119,7 +125,8 @@ def blocks(tag):
         if all(k in tf for k in ("default", "exp", "rowsum")):
             base = tf["rowsum"][1]
             rows = ["| form of P | C3 dense / imposed 42 %, TFLOP/s | vs the reference's form | real step-49 lists thr -4.22 / -2.46: max abs O error (bound), max abs LSE error |", "|---|---|---|---|"]
-            for key, name in (("rowsum", "`LA_FLAG_EXACT_ROWSUM` (the reference's arithmetic)"), ("exp", "`LA_FLAG_EXACT_EXP`"), ("default", "**default** (block-scaled log-linear encoding)")):
+            for key, name in (("rowsum", "**default** (the reference's arithmetic; `LA_FLAG_EXACT_ROWSUM` until round 5)"), ("exp", "`LA_FLAG_FP8_MFMA_ROWSUM` (`LA_FLAG_EXACT_EXP` until round 5)"),
+                              ("default", "`LA_FLAG_FP8_ENCODED_P` (block-scaled log-linear encoding; the default until round 5)")):
                 e1, e2 = err.get((key, "-4.22")), err.get((key, "-2.462"))
                 es = f"{e1[0]} ({e1[1]}), {e1[2]} / {e2[0]} ({e2[1]}), {e2[2]}" if e1 and e2 else "n/a"
                 rows.append(f"| {name} | {tf[key][0]:.0f} / {tf[key][1]:.0f} | {100 * (tf[key][1] / base - 1):+.1f} % | {es} |")

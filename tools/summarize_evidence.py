@@ -107,8 +107,9 @@ with open(os.path.join(PROF, f"{tag}_kernel_stats.csv"), "w") as f:
 
 for dt in ("bf16", "fp8"):
     kname = "la_fwd_x64_fp8" if dt == "fp8" else "la_fwd_x64_kernel"
-    # fp8: the bench line also times the LA_FLAG_EXACT_EXP body (template argument 1); the PMC passes and this summary are the default body (0)
-    stat_name = "la_fwd_x64_fp8_kernel<true, 0>" if dt == "fp8" else kname
+    # fp8: the bench line also times the two opt-in forms (template arguments 1 = LA_FLAG_FP8_MFMA_ROWSUM, 0 = LA_FLAG_FP8_ENCODED_P); the PMC passes
+    # and this summary are the DEFAULT body (2: the reference's arithmetic)
+    stat_name = "la_fwd_x64_fp8_kernel<true, 2>" if dt == "fp8" else kname
     avg_ms = next((r["avg_ms"] for r in ks if stat_name in r["name"]), None)
     pmc, meta = {}, {}
     for pas in ("mfma", "wait", "fetch", "write"):
