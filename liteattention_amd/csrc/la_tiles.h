@@ -31,6 +31,8 @@ constexpr TileShape tile_shape(int head_dim, int element_size) {
     }
     if (element_size == 1) {
         if (head_dim == 128) return {256, 64};  // fp8 e4m3: x64 structure on the block-scaled MFMA; K 8 KiB + V^T 8 KiB per stage
+        if (head_dim == 192 || head_dim == 256) return {128, 64};   // no fp8 body above 128: la_fwd up-converts the operands into the workspace
+                                                                    // (la_prep_fp8.hip) and runs the bf16 kernel of that head dim: ITS tiles
     }
     return {0, 0};
 }

@@ -79,7 +79,7 @@ def kernel_head_dim(head_dim: int, element_size: int, flags: Optional[int] = Non
     zero-pads q, k, v to it (``mha_fwd``), which is exact: zero columns add 0 to every score and give zero output columns,
     which are sliced away. The reference instantiates 64/96/128/192/256 (hopper/setup.py:57-61) and picks the next size up the
     same way (flash_api.cpp round_up_headdim). bf16 / fp16: 64, 96, 128, 192, 256 are built (with LA_FWD_KERNEL=v2, the
-    hipcc-scheduled A/B kernels: 64, 128, 256); fp8: 128; beyond that the library's typed error is raised. The library is
+    hipcc-scheduled A/B kernels: 64, 128, 256); fp8: 128 natively, 192 / 256 on the bf16 kernels inside la_fwd; beyond that the library's typed error is raised. The library is
     asked (``la_get_tile_sizes_ex``), there is no second table here."""
     if head_dim <= 0 or head_dim % (16 if element_size == 1 else 8) != 0:
         return head_dim                                      # la_get_tile_sizes / mha_fwd report the error
@@ -93,9 +93,7 @@ def kernel_head_dim(head_dim: int, element_size: int, flags: Optional[int] = Non
 
 def get_tile_sizes(head_dim: int, element_size: int) -> Tuple[int, int]:
     """(kBlockM, kBlockN) of the gfx950 kernel that serves this head_dim — the single source for skip-list geometry.
-    e4m3 above head_dim 128 is served by the bf16 kernel of that head dim (``mha_fwd``): its tiles."""
-    if element_size == 1 and head_dim > 128:
-        element_size = 2
+    e4m3 above head_dim 128 is served by the bf16 kernel of that head dim (inside ``la_fwd``): the library answers with its tiles."""
     flags = _cabi.default_flags()
     return _cabi.get_tile_sizes(kernel_head_dim(head_dim, element_size, flags), element_size, flags)
 
@@ -103,9 +101,7 @@ def get_tile_sizes(head_dim: int, element_size: int) -> Tuple[int, int]:
 def device_slots(head_dim: int, element_size: int) -> Tuple[int, int]:
     """(compute units, resident workgroups per compute unit) of the kernel that serves this head_dim / element size - mapped exactly
     as ``get_tile_sizes`` maps them (a head dim between instantiations runs the next size up; e4m3 above head_dim 128 runs the bf16
-    kernel of that head dim), THEN asked from the library (``la_device_slots`` only knows instantiated kernels: 80 -> LA_ERR_HEAD_DIM)."""
-    if element_size == 1 and head_dim > 128:
-        element_size = 2
+    kernel of that head dim, which the library knows), THEN asked from the library (``la_device_slots`` only knows instantiated kernels: 80 -> LA_ERR_HEAD_DIM)."""
     flags = _cabi.default_flags()
     return _cabi.device_slots(kernel_head_dim(head_dim, element_size, flags), element_size, flags)
 
@@ -243,7 +239,7 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
         raise NotImplementedError("head_dim_v != head_dim is outside the QK-Skip hot path in this build")
     if softmax_scale is None:
         softmax_scale = D ** -0.5
-    if (num_splits > 1 or num_splits == -1) and attn_read_list is None and _q_windows is None and not (is_fp8 and D > 128):
+    if (num_splits > 1 or num_splits == -1) and attn_read_list is None and _q_windows is None:
         # split-KV on the host (round 6; the reference: get_num_splits / num_splits_heuristic, flash_api.cpp:437-465, heuristics.h:25-58,
         # compiled out of its default build, hopper/setup.py:48 - where num_splits = 0 therefore means 1, as it does here): a dense launch
         # with fewer (batch, head, q-tile) items than the device has workgroup slots leaves compute units idle (text queries against the
@@ -256,24 +252,10 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
                 return res
 
     host_flags = _cabi.default_flags()                       # the environment is read ONCE per call
-    if is_fp8 and D > 128:
-        # e4m3 at head dims 192 / 256 (and the padded sizes between): no fp8 kernel is built there (the reference's fp8
-        # instantiations are compiled out of its default build, hopper/setup.py:55). Served by the bf16 kernel of that head dim
-        # on up-converted operands - one extra pass over q, k, v. e4m3 values are exact in bf16, so S is the fp8 kernel's S; the
-        # descales ride on q (q_descale * k_descale) and v (v_descale), each rounded to bf16 once (exact when they are 1 or
-        # powers of two); P is bf16, i.e. MORE precise than an fp8 kernel's. Lists use the bf16 kernel's tiles (get_tile_sizes).
-        g = H // Hk
-
-        def per_head(t):                                     # (B, Hk) -> (B, 1, H, 1)
-            return t.repeat_interleave(g, dim=1)[:, None, :, None]
-        qs = None if (descales[0] is None and descales[1] is None) else \
-            (1.0 if descales[0] is None else descales[0]) * (1.0 if descales[1] is None else descales[1])
-        q16 = q.to(torch.bfloat16) if qs is None else (q.float() * per_head(qs)).to(torch.bfloat16)
-        v16 = v.to(torch.bfloat16) if descales[2] is None else (v.float() * descales[2][:, None, :, None]).to(torch.bfloat16)
-        return mha_fwd(q16, k.to(torch.bfloat16), v16, out=out, softmax_scale=softmax_scale, attn_read_list=attn_read_list,
-                       attn_must_do_list=attn_must_do_list, attn_write_list=attn_write_list, thr=thr, _must_do_is_1d=_must_do_is_1d,
-                       _q_windows=_q_windows, _window_hook=_window_hook, _static_sched=_static_sched,
-                       _flags=_flags & _cabi.LA_FLAG_EXACT_RESCALE)
+    # (e4m3 at head dims 192 / 256 and the padded sizes between: no fp8 body is built there - the reference's own fp8 instantiations are
+    # compiled out of its default build, hopper/setup.py:55 - the LIBRARY serves them with the bf16 kernel of that head dim on operands it
+    # up-converts into the workspace, descales folded in (la_prep_fp8.hip; rounds 3-5 did that here with torch elementwise passes). Lists
+    # use that kernel's tiles, which is what la_get_tile_sizes answers for them.)
     D_kernel = kernel_head_dim(D, q.element_size(), host_flags)
     if D_kernel != D:
         # head_dim between the instantiated sizes: zero-pad the last dim (one extra pass over q, k, v; exact, see
@@ -553,20 +535,6 @@ def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
                 raise RuntimeError(f"{name} must be a float32 tensor of shape (batch_size, nheads_k) on the input device")
         descales.append(t)
     out_dtype = torch.bfloat16 if is_fp8 else q.dtype                                              # :859-863
-    if is_fp8 and D > 128:
-        # as in mha_fwd: e4m3 above head_dim 128 runs on the bf16 kernel of that head dim after an up-conversion pass; the per-(sequence,
-        # K/V head) descales are spread over the packed rows on the device (no host sync: the output sizes are the packed totals)
-        g = H // Hk
-        lens_q = (cu_seqlens_q[1:] - cu_seqlens_q[:-1]).long()
-        lens_k = (cu_seqlens_k[1:] - cu_seqlens_k[:-1]).long()
-        qs = None if (descales[0] is None and descales[1] is None) else \
-            (1.0 if descales[0] is None else descales[0]) * (1.0 if descales[1] is None else descales[1])
-        q16 = q.to(torch.bfloat16) if qs is None else \
-            (q.float() * torch.repeat_interleave(qs.repeat_interleave(g, dim=1), lens_q, dim=0, output_size=Tq)[:, :, None]).to(torch.bfloat16)
-        v16 = v.to(torch.bfloat16) if descales[2] is None else \
-            (v.float() * torch.repeat_interleave(descales[2], lens_k, dim=0, output_size=Tk)[:, :, None]).to(torch.bfloat16)
-        return _mha_fwd_varlen(q16, k.to(torch.bfloat16), v16, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, None, None, None,
-                               softmax_scale, attn_read_list, attn_write_list, attn_must_do_list, thr, _must_do_is_1d)
     D_kernel = kernel_head_dim(D, q.element_size())
     if D_kernel != D:
         if out is not None and (out.dtype != out_dtype or tuple(out.shape) != (Tq, H, D) or out.stride(-1) != 1):

@@ -289,13 +289,17 @@ def test_round4_entry_points_validate_without_a_device():
 
 def test_window_planning_maps_the_head_dim_before_asking_the_library():
     """``HeadShardedLiteAttention.q_windows`` asked ``la_device_slots`` with the RAW head dim / element size, which
-    the library only answers for instantiated kernels (80, 72 -> LA_ERR_HEAD_DIM; e4m3 at 256 -> LA_ERR_HEAD_DIM), so every overlapped
-    call at a zero-padded head dim raised. The host maps exactly as ``get_tile_sizes`` does (80 -> 96, e4m3 above 128 -> bf16 kernel)."""
+    the library only answers for instantiated kernels (80, 72 -> LA_ERR_HEAD_DIM), so every overlapped call at a zero-padded head dim
+    raised. The host maps exactly as ``get_tile_sizes`` does (80 -> 96); e4m3 at 192 / 256 is answered by the library itself since round 6
+    (la_fwd serves it with the bf16 kernel of that head dim: its tiles, its slots)."""
     from liteattention_amd import flash_attn_interface as fai
     lib = _cabi.load()
     cu, per = ctypes.c_int(), ctypes.c_int()
-    for d, e in ((80, 2), (72, 2), (256, 1)):
+    for d, e in ((80, 2), (72, 2), (160, 1)):
         assert lib.la_device_slots(d, e, 0, ctypes.byref(cu), ctypes.byref(per)) == _cabi.LA_ERR_HEAD_DIM      # the raw question fails
+    m, n = ctypes.c_int(), ctypes.c_int()
+    assert lib.la_get_tile_sizes(256, 1, ctypes.byref(m), ctypes.byref(n)) == _cabi.LA_OK and (m.value, n.value) == (128, 64)
+    assert lib.la_get_tile_sizes(192, 1, ctypes.byref(m), ctypes.byref(n)) == _cabi.LA_OK and (m.value, n.value) == (128, 64)
     try:
         want96, want256 = _cabi.device_slots(96, 2), _cabi.device_slots(256, 2)
     except RuntimeError:

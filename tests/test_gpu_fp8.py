@@ -169,7 +169,7 @@ def test_fp8_running_max_that_grows_late_in_the_walk(gain):
 @pytest.mark.parametrize("D", [192, 256, 160])
 def test_fp8_above_head_dim_128_runs_on_the_bf16_kernel_of_that_head_dim(D):
     """No fp8 kernel is built above head_dim 128 (the reference's fp8 instantiations are compiled out of its default build,
-    hopper/setup.py:55): the host up-converts e4m3 -> bf16 (exact), puts q_descale * k_descale on q and v_descale on v, and runs the
+    hopper/setup.py:55): la_fwd up-converts e4m3 -> bf16 (exact) into its workspace (round 6: a fused pass per tensor inside the library; until round 5 torch elementwise passes on the host), puts q_descale * k_descale on q and v_descale on v, and runs the
     bf16 kernel of that head dim with ITS tiles. Dense with GQA + descales against the oracle with fp32 P (the result is more precise
     than an fp8 kernel's: P is bf16), then three steps of lists with power-of-two descales (exact) against the oracle."""
     import liteattention_amd as L
