@@ -12,7 +12,8 @@ def test_design_tables_are_generated_from_the_committed_profiles():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_design_tables.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     text = open(os.path.join(ROOT, "MEASUREMENTS.md")).read()
-    for name in ("headline", "rocprof_bf16", "rocprof_fp8", "traffic", "real_gap", "fp8_forms", "sched_sweep", "denoise50"):
+    for name in ("headline", "rocprof_bf16", "rocprof_fp8", "traffic", "real_gap", "fp8_forms", "sched_sweep", "denoise50", "denoise50_survey",
+                 "half_vote", "joint_recipe"):
         body = text.split(f"<!-- GEN:{name} -->")[1].split(f"<!-- /GEN:{name} -->")[0]
         assert body.strip(), f"generated block {name} is empty"
 

@@ -143,6 +143,30 @@ def test_phase_and_reinit_rules(rec):
         att(torch.zeros(3, 300, 3, 128, dtype=torch.bfloat16), kshort.repeat(3, 1, 1, 1), kshort.repeat(3, 1, 1, 1))
 
 
+def test_split_heuristic_restates_the_reference_rule_and_adds_its_round():
+    """`num_splits_heuristic` (flash_attn_interface.py) after hopper/_internal/cpp/heuristics.h:25-58 (non-causal branch): no split when the
+    items almost fill the device or the key range is at most four of the REFERENCE's tiles (704 keys); otherwise the smallest split count
+    within 85 % of the best last-round efficiency - raised here to at least 1.25 rounds of items (measured: profiles/r06_split_kv.md)."""
+    from liteattention_amd.flash_attn_interface import num_splits_heuristic as h
+
+    def ref_rule(total, slots, nblocks, max_splits=128):          # heuristics.h:25-58, restated line by line
+        import math
+        if total >= 0.8 * slots:
+            return 1
+        if nblocks <= 4:
+            return 1
+        max_splits = min(max_splits, slots, nblocks)
+        eff = [(total * s / slots) / math.ceil(total * s / slots) for s in range(1, max_splits + 1)]
+        return next(s for s, e in enumerate(eff, 1) if e >= 0.85 * max(eff))
+    assert h(300, 256, 1000, keys=64000) == 1 and h(205, 256, 1000, keys=64000) == 1          # >= 0.8 of the slots
+    assert h(80, 256, 8, keys=512) == 1 and h(80, 256, 11, keys=704) == 1                      # "never split for hdim 128 and seqlen_k 512"
+    assert h(80, 256, 4, keys=70000) == 1
+    for total, slots, nblocks in ((80, 256, 1174), (16, 256, 141), (8, 256, 79), (100, 256, 40), (1, 256, 5000), (200, 304, 64)):
+        want = max(ref_rule(total, slots, nblocks), -(-(5 * slots) // (4 * total)))
+        assert h(total, slots, nblocks, keys=64 * nblocks) == min(want, 128, slots, nblocks), (total, slots, nblocks)
+    assert h(80, 256, 1174, keys=75088) == 4                      # the text-to-video call of the recipe: the reference's rule says 3
+
+
 def test_dense_mode_passes_no_lists(rec):
     """Appendix B-1: enable_skipping=False must work and hand None lists to the op."""
     att = L.LiteAttention(enable_skipping=False)

@@ -89,6 +89,39 @@ def blocks(tag):
                             f"{x['t_last_over_dense']} | {x['ideal_1_minus_s']} | {x.get('reference_t_over_t0_at_target')} | "
                             f"{x['total_ms_50_steps']} | {x['speedup_vs_dense_50_steps']}x | {chk} | {x['mean_abs_err_vs_dense']} / {x['max_abs_err_vs_dense']} |")
             out["denoise50"] = rows
+    if b:
+        hv = b.get("half_vote") or {}
+        if "at_fixed_thresholds" in hv:
+            rows = ["| thr (target of the 256-row vote) | 50 steps ms: 256-row / 128-row (half) vote | ratio | last-step sparsity 256 / 128 | mean abs error vs dense 256 / 128 | max abs error 128 |",
+                    "|---|---|---|---|---|---|"]
+            tile = {r["target"]: r for r in (b.get("denoise50") or {}).get("runs", [])}
+            for r in hv["denoise50"]["runs"]:
+                t, x = tile.get(r["target"], {}), hv["at_fixed_thresholds"].get(r["target"], {})
+                rows.append(f"| {r['thr']} ({r['target']}) | {t.get('total_ms_50_steps')} / {r['total_ms_50_steps']} | {x.get('total_ms_half_over_tile256')} | "
+                            f"{100 * t.get('sparsity_last_step', 0):.1f} % / {100 * r['sparsity_last_step']:.1f} % | {t.get('mean_abs_err_vs_dense')} / {r['mean_abs_err_vs_dense']} | "
+                            f"{r['max_abs_err_vs_dense']} |")
+            sw = {round(s["sparsity"], 2): s for s in b.get("sweep") or []}
+            rows += ["", "Imposed lists in the 128-row geometry (same box, same process) against the sweep of the 256-row vote: " +
+                     "; ".join(f"{100 * e['sparsity']:.0f} %: {e['ms']} ms ({e['executed_tflops']} TFLOP/s, {e['frac_of_mfma_peak']} of the peak) against "
+                               f"{(sw.get(round(e['sparsity'], 2)) or {}).get('kernel_ms')} ms" for e in hv.get("imposed_lists", [])) + "."]
+            out["half_vote"] = rows
+        sv = b.get("denoise50_survey") or {}
+        if "runs" in sv:
+            rows = ["| target | thr (log2, bisected over [-20, 0)) | last-step sparsity | last step ms | 50 steps ms | mean / max abs error vs dense output |", "|---|---|---|---|---|---|"]
+            rows += [f"| {r['target']} | {r['thr']} | {100 * r['sparsity_last_step']:.1f} % | {r['ms_last_step']} | {r['total_ms_50_steps']} | {r['mean_abs_err_vs_dense']} / {r['max_abs_err_vs_dense']} |"
+                     for r in sv["runs"]]
+            out["denoise50_survey"] = rows
+        jr = b.get("joint_recipe") or {}
+        if "v2v" in jr:
+            rows = ["| call | ms | TFLOP/s (GB/s for the merges) | of the MFMA (HBM) peak | launches timed |", "|---|---|---|---|---|"]
+            for n in ("t2t", "t2v", "v2t", "v2v"):
+                x = jr[n]
+                rows.append(f"| {n}" + (f" ({x['num_splits']} key splits)" if x.get("num_splits", 1) > 1 else "") + f" | {x['ms']} | {x['tflops']} | {x['frac_of_mfma_peak']} | {x['launches_timed']} |")
+            for n in ("merge_text", "merge_video"):
+                x = jr[n]
+                rows.append(f"| {n} | {x['ms']} | {x['gb_per_s']} GB/s | {x['frac_of_hbm_peak']} of HBM | {x['launches_timed']} |")
+            rows.append(f"| **everything but v2v** | **{jr['everything_but_v2v_ms']}** | | **{100 * jr['everything_but_v2v_over_v2v']:.1f} % of the v2v call** | |")
+            out["joint_recipe"] = rows
     for name, d in (("rocprof_bf16", rp), ("rocprof_fp8", rp8)):
         if not d:
             continue
