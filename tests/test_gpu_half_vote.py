@@ -212,8 +212,8 @@ def _suite(args, timeout=1500):
 @pytest.mark.parametrize("files", [["tests/test_gpu_parity.py", "tests/test_gpu_headline.py"],
                                    ["tests/test_gpu_fragmented.py", "tests/test_gpu_fp16.py", "tests/test_gpu_gqa_windows.py"],
                                    ["tests/test_gpu_varlen_lists.py", "tests/test_gpu_denoise_lists.py", "tests/test_gpu_round2.py"],
-                                   ["tests/test_gpu_head_dims.py", "tests/test_gpu_round4.py", "tests/test_gpu_reference_grid.py"]],
-                         ids=["parity+headline", "fragmented+fp16+gqa_windows", "varlen+denoise+round2"] + ["head_dims+round4+reference_grid"])
+                                   ["tests/test_gpu_head_dims.py", "tests/test_gpu_round4.py"]],
+                         ids=["parity+headline", "fragmented+fp16+gqa_windows", "varlen+denoise+round2"] + ["head_dims+round4"])
 def test_the_parity_suite_under_the_half_vote_geometry(files):
     r = _suite(files)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
