@@ -45,7 +45,8 @@ else:
     v0 = torch.randn(S, H, D, device=dev, generator=g)
     base = (q0[None], k0[None], v0[None])
     att.threshold = a.real
-    cache = f"/tmp/la_real_lists_{a.real}_{a.steps}.pt"      # the lists do not depend on the library variant (votes are bit-exact): reuse
+    cache = f"/tmp/la_real_lists_{a.real}_{a.steps}_{bm}.pt"      # (per list geometry: LA_VOTE=half has 128-row lists)
+    #      # the lists do not depend on the library variant (votes are bit-exact): reuse
     for t in range(a.steps):
         if os.path.exists(cache) and t < a.steps - 1:
             continue
