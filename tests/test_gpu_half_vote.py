@@ -215,6 +215,7 @@ def _suite(args, timeout=1500):
                                    ["tests/test_gpu_head_dims.py", "tests/test_gpu_round4.py"]],
                          ids=["parity+headline", "fragmented+fp16+gqa_windows", "varlen+denoise+round2"] + ["head_dims+round4"])
 def test_the_parity_suite_under_the_half_vote_geometry(files):
-    r = _suite(files)
+    # (e4m3 and head dims 192 / 256 have no half-vote form - the flag does nothing there and the default run covers them: left out)
+    r = _suite(files + ["-k", "not fp8 and not e4m3 and not 192 and not 256"])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
