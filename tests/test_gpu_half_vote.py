@@ -1,5 +1,5 @@
 """GPU: LA_FLAG_HALF_VOTE - the hand-scheduled head_dim-128 kernel with its skip lists kept per 128-ROW HALF of the 256-row workgroup
-(round 6; liteattention_amd/csrc/gen_fwd_x64.py LA_X64_FORM=half, la_fwd_kernel_x64.hip `half_expand_lists` / `half_place_walk`). The workgroup walks the
+(round 6; liteattention_amd/csrc/gen_fwd_x64.py LA_X64_FORM=half, la_fwd_kernel_x64.hip `half_build_walk_wave`). The workgroup walks the
 union of its two halves' lists and a wave sits out the tiles only the other half lists; every half must behave exactly like an independent
 128-row q-tile walking its own list, i.e. like the oracle at block_m = 128 (the reference's own q-granularity for bf16 head_dim 128,
 hopper/_internal/cpp/tile_size.h:35-39): outputs and LSE within the oracle tolerance, write lists bit-exact (1e-3 margin rule of
