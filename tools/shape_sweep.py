@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""Round 6: the shapes beside the headline ("the shapes nobody has looked at") - dense and list-walking launches over sequence lengths,
+batch sizes, head counts, GQA, cross-attention shapes; HIP events in steady state; useful TFLOP/s and fraction of the bf16 MFMA peak. Every
+result is also checked for finiteness (a crash or a NaN here is a finding). -> gpurun_out/shape_sweep.json, profiles/r06_shape_sweep.md"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import liteattention_amd as L                                     # noqa: E402
+from tools.selfcheck import banded_rows, executed_flops, impose_lists     # noqa: E402
+
+dev = torch.device("cuda", 0)
+PEAK = 2500.0
+
+
+def steady(fn, est_ms):
+    for _ in range(max(3, int(100.0 / max(est_ms, 0.02)))):
+        fn()
+    reps = max(5, min(400, int(200.0 / max(est_ms, 0.02))))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def run(B, Sq, Sk, H, Hk, D, sparsity=None, splits=1):
+    g = torch.Generator(device=dev).manual_seed(B + Sq + Sk + H)
+    q = torch.randn(B, Sq, H, D, device=dev, generator=g).bfloat16()
+    k = torch.randn(B, Sk, Hk, D, device=dev, generator=g).bfloat16()
+    v = torch.randn(B, Sk, Hk, D, device=dev, generator=g).bfloat16()
+    flops = 4.0 * B * H * Sq * Sk * D
+    if sparsity is None:
+        fn = lambda: L.flash_attn_func(q, k, v, num_splits=splits)            # noqa: E731
+    else:
+        bm, bn = L.get_tile_sizes(D, 2)
+        att = L.LiteAttention(threshold=-10.0, max_batch_size=B)
+        att.threshold = float("-inf")
+        att._get_read_write_lists(q, k)
+        att._phase = 0
+        rows = banded_rows(-(-Sq // bm), -(-Sk // bn), bm, bn, sparsity)
+        impose_lists(att, rows)
+        flops = executed_flops(rows, H, B, Sq, Sk, bm, bn, D)
+        fn = lambda: att(q, k, v)                                               # noqa: E731
+    out = fn()
+    ok = bool(torch.isfinite(out.float()).all().item())
+    ms = steady(fn, flops / 1.0e12 * 1e3)
+    return {"B": B, "Sq": Sq, "Sk": Sk, "H": H, "Hk": Hk, "D": D, "sparsity": sparsity, "num_splits": splits, "ms": round(ms, 4),
+            "tflops": round(flops / ms / 1e9, 1), "frac": round(flops / ms / 1e9 / PEAK, 4), "finite": ok}
+
+
+cases = []
+for S in (1024, 2048, 4096, 8192, 16384, 32768):
+    cases.append((1, S, S, 40, 40, 128, None, 1))
+    cases.append((1, S, S, 40, 40, 128, None, -1))
+    cases.append((1, S, S, 40, 40, 128, 0.42, 1))
+for B, S in ((2, 16384), (8, 4096), (16, 1024)):
+    cases.append((B, S, S, 40, 40, 128, None, 1))
+    cases.append((B, S, S, 40, 40, 128, 0.42, 1))
+cases += [(1, 16384, 16384, 8, 8, 128, None, 1), (1, 16384, 16384, 8, 8, 128, None, -1), (1, 16384, 16384, 40, 8, 128, None, 1), (1, 16384, 16384, 40, 1, 128, 0.42, 1),
+          (1, 75600, 512, 40, 40, 128, None, 1), (1, 512, 75600, 40, 40, 128, None, 1), (1, 512, 75600, 40, 40, 128, None, -1), (2, 4096, 77, 24, 24, 128, None, 1),
+          (1, 4096, 4096, 24, 24, 64, None, 1), (1, 4096, 4096, 24, 24, 64, 0.42, 1), (1, 4096, 4096, 16, 16, 256, None, 1), (1, 4096, 4096, 16, 16, 256, None, -1)]
+res = []
+for c in cases:
+    try:
+        r = run(*c)
+    except Exception as e:  # noqa: BLE001
+        r = {"case": list(c), "error": repr(e)}
+    res.append(r)
+    print(json.dumps(r), flush=True)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "shape_sweep.json"), "w"), indent=1)
