@@ -66,7 +66,9 @@ for case in range(n_cases):
             for step in range(3):
                 q, k, v = [x.cuda() for x in make(dtype, B, S, H, D, seed, step, gen)]
                 o1, l1 = a1(q, k, v, return_softmax_lse=True)
-                cuts = sorted(set([0, Qt] + [rng.randrange(0, Qt + 1) for _ in range(rng.randrange(0, 4))]))
+                from liteattention_amd.flash_attn_interface import q_tiles_per_item
+                u = q_tiles_per_item(D, es)              # LA_VOTE=half: a workgroup item is two q-tiles; windows hold whole items
+                cuts = sorted(set([0, Qt] + [rng.randrange(0, Qt + 1) // u * u for _ in range(rng.randrange(0, 4))]))
                 wins = [(cuts[i], cuts[i + 1] - cuts[i]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
                 o2, l2 = a2.call_windowed(q, k, v, wins, return_softmax_lse=True)
                 if not (torch.equal(o1, o2) and torch.equal(l1, l2) and same_rows(a2.current_read_list(), a1.current_read_list())):
