@@ -56,7 +56,8 @@ DenseSplit dense_split(int k_tiles, int head_dim, int64_t batch, int64_t seqlen_
     d.n = (k_tiles + per - 1) / per;
     d.chunk_tiles = (k_tiles + d.n - 1) / d.n;
     d.o_bytes = ((static_cast<uint64_t>(batch) * seqlen_q * num_heads * head_dim_v * 2) + 15) & ~15ull;
-    d.lse_bytes = ((static_cast<uint64_t>(batch) * num_heads * seqlen_q * 4) + 15) & ~15ull;
+    d.lse_bytes = static_cast<uint64_t>(batch) * num_heads * seqlen_q * 4;      // (exact: the merge reads run s at s * (elements of one partial); the O partials - always a
+                                                                                // multiple of 16 bytes, head_dim_v % 8 == 0 - come first, so every O partial is 16-byte aligned)
     return d;
 }
 // e4m3 above head_dim 128: the bf16 form of the same arguments over up-converted operands in the workspace (la_prep_fp8.hip)
@@ -364,9 +365,6 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
             err = la::launch_fwd_x64(ps, a->head_dim, false, f16, stream);
             if (err != hipSuccess) { g_last_hip_error = static_cast<int>(err); return LA_ERR_LAUNCH; }
         }
-        // the partial buffers are 16-byte padded per run: la_combine's kernel reads run s at s * (elements of one partial), so the padding must be 0
-        if (d.o_bytes != static_cast<uint64_t>(p.batch) * p.seqlen_q * p.num_heads * a->head_dim_v * 2 ||
-            d.lse_bytes != static_cast<uint64_t>(p.batch) * p.num_heads * p.seqlen_q * 4) return LA_ERR_SEQLEN;      // (head_dim_v % 8 == 0: only an odd batch * heads * rows of LSE could pad)
         err = la::launch_combine(o_part, true, f16, lse_part, p.o, a->lse, d.n, p.batch, p.seqlen_q, p.num_heads, a->head_dim_v, stream, false,
                                  p.o_batch_stride, p.o_row_stride, p.o_head_stride);
     } else if (x64) {

@@ -472,6 +472,8 @@ def _mha_fwd_split_kv(q, k, v, n, out, softmax_scale, descales):
     key = (B, n, Sq, Sk, chunk, str(q.device))
     cu = _SPLIT_CU.get(key)
     if cu is None:
+        while len(_SPLIT_CU) >= 16:                              # a handful of shapes per process; never grow without bound
+            _SPLIT_CU.pop(next(iter(_SPLIT_CU)))
         cu_q = torch.arange(0, B * n + 1, dtype=torch.int32) * Sq
         cu_k = torch.tensor([b * Sk + min(s * chunk, Sk) for b in range(B) for s in range(n)] + [B * Sk], dtype=torch.int32)
         cu = _SPLIT_CU[key] = (cu_q.to(q.device), cu_k.to(q.device))

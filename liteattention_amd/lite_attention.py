@@ -176,18 +176,18 @@ class LiteAttention:
         must_do = None
         if read_list is not None:
             must_do = self._must_do_device_row(must_do_list, query, read_list.shape[3])
-        descales = {}
+        extra = {}
         if q_descale is not None or k_descale is not None or v_descale is not None:      # only when given: the host-logic
-            descales = dict(q_descale=q_descale, k_descale=k_descale, v_descale=v_descale)   # tests record the exact call
+            extra = dict(q_descale=q_descale, k_descale=k_descale, v_descale=v_descale)     # tests record the exact call
         if read_list is None:
             # dense calls (enable_skip_optimization(False): the t2t / t2v / v2t calls of the text + video recipe, README.md:225-246) may be
             # split over the keys when they have fewer items than the device has workgroup slots: num_splits = -1 lets the op decide by
             # the reference's heuristic (flash_api.cpp:437, heuristics.h:25-58; the reference class passes nothing, i.e. 1: its default
             # build has no split kernel, hopper/setup.py:48)
-            descales["num_splits"] = -1
+            extra["num_splits"] = -1
         output = flash_attn_func(q=query, k=key, v=value, softmax_scale=scale, attn_read_list=read_list,
                                  attn_must_do_list=must_do, attn_write_list=write_list, thr=self.threshold,
-                                 return_softmax_lse=return_softmax_lse, **descales)
+                                 return_softmax_lse=return_softmax_lse, **extra)
         if read_list is not None and _verbose():
             self._last_percentage = self.calc_percentage(read_list[: query.shape[0]])
             print(f"[Info]: Percentage of tiles skipped: {1.0 - self._last_percentage:.2%}")

@@ -178,6 +178,7 @@ def test_longest_key_sequence(D):
     # beyond one launch's walk (round 6): a DENSE call is cut into runs of tiles inside la_fwd and merged by LSE; a call with skip lists
     # keeps the bound and its typed error
     Sk2 = 2048 * 64 - 5                                     # S = 131 072: two runs
+    q = torch.randn(1, 131, 1, D, device="cuda", generator=g).bfloat16()       # an odd row count: the partial LSE buffers of the runs are not 16-byte multiples
     k2 = torch.randn(1, Sk2, 1, D, device="cuda", generator=g).bfloat16()
     v2 = torch.randn(1, Sk2, 1, D, device="cuda", generator=g).bfloat16()
     out2, lse2 = L.flash_attn_func(q, k2, v2, return_softmax_lse=True)
@@ -186,7 +187,7 @@ def test_longest_key_sequence(D):
     assert (out2.float()[0, :, 0] - ref2).abs().max().item() <= 2.0 ** -7 * ref2.abs().max().item() + 1e-3      # two bf16 roundings: partials, merge
     assert (lse2[0, 0] - torch.logsumexp(sc, -1)).abs().max().item() <= 1e-3
     bm, bn = L.get_tile_sizes(D, 2)
-    lists = torch.zeros(2, 1, 1, 1, -(-Sk2 // bn) + 1, dtype=torch.int32, device="cuda")
+    lists = torch.zeros(2, 1, 1, -(-131 // bm), -(-Sk2 // bn) + 1, dtype=torch.int32, device="cuda")
     with pytest.raises(RuntimeError, match=_cabi.status_string(_cabi.LA_ERR_SEQLEN)[:20]):
         L.flash_attn_func(q, k2, v2, attn_read_list=lists[0], attn_write_list=lists[1])
 
