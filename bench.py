@@ -315,6 +315,39 @@ def other_head_dims(L, dev, dims=(64, 96, 192, 256), S=16384, H=40):
     return out
 
 
+def fp8_head_dim_64(L, dev, S=16384, H=40, D=64):
+    """e4m3 at head_dim 64 on its native body (round 6; until then zero-padded onto the head_dim-128 body), dense at the shape of
+    `other_head_dims`, in the reference's arithmetic (the default) and in the two opt-in forms of P; sampled-row check of each timed output
+    (fp8 bounds of the headline fp8 record)."""
+    import torch
+    from tools.selfcheck import sampled_row_check
+    g = torch.Generator(device=dev).manual_seed(4)
+    q, k, v = [torch.randn(1, S, H, D, device=dev, generator=g).bfloat16().to(torch.float8_e4m3fn) for _ in range(3)]
+    bm, bn = L.get_tile_sizes(D, 1)
+    out = {"what": f"dense e4m3 B=1 S={S} H={H} D={D} (V^T prepare pass included); ~150 ms of warm-up launches, then >= 300 ms of timed launches, median",
+           "tiles": [bm, bn], "forms": {}}
+    for key, env in (("reference_arithmetic", None), ("mfma_rowsum", "mfma_rowsum"), ("encoded_p", "encoded")):
+        os.environ.pop("LA_FP8_P", None)
+        if env:
+            os.environ["LA_FP8_P"] = env
+        try:
+            res = []
+
+            def launch():
+                res[:] = L.flash_attn_func(q, k, v, return_softmax_lse=True)
+            launch()
+            ms, reps = steady_state_ms(launch, est_ms=4.0 * H * S * S * D / 1.2e12)
+            o, lse = res
+            ver = sampled_row_check(q, k, v, o, lse, None, bm, bn, heads=(0, H - 1), n_rows=64, o_rtol=0.05, o_atol=1e-3,
+                                    lse_atol=2e-4 if env is None else 2.5e-3)
+            tf = 4.0 * H * S * S * D / (ms * 1e-3) / 1e12
+            out["forms"][key] = {"ms": round(ms, 3), "launches_timed": reps, "tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / MFMA_FP8_PEAK_TFLOPS, 4),
+                                 "verified": {"rows": ver["rows"], "max_err": ver["max_err"], "max_err_lse": ver["max_err_lse"], "ok": ver["ok"]}}
+        finally:
+            os.environ.pop("LA_FP8_P", None)
+    return out
+
+
 def config1_dense(L, dev, S=32768, H=40, D=128):
     """BASELINE.json configs[1]: 1 x MI355X, bf16, seq_len 32768, 40 heads, head_dim 128, 0 % sparsity (dense, FlashAttention-
     equivalent), against the MFMA roofline. Kernel time by HIP events on the launch stream (steady state: `steady_state_ms`);
@@ -806,6 +839,8 @@ def main():
                 finally:
                     os.environ.pop("LA_FP8_P", None)
             result["fp8"]["reference_arithmetic"] = "value (the default form)"
+            if not args.no_head_dims:
+                result["fp8"]["head_dim_64"] = fp8_head_dim_64(L, dev)
         except Exception as e:  # noqa: BLE001
             result["fp8"] = {"value": None, "error": repr(e)}
 
@@ -866,6 +901,8 @@ def main():
             for key in ("mfma_rowsum", "encoded_p"):
                 if key in result["fp8"]:
                     rf[f"fp8_{key}_frac"] = result["fp8"][key]["frac"]
+            if "forms" in result["fp8"].get("head_dim_64", {}):
+                rf["fp8_head_dim_64_frac"] = {k: f["frac_of_mfma_peak"] for k, f in result["fp8"]["head_dim_64"]["forms"].items()}
         if "runs" in result.get("other_head_dims", {}):
             rf["other_head_dims"] = {str(r["head_dim"]): r["frac_of_mfma_peak"] for r in result["other_head_dims"]["runs"]}
         if "frac_of_mfma_peak" in result.get("config1_dense_s32768", {}):

@@ -55,12 +55,24 @@ def option_tag():
 
 
 
-XPAIRS = int(opt_val("x", "8" if ("exp" not in OPT and "lvalu" not in OPT) else "4"))          # pair-groups (of 16) done in phase 2. EVEN: two pair-groups share one packed-e4m3 destination register
+XPAIRS = int(opt_val("x", {128: {"lin": "8", "exp": "4", "lvalu": "4"}, 64: {"lin": "12", "exp": "2", "lvalu": "6"}}[int(os.environ.get("LA_X64F8_D", "128"))]
+                        ["lvalu" if "lvalu" in OPT else "exp" if "exp" in OPT else "lin"]))          # pair-groups (of 16) done in phase 2. EVEN: two pair-groups share one packed-e4m3 destination register
                                           # (lo / hi half by op_sel); an odd split leaves a half-written register across the phase boundary
-                                          # (measured x = 2 / 4: 2078-2101 TFLOP/s at 42 %, x = 3 / 5 / 6: 2048-2065)
+                                          # (measured x = 2 / 4: 2078-2101 TFLOP/s at 42 %, x = 3 / 5 / 6: 2048-2065). head_dim 64 (phase 1 has 4 MFMAs, not 8;
+                                          # tools/debug/fp8_d64_ab.py, dense S = 16 384: lvalu x = 2 / 4 / 6 / 8: 2.40 / 2.41 / 2.30 / 2.40 ms; exp 2 / 4 / 6 / 8: 2.11 / 2.18 /
+                                          # 2.13 / 2.19; lin 4 / 8 / 10 / 12 / 14: 1.66 / 1.60 / 1.65 / 1.585 / 1.68 against 1.67 of that session's x = 8)
+# Head dim (round 6): 128, or 64 = the same step with ONE 64-wide contraction per score block and two 32-wide d-blocks of O^T: 4 QK + 4 PV
+# MFMAs per step instead of 8 + 8 under the same softmax. K tile = 64 keys x 64 bytes, held in LDS as 32 pseudo-rows of 128 bytes (key R in
+# chunks 0-3, key R + 32 in chunks 4-7) so that the fragment addresses and the swizzle are those of head_dim 128 with `sx` read as the key
+# block; prepared V^T tile = its first 64 rows. One LDS-DMA piece of 1 KiB per wave, tensor and step instead of two.
+D = int(os.environ.get("LA_X64F8_D", "128"))
+assert D in (64, 128), D
+NSX, ND = D // 64, D // 32                # 64-wide contraction steps of S^T = K Q^T; 32-wide d-blocks of O^T
+DB = ND                                   # gen_epilogue.py: d-blocks to store
+PIECES = D // 64                          # 1 KiB LDS-DMA pieces per wave and tile
 PK = "pk" in OPT                          # A/B: packed fp32 FMA / add in the softmax (v_pk_fma_f32, v_pk_add_f32). MEASURED ANTI-LEVER here too:
                                           # 64 fewer instructions per step, bit-identical results, 1891 vs 2068 TFLOP/s at 42 % (round 2, tools/ab.py --fp8)
-NG = 8                                    # QK MFMAs (gaps) of phase 1
+NG = 4 * NSX                              # QK MFMAs (gaps) of phase 1
 # Row sums. "lvalu" (round 2): l = sum of the UN-rounded fp32 P, 64 v_add_f32 per step (the reference's form, softmax.h:275-296).
 # Default (round 3): l~ = sum of the e4m3-ROUNDED P, taken from the matrix pipe: one more 32 x 32 x 64 MFMA per q-block and step
 # with an all-ones A operand (every row of the result is the column sum of P^T), accumulated in a[192:223] and rescaled with O.
@@ -83,7 +95,7 @@ LMFMA = "lvalu" not in OPT
 # hardware rounding keeps P down to 2^-10. Needs the row sums of the ENCODED P (LMFMA): no fp32 P exists in this form.
 LIN = LMFMA and "exp" not in OPT
 LIN_DELTA = 0.0575
-NG2 = 10 if LMFMA else 8                  # MFMAs (gaps) of phase 2: PV + the two row-sum MFMAs
+NG2 = 2 * ND + (2 if LMFMA else 0)        # MFMAs (gaps) of phase 2: PV + the two row-sum MFMAs
 # Lazy-rescale slack TAU (log2 units) and the offset of P. P <= 2^(P_OFFSET + TAU) must stay finite in e4m3 (max 448 = 2^8.8):
 # exp / lvalu: the reference's 2^8 ceiling (Max_offset = 8, softmax.h:85-87), TAU = 2. lin: ceiling 2^8.75 (byte 126; byte 127 is NaN)
 # and TAU = 1 - the byte grid ends at byte 1 = 2^-9 <-> y = -6.94, so a key is kept while its weight is above 2^-(P_OFFSET + 6.94)
@@ -103,7 +115,7 @@ MX = LIN and "nomx" not in OPT
 TAU = float(opt_val("tau", "32" if MX else ("1" if LIN else "2")))
 P_CEIL = 8.75 if LIN else 8.0
 P_OFFSET = 7.0 if MX else P_CEIL - TAU
-DMA_GAPS = [int(x) for x in opt_val("dmagaps", "0,1,1,2,3,3").replace(".", ",").split(",")]   # m0K,K0,K1,m0V,V0,V1 (phase 1 gaps; an M0 write is never adjacent to its first use)
+DMA_GAPS = [int(x) for x in opt_val("dmagaps", "0,1,1,2,3,3" if D == 128 else "0,1,2,3").replace(".", ",").split(",")]   # m0K,K0,K1,m0V,V0,V1 (phase 1 gaps; an M0 write is never adjacent to its first use)
 
 
 # ---------------------------------------------------------------- AGPR map
@@ -115,7 +127,7 @@ def QA(qb, sx):
     return 128 + 16 * qb + 8 * sx
 
 
-def KA(j):          # j = 2*kb + sx
+def KA(j):          # j = 2*kb + sx (head_dim 64: j = kb)
     return 160 + 8 * j
 
 
@@ -220,6 +232,8 @@ def finalize(items):
 
 # ---------------------------------------------------------------- building blocks
 def k_read(kbuf_imm, j, t):
+    if D == 64:     # pseudo-rows of 128 bytes: the key block selects the chunk group, as sx does at 128
+        return ("LDS", f"ds_read_b128 {ar(KA(j) + 4 * t, 4)}, {v(KADDR[2 * j + t])} offset:{kbuf_imm}", ("k", j, t))
     kb, sx = j >> 1, j & 1
     return ("LDS", f"ds_read_b128 {ar(KA(j) + 4 * t, 4)}, {v(KADDR[2 * sx + t])} offset:{kbuf_imm + kb * 4096}", ("k", j, t))
 
@@ -235,7 +249,7 @@ SCALES = f"{v(VSC)}, {v(VSC)} op_sel_hi:[0,0,0]"
 def mfma_qk(sset, kb, sx, qb):
     d = S_(sset, qb, kb)
     c = "0" if sx == 0 else vr(d, 16)
-    return f"    {MFMA} {vr(d, 16)}, {ar(KA(2 * kb + sx), 8)}, {ar(QA(qb, sx), 8)}, {c}, {SCALES}"
+    return f"    {MFMA} {vr(d, 16)}, {ar(KA(NSX * kb + sx), 8)}, {ar(QA(qb, sx), 8)}, {c}, {SCALES}"
 
 
 def mfma_pv(sset, db, qb):
@@ -462,7 +476,7 @@ def rescale_o_block(lbl, back):
     emit("s_nop 15")
     emit("s_nop 15")
     for qb in (0, 1):
-        for base in range(0, 64, 8):
+        for base in range(0, 16 * ND, 8):
             for k in range(8):
                 emit(f"v_accvgpr_read_b32 {v(T[k])}, a{64 * qb + base + k}")
             for k in range(8):
@@ -489,10 +503,10 @@ def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True, st=0):
     o = []
     if do_k:
         o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {kbuf_imm}")
-        o += [f"    global_load_lds_dwordx4 {v(LK[j])}, {sr(TBS[st])} offset:{1024 * j}" for j in range(2)]
+        o += [f"    global_load_lds_dwordx4 {v(LK[j])}, {sr(TBS[st])} offset:{1024 * j}" for j in range(PIECES)]
     if do_v:
         o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {V_REGION + vbuf_imm}")
-        o += [f"    global_load_lds_dwordx4 {v(LV)}, {sr(VBS[st])} offset:{1024 * j}" for j in range(2)]
+        o += [f"    global_load_lds_dwordx4 {v(LV)}, {sr(VBS[st])} offset:{1024 * j}" for j in range(PIECES)]
     return o
 
 
@@ -524,9 +538,9 @@ def distribute(queue, post, start, cap=0):
 
 
 deferred = []
-QK_ORDER = [(sx, kb, qb) for sx in (0, 1) for kb in (0, 1) for qb in (0, 1)]      # dependent pairs are 4 MFMAs apart
-PV_ORDER = [(db, qb) for db in range(4) for qb in (0, 1)] + ([(4, 0), (4, 1)] if LMFMA else [])   # db 4 = the row-sum MFMA
-K_FRAGS = [(j, t) for j in (0, 2, 1, 3) for t in (0, 1)]                            # sx = 0 fragments first
+QK_ORDER = [(sx, kb, qb) for sx in range(NSX) for kb in (0, 1) for qb in (0, 1)]      # dependent pairs are 4 MFMAs apart
+PV_ORDER = [(db, qb) for db in range(ND) for qb in (0, 1)] + ([(4, 0), (4, 1)] if LMFMA else [])   # db 4 = the row-sum MFMA
+K_FRAGS = [(j, t) for j in ((0, 2, 1, 3) if D == 128 else (0, 1)) for t in (0, 1)]  # sx = 0 fragments first
 
 
 def step(variant):
@@ -541,8 +555,8 @@ def step(variant):
     mf = [mfma_qk(nxt, kb, sx, qb) for (sx, kb, qb) in QK_ORDER]
     for g, op in zip(DMA_GAPS, dma_ops(kbuf_stage, vbuf_stage, st=variant)):
         post[g].append(op)
-    for f, (db, t) in enumerate([(db, t) for db in range(4) for t in (0, 1)]):
-        post[4 + f // 2].append(v_read(vbuf_cur, db, t))
+    for f, (db, t) in enumerate([(db, t) for db in range(ND) for t in (0, 1)]):
+        post[NG // 2 + f // 2].append(v_read(vbuf_cur, db, t))
     distribute(softmax_stream(cur, list(range(XPAIRS, 16))), post, int(opt_val("smstart", "0")))
     for t in range(NG):
         out.append(mf[t])
@@ -559,7 +573,7 @@ def step(variant):
         mf.append(mfma_pv(cur, db, qb))
         if "klate" in OPT:
             post[t].append(k_read(kbuf_read, *K_FRAGS[t]))
-        elif t < 4:                              # K(i+2) fragments in the first half: nothing young is left for the drain
+        elif t < len(K_FRAGS) // 2:              # K(i+2) fragments in the first half: nothing young is left for the drain
             post[t] += [k_read(kbuf_read, *K_FRAGS[2 * t]), k_read(kbuf_read, *K_FRAGS[2 * t + 1])]
     rare, back = new_label("rare"), new_label("rare_back")
     fl, flback = new_label("flush"), new_label("flush_back")
@@ -631,7 +645,7 @@ def prologue():
         emit(f"v_readfirstlane_b32 {s(S_NEGC8)}, {v(T[1])}")
         emit(f"s_mov_b32 {s(S_M8)}, 0x{float_bits(-8.0):08x}")
     emit(f"s_sub_u32 {s(S_NM1)}, {s(S_NTILES)}, 1")
-    emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, 11")          # 2 KiB of every 8 KiB tile per wave
+    emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, {10 + NSX - 1}")          # 2 KiB of every 8 KiB tile per wave (head_dim 64: 1 KiB of 4)
     emit(f"s_add_u32 {s(S_DMAW)}, {s(S_DMAW)}, {s(S_LDS)}")
     emit(f"s_mov_b32 {s(S_I)}, 0")
     emit(f"s_mov_b32 {s(S_RESC)}, 0")
@@ -667,8 +681,22 @@ def prologue():
     # DMA lane offsets. K piece j of this wave: rows 16 w + 8 j + rip (rip = lane >> 3), source chunk cpos ^ ((row >> 1) & 7)
     emit(f"v_lshrrev_b32 {v(T[6])}, 3, {v(LANE)}")            # rip
     emit(f"v_and_b32 {v(T[7])}, 7, {v(LANE)}")                # cpos
+    if D == 64:
+        # one piece per wave: pseudo-row R = 8 w + rip, LDS chunk cpos holds source chunk cs = cpos ^ ((R >> 1) & 7) = chunk cs & 3 of key R + 32 (cs >> 2)
+        emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 3")
+        emit(f"v_add_u32 {v(T[4])}, {s(S_T0)}, {v(T[6])}")
+        emit(f"v_lshrrev_b32 {v(T[5])}, 1, {v(T[4])}")
+        emit(f"v_and_b32 {v(T[5])}, 7, {v(T[5])}")
+        emit(f"v_xor_b32 {v(T[5])}, {v(T[5])}, {v(T[7])}")
+        emit(f"v_lshrrev_b32 {v(T[8])}, 2, {v(T[5])}")
+        emit(f"v_lshl_add_u32 {v(T[4])}, {v(T[8])}, 5, {v(T[4])}")
+        emit(f"v_and_b32 {v(T[5])}, 3, {v(T[5])}")
+        emit(f"v_min_i32 {v(T[4])}, {v(T[4])}, {s(S_LASTROW)}")   # seqlen_k < 64: rows of the only tile stay inside K
+        emit(f"v_mul_lo_u32 {v(LK[0])}, {v(T[4])}, {s(S_KRS)}")
+        emit(f"v_lshl_add_u32 {v(LK[0])}, {v(T[5])}, 4, {v(LK[0])}")
+        emit(f"v_add_u32 {v(LK[0])}, 1024, {v(LK[0])}")            # S_KBASE carries -1024 (as at head_dim 128)
     emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 4")
-    for j in (0, 1):
+    for j in ((0, 1) if D == 128 else ()):
         emit(f"v_add_u32 {v(T[4])}, {s(S_T0)}, {v(T[6])}")
         if j:
             emit(f"v_add_u32 {v(T[4])}, 8, {v(T[4])}")
@@ -680,8 +708,8 @@ def prologue():
         emit(f"v_lshl_add_u32 {v(LK[j])}, {v(T[5])}, 4, {v(LK[j])}")
         if not j:
             emit(f"v_add_u32 {v(LK[j])}, 1024, {v(LK[j])}")            # +1024 - 1024 j; S_KBASE carries -1024
-    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 11")
-    emit(f"v_lshl_add_u32 {v(LV)}, {v(LANE)}, 4, {s(S_T0)}")  # 2048 w + 16 lane: linear copy of the prepared tile
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, {10 + NSX - 1}")
+    emit(f"v_lshl_add_u32 {v(LV)}, {v(LANE)}, 4, {s(S_T0)}")  # 2048 w + 16 lane (head_dim 64: 1024 w): linear copy of the prepared tile
 
     emit("; ---- Q fragments -> AGPRs: row q_row0 + 64 w + 32 qb + l31, d = 64 sx + 32 t + 16 hh + [0,16); rows past seqlen_q are ZERO")
     emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 6")
@@ -699,16 +727,17 @@ def prologue():
         emit(f"v_add_co_u32 {v(T[4])}, vcc, {s(S_QBASE)}, {v(T[4])}")
         emit(f"v_mov_b32 {v(T[7])}, {s(S_QBASE + 1)}")
         emit(f"v_addc_co_u32 {v(T[5])}, vcc, {v(T[5])}, {v(T[7])}, vcc")
-        for sx in (0, 1):
+        for sx in range(NSX):
             for t in (0, 1):
                 emit(f"global_load_dwordx4 {vr(16 * qb + 8 * sx + 4 * t, 4)}, {vr(T[4], 2)}, off offset:{64 * sx + 32 * t}")
     emit("s_waitcnt vmcnt(0)")
     for qb in (0, 1):
         emit(f"v_cmp_gt_i32 vcc, {s(S_SEQLENQ)}, {v(QROW[qb])}")
-        for r in range(16):
+        for r in range(8 * NSX):
             emit(f"v_cndmask_b32 {v(16 * qb + r)}, 0, {v(16 * qb + r)}, vcc")
-    for r in range(32):
-        emit(f"v_accvgpr_write_b32 a{128 + r}, {v(r)}")
+    for qb in (0, 1):
+        for r in range(8 * NSX):
+            emit(f"v_accvgpr_write_b32 a{128 + 16 * qb + r}, {v(16 * qb + r)}")
     emit("; ---- state")
     for r in list(range(128)) + (list(range(LSUM(0), LSUM(1) + 16)) if LMFMA else []):
         emit(f"v_accvgpr_write_b32 a{r}, 0")
@@ -832,13 +861,16 @@ def main():
     mode = 2 if not LMFMA else (0 if LIN else 1)               # PMODE of the shell (la_fwd_kernel_x64_fp8.hip)
     # the three bodies of the build are told apart by their FILE NAME in the shell's includes: a body generated under options that belong to
     # another name (e.g. a global LA_X64F8_OPT in the environment of a default build) must fail here, not at link time
-    by_name = 1 if path.endswith("_exp_body.inc") else (2 if path.endswith("_lvalu_body.inc") else (0 if path.endswith("la_fwd_x64_fp8_body.inc") else mode))
+    by_name = 1 if path.endswith("_exp_body.inc") else (2 if path.endswith("_lvalu_body.inc") else (0 if path.endswith(("la_fwd_x64_fp8_body.inc", "la_fwd_x64_fp8_d64_body.inc")) else mode))
+    if ("_d64_" in os.path.basename(path)) != (D == 64):
+        raise SystemExit(f"{path}: generated for head_dim {D} (LA_X64F8_D) but named like the other head dim's body")
     if by_name != mode:
         raise SystemExit(f"{path}: generated with the options of P mode {mode} (LA_X64F8_OPT={os.environ.get('LA_X64F8_OPT', '')!r}) "
                          f"but named like the body of P mode {by_name}")
-    with open(path.replace("_body.inc", "_consts.h"), "w") as f:
-        f.write("// GENERATED by gen_fwd_x64_fp8.py together with the body of the same name — do not edit.\n")
-        f.write(f"#define LA_X64F8_TAU_{mode} {TAU!r}f\n#define LA_X64F8_OFFSET_{mode} {P_OFFSET!r}f\n")
+    if D == 128:     # (TAU and the offset of P depend on the form of P, not on the head dim: one header per form)
+        with open(path.replace("_body.inc", "_consts.h"), "w") as f:
+            f.write("// GENERATED by gen_fwd_x64_fp8.py together with the body of the same name — do not edit.\n")
+            f.write(f"#define LA_X64F8_TAU_{mode} {TAU!r}f\n#define LA_X64F8_OFFSET_{mode} {P_OFFSET!r}f\n")
     with open(path, "w") as f:
         f.write("// GENERATED by gen_fwd_x64_fp8.py — do not edit. Inline-asm body of la_fwd_x64_fp8_kernel.\n")
         f.write(option_tag() + "\n")

@@ -114,7 +114,7 @@ const char* la_status_string(int status) {
         case LA_ERR_NULL_ARG: return "required pointer is NULL";
         case LA_ERR_STRUCT_SIZE: return "la_fwd_args.struct_size mismatch (ABI version skew)";
         case LA_ERR_DTYPE: return "FlashAttention only supports fp16, bf16, and fp8_e4m3 type; this build instantiates all three";
-        case LA_ERR_HEAD_DIM: return "head_size not instantiated in this build (bf16 / fp16: 64, 96, 128, 192, 256 - under LA_FLAG_KERNEL_128ROW only 64, 128, 256; fp8: 128 natively, 192 / 256 on the bf16 kernels)";
+        case LA_ERR_HEAD_DIM: return "head_size not instantiated in this build (bf16 / fp16: 64, 96, 128, 192, 256 - under LA_FLAG_KERNEL_128ROW only 64, 128, 256; fp8: 64 and 128 natively, 192 / 256 on the bf16 kernels)";
         case LA_ERR_SHAPE: return "invalid shape (batch, seqlen_q, heads and head_dim must be positive; number of heads in key/value must divide number of heads in query)";
         case LA_ERR_STRIDE: return "Input tensor must have contiguous last dimension and 16-byte aligned rows";
         case LA_ERR_TILE_MISMATCH: return "block_m/block_n do not match la_get_tile_sizes(): skip lists would be mis-indexed";
@@ -176,7 +176,7 @@ int64_t la_fwd_workspace_bytes(const la_fwd_args* a) {
     if (trc != LA_OK) return trc;
     if (a->batch <= 0 || a->num_heads <= 0 || a->num_heads_k <= 0 || a->seqlen_k < 0) return LA_ERR_SHAPE;
     // V^T tiles, then the ticket counter of the dynamic work distribution
-    return static_cast<int64_t>(la::fp8_workspace_bytes(a->batch, a->num_heads_k, (a->seqlen_k + bn - 1) / bn) + kSchedWorkspaceBytes);
+    return static_cast<int64_t>(la::fp8_workspace_bytes(a->batch, a->num_heads_k, (a->seqlen_k + bn - 1) / bn, a->head_dim) + kSchedWorkspaceBytes);
 }
 
 int la_fwd(const la_fwd_args* a, void* stream_) {
@@ -263,7 +263,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
 
     la::FwdParams p{};
     if (fp8) {
-        const size_t tiles = la::fp8_workspace_bytes(a->batch, a->num_heads_k, (a->seqlen_k + bn - 1) / bn);
+        const size_t tiles = la::fp8_workspace_bytes(a->batch, a->num_heads_k, (a->seqlen_k + bn - 1) / bn, a->head_dim);
         if (a->workspace == nullptr || a->workspace_bytes < tiles + kSchedWorkspaceBytes || !aligned16(a->workspace))
             return LA_ERR_WORKSPACE;
         if (!(a->flags & LA_FLAG_STATIC_SCHED))        // lists or dense: persistent workgroups + ticket queues
@@ -324,11 +324,11 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
         hipError_t e8 = hipSuccess;
         if (!(a->flags & LA_FLAG_V_PREPARED))
             e8 = la::launch_prep_v_fp8(a->v, a->v_batch_stride, a->v_row_stride, a->v_head_stride, a->workspace,
-                                       a->batch, a->seqlen_k, a->num_heads_k, p.k_tiles, stream, a->cu_seqlens_k);
+                                       a->batch, a->seqlen_k, a->num_heads_k, p.k_tiles, a->head_dim, stream, a->cu_seqlens_k);
         if (e8 == hipSuccess) {
             p.v = static_cast<const uint16_t*>(a->workspace);
             e8 = la::launch_fwd_x64_fp8(p, a->read_list != nullptr,
-                                             (a->flags & LA_FLAG_FP8_ENCODED_P) ? 0 : (a->flags & LA_FLAG_FP8_MFMA_ROWSUM) ? 1 : 2, stream);   // default: the reference's arithmetic
+                                             (a->flags & LA_FLAG_FP8_ENCODED_P) ? 0 : (a->flags & LA_FLAG_FP8_MFMA_ROWSUM) ? 1 : 2, a->head_dim, stream);   // default: the reference's arithmetic
         }
         if (e8 != hipSuccess) { g_last_hip_error = static_cast<int>(e8); return LA_ERR_LAUNCH; }
         return LA_OK;

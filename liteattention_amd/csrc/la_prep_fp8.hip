@@ -2,7 +2,7 @@
 //
 // BASELINE.json configs[4]. The reference transposes V in shared memory inside its kernel for the PV operand
 // (hopper/_internal/cpp/mainloop_fwd_sm90_tma_gmma_ws.hpp:942-984); gfx950 has no 8-bit transpose read, so a prepare kernel
-// rewrites V ONCE per call into V^T tiles [B, Hk, Kt][128 d][64 keys] whose 64-byte rows already hold the keys in the order
+// rewrites V ONCE per call into V^T tiles [B, Hk, Kt][D d][64 keys] whose 64-byte rows already hold the keys in the order
 // the PV operand of the block-scaled MFMA wants (k-step pair j, lane-half hh, k-step parity, accumulator slot
 // e <-> key 16kk + 4hh + (e&3) + 8(e>>2)) and are already XOR-swizzled for conflict-free ds_read_b128; the forward kernel
 // stages them with a linear LDS-DMA. One extra pass over V (0.4 GB at S=75600, H=40) against ~60 TFLOP of attention.
@@ -16,10 +16,7 @@ namespace la {
 
 namespace {
 
-constexpr int F8_D = 128;
 constexpr int F8_BN = 64;
-constexpr int F8_KROW = F8_D;                 // bytes per K row in LDS
-constexpr int F8_TILE = F8_BN * F8_KROW;      // 8 KiB (K tile and V^T tile)
 constexpr int F8_VROW = F8_BN;                // bytes per V^T row (64 keys)
 
 // V^T rows are 64 bytes = 4 chunks: four rows per bank row -> chunk ^ ((row>>2)&3)
@@ -28,16 +25,18 @@ __device__ __forceinline__ constexpr int f8_v_swz(int row) { return (row >> 2) &
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-// Prepare kernel: V (B,Sk,H,128) e4m3 -> V^T tiles [B,H,Kt][128][64] (key order and swizzle as above).
+// Prepare kernel: V (B,Sk,H,D) e4m3 -> V^T tiles [B,H,Kt][D][64] (key order and swizzle as above), D = 128 or 64 (a head_dim-64 tile is
+// the first 64 rows of what a head_dim-128 tile would be: 4 KiB).
 // One workgroup per (b, h, k-tile); rows past seqlen_k become zeros (P is 0 there anyway).
 // Packed variable-length batches (cu_seqlens_k != nullptr): v is (total_k, H, 128), sequence b owns rows [cu[b], cu[b + 1]) and its
 // tiles are written to the same [B, H, Kt] grid (Kt = tiles of the longest sequence; the tiles past a sequence's end are zeros).
 // ------------------------------------------------------------------------------------------------
+template <int D>
 __global__ void __launch_bounds__(256) la_prep_v_fp8_kernel(const uint8_t* __restrict__ v, int64_t v_batch_stride,
                                                             int64_t v_row_stride, int64_t v_head_stride,
                                                             uint8_t* __restrict__ vt, int seqlen_k, int num_heads,
                                                             int k_tiles, const int* __restrict__ cu_seqlens_k) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[F8_BN][F8_D + 16];   // [key][d], padded rows
+    __shared__ __attribute__((aligned(16))) uint8_t tile[F8_BN][D + 16];   // [key][d], padded rows
     const int n = blockIdx.x % k_tiles;
     const int bh = blockIdx.x / k_tiles;
     const int h = bh % num_heads, b = bh / num_heads;
@@ -48,21 +47,22 @@ __global__ void __launch_bounds__(256) la_prep_v_fp8_kernel(const uint8_t* __res
         src = v + static_cast<int64_t>(k0) * v_row_stride + h * v_head_stride;
     }
     const int tid = threadIdx.x;
-    // coalesced load: 64 rows x 128 bytes = 512 chunks of 16 bytes, 2 per thread
+    // coalesced load: 64 rows x D bytes = 4 D chunks of 16 bytes, D / 64 per thread
+    constexpr int kPerThread = D / 64, kRowChunks = D / 16;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < kPerThread; ++it) {
         const int cid = tid + 256 * it;
-        const int row = cid >> 3, ch = cid & 7;
+        const int row = cid / kRowChunks, ch = cid % kRowChunks;
         u32x4 t = {0u, 0u, 0u, 0u};
         const int key = n * F8_BN + row;
         if (key < seqlen_k) t = *reinterpret_cast<const u32x4*>(src + static_cast<int64_t>(key) * v_row_stride + ch * 16);
         *reinterpret_cast<u32x4*>(&tile[row][ch * 16]) = t;
     }
     __syncthreads();
-    // 128 rows (d) x 4 chunks of 16 bytes out, 2 per thread
-    uint8_t* dst = vt + (static_cast<int64_t>(bh) * k_tiles + n) * F8_TILE;
+    // D rows (d) x 4 chunks of 16 bytes out, D / 64 per thread
+    uint8_t* dst = vt + (static_cast<int64_t>(bh) * k_tiles + n) * (F8_BN * D);
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < kPerThread; ++it) {
         const int cid = tid + 256 * it;
         const int d = cid >> 2, cpos = cid & 3;
         const int ch = cpos ^ f8_v_swz(d);            // logical chunk = 2*j + hh
@@ -86,12 +86,17 @@ __global__ void __launch_bounds__(256) la_prep_v_fp8_kernel(const uint8_t* __res
 }
 
 hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_row_stride, int64_t v_head_stride,
-                             void* vt, int batch, int seqlen_k, int num_heads, int k_tiles, hipStream_t stream,
+                             void* vt, int batch, int seqlen_k, int num_heads, int k_tiles, int head_dim, hipStream_t stream,
                              const int* cu_seqlens_k) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(la_prep_v_fp8_kernel, dim3(batch * num_heads * k_tiles), dim3(256), 0, stream,
-                       static_cast<const uint8_t*>(v), v_batch_stride, v_row_stride, v_head_stride,
-                       static_cast<uint8_t*>(vt), seqlen_k, num_heads, k_tiles, cu_seqlens_k);
+    if (head_dim == 64)
+        hipLaunchKernelGGL(la_prep_v_fp8_kernel<64>, dim3(batch * num_heads * k_tiles), dim3(256), 0, stream,
+                           static_cast<const uint8_t*>(v), v_batch_stride, v_row_stride, v_head_stride,
+                           static_cast<uint8_t*>(vt), seqlen_k, num_heads, k_tiles, cu_seqlens_k);
+    else
+        hipLaunchKernelGGL(la_prep_v_fp8_kernel<128>, dim3(batch * num_heads * k_tiles), dim3(256), 0, stream,
+                           static_cast<const uint8_t*>(v), v_batch_stride, v_row_stride, v_head_stride,
+                           static_cast<uint8_t*>(vt), seqlen_k, num_heads, k_tiles, cu_seqlens_k);
     return hipGetLastError();
 }
 
@@ -161,8 +166,8 @@ hipError_t launch_upconvert_fp8(const void* src, int64_t batch_stride, int64_t r
     return hipGetLastError();
 }
 
-size_t fp8_workspace_bytes(int batch, int num_heads, int k_tiles) {
-    return static_cast<size_t>(batch) * num_heads * k_tiles * F8_TILE;
+size_t fp8_workspace_bytes(int batch, int num_heads, int k_tiles, int head_dim) {
+    return static_cast<size_t>(batch) * num_heads * k_tiles * F8_BN * head_dim;
 }
 
 }  // namespace la

@@ -79,7 +79,7 @@ def kernel_head_dim(head_dim: int, element_size: int, flags: Optional[int] = Non
     zero-pads q, k, v to it (``mha_fwd``), which is exact: zero columns add 0 to every score and give zero output columns,
     which are sliced away. The reference instantiates 64/96/128/192/256 (hopper/setup.py:57-61) and picks the next size up the
     same way (flash_api.cpp round_up_headdim). bf16 / fp16: 64, 96, 128, 192, 256 are built (with LA_FWD_KERNEL=v2, the
-    hipcc-scheduled A/B kernels: 64, 128, 256); fp8: 128 natively, 192 / 256 on the bf16 kernels inside la_fwd; beyond that the library's typed error is raised. The library is
+    hipcc-scheduled A/B kernels: 64, 128, 256); fp8: 64 and 128 natively, 192 / 256 on the bf16 kernels inside la_fwd; beyond that the library's typed error is raised. The library is
     asked (``la_get_tile_sizes_ex``), there is no second table here."""
     if head_dim <= 0 or head_dim % (16 if element_size == 1 else 8) != 0:
         return head_dim                                      # la_get_tile_sizes / mha_fwd report the error

@@ -147,7 +147,8 @@ def main():
         print(name, "pt_maxerr", (out_pt.float() - out_ref).abs().max().item())
     # G5-fp8: e4m3 inputs with per-(batch, head) descales (hopper/tests/test_flash_attn.py:204-219, 253)
     for name, seed, B, Sq, Sk, H, D in [("fp8_b2_s333_h3_d128", 11, 2, 333, 333, 3, 128),
-                                        ("fp8_sq200_sk777_h2_d128", 12, 1, 200, 777, 2, 128)]:
+                                        ("fp8_sq200_sk777_h2_d128", 12, 1, 200, 777, 2, 128),
+                                        ("fp8_sq130_sk517_h2_d64", 13, 1, 130, 517, 2, 64)]:      # round 6: the native head_dim-64 fp8 body
         q, k, v = dense_inputs(seed, B, Sq, Sk, H, D, torch.float8_e4m3fn)
         g = torch.Generator().manual_seed(1000 + seed)
         qd, kd, vd = [torch.rand(B, H, generator=g) * 2 for _ in range(3)]

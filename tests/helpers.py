@@ -10,7 +10,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 DENSE_CASES = ["cfg0_fp32_s2048_d64", "bf16_b2_s333_h3_d128", "bf16_s512_h2_d128", "bf16_sq113_sk203_h2_d128"]
 FP16_CASES = ["fp16_b2_s333_h3_d128", "fp16_sq130_sk517_h2_d64"]
-FP8_CASES = ["fp8_b2_s333_h3_d128", "fp8_sq200_sk777_h2_d128"]
+FP8_CASES = ["fp8_b2_s333_h3_d128", "fp8_sq200_sk777_h2_d128", "fp8_sq130_sk517_h2_d64"]
 GQA_CASES = ["gqa_bf16_b2_s200_h6_hk2_d128", "mqa_bf16_sq130_sk517_h4_hk1_d64"]     # nheads_k < nheads
 GQA_FP8_CASES = ["gqa_fp8_b1_s260_h4_hk2_d128"]
 

@@ -16,7 +16,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "liteattention_amd")
 POISON = {"LA_X64_OPT": "nosoftmax,mfmasum", "LA_X64_D64_OPT": "w2", "LA_X64_D256_OPT": "nobarrier", "LA_X64F8_OPT": "nomx",
-          "LA_X64F8_DEFAULT_OPT": "nobarrier", "LA_X64F8_EXP_OPT": "halfbarrier", "LA_X64F8_LVALU_OPT": "nowaitvm", "LA_X64_FORM": "half", "LA_X64_HALF_OPT": "nosoftmax"}
+          "LA_X64F8_DEFAULT_OPT": "nobarrier", "LA_X64F8_EXP_OPT": "halfbarrier", "LA_X64F8_LVALU_OPT": "nowaitvm", "LA_X64_FORM": "half", "LA_X64_HALF_OPT": "nosoftmax", "LA_X64F8_D": "64",
+          "LA_X64F8_D64_LVALU_OPT": "nobarrier"}
 
 
 def _generate(tmp, variant, env):
@@ -37,7 +38,7 @@ def test_a_poisoned_environment_yields_the_clean_product_bodies(tmp_path):
     clean_dir.mkdir(); dirty_dir.mkdir()
     a = _generate(clean_dir, False, {})
     b = _generate(dirty_dir, False, POISON)
-    assert len(a["generated"]) == 19 and [os.path.basename(p) for p in a["generated"]] == [os.path.basename(p) for p in b["generated"]]
+    assert len(a["generated"]) == 22 and [os.path.basename(p) for p in a["generated"]] == [os.path.basename(p) for p in b["generated"]]
     for pa, pb in zip(a["generated"], b["generated"]):
         assert open(pa, "rb").read() == open(pb, "rb").read(), os.path.basename(pa)        # byte for byte
         head = open(pb).read(400)
@@ -113,8 +114,9 @@ def test_every_loop_head_sits_at_its_pinned_code_placement():
     lib = os.path.join(PKG, "libliteattention_amd.so")
     if not os.path.exists(objdump) or not os.path.exists(lib):
         pytest.skip("llvm-objdump or the library is not there")
-    want = {"Li64E": 24, "Li96E": 8, "Li128E": 8, "Li192E": 8, "Li256E": 0, "fp8_kernelILb1ELi0E": 0, "fp8_kernelILb0ELi0E": 0,
-            "fp8_kernelILb1ELi1E": 24, "fp8_kernelILb0ELi1E": 24, "fp8_kernelILb1ELi2E": 8, "fp8_kernelILb0ELi2E": 8}
+    # (the fp8 names carry their head dim too - <lists, form of P, head dim> - so their keys are tried first; a form's phase is the same at 64 and 128)
+    want = {"fp8_kernelILb1ELi0E": 0, "fp8_kernelILb0ELi0E": 0, "fp8_kernelILb1ELi1E": 24, "fp8_kernelILb0ELi1E": 24, "fp8_kernelILb1ELi2E": 8,
+            "fp8_kernelILb0ELi2E": 8, "Li64E": 24, "Li96E": 8, "Li128E": 8, "Li192E": 8, "Li256E": 0}
     seen = 0
     with tempfile.TemporaryDirectory() as d:
         copy = os.path.join(d, "lib.so")
@@ -127,11 +129,11 @@ def test_every_loop_head_sits_at_its_pinned_code_placement():
                 nxt = re.search(r"^[0-9a-f]+ <", seg, re.M)
                 seg = seg[:nxt.start()] if nxt else seg
                 heads = re.findall(r"s_cmp_lt_u32 s63, s55\s+// ([0-9A-Fa-f]+):", seg)          # the loop test: S_I < S_NTILES
-                if re.search(r"Li\d+ELb1E", m.group(1)):          # the half-vote form: its loop head is the test of the step form (the loop test sits in front of the drain)
+                if "fp8" not in m.group(1) and re.search(r"Li\d+ELb1E", m.group(1)):          # the half-vote form: its loop head is the test of the step form (the loop test sits in front of the drain)
                     heads = re.findall(r"s_cmp_eq_u32 s81, 3\s+// ([0-9A-Fa-f]+):", seg)
                 if not heads:
                     continue
                 key = next(k for k in want if k in m.group(1))
                 assert int(heads[0], 16) % 32 == want[key], (m.group(1), int(heads[0], 16) % 32, want[key])
                 seen += 1
-    assert seen == 32, seen            # 5 head dims x 2 element types x 2 (lists / dense) + the half-vote form of head dims 64 / 96 / 128 x 2 element types + 3 fp8 forms x 2
+    assert seen == 38, seen            # 5 head dims x 2 element types x 2 (lists / dense) + the half-vote form of head dims 64 / 96 / 128 x 2 element types + 3 fp8 forms x 2 x 2 head dims

@@ -1,0 +1,175 @@
+"""GPU: the native head_dim-64 fp8 (e4m3) body (round 6; gen_fwd_x64_fp8.py under LA_X64F8_D=64, la_fwd_kernel_x64_fp8.hip <.., .., 64>).
+
+Until round 5 e4m3 at head dims <= 64 ran zero-padded on the head_dim-128 body. The native body does one 64-wide contraction per score
+block and two d-blocks of O^T; every fp32 operation on a real column is the one the padded form does (a zero product adds exactly 0 to a
+score; d-blocks of O^T are independent), so the two must agree BIT FOR BIT - O, LSE and the written lists, in all three forms of P. That
+is the first test; the others hold the body against the oracle directly (ragged shapes, lists over steps with descales and GQA, the
+lazy-rescale path, smaller head dims served by this body) as tests/test_gpu_fp8.py does at 128; packed variable-length batches at 64:
+tests/test_gpu_varlen_lists.py. The
+reference-generated golden `fp8_sq130_sk517_h2_d64` runs in test_gpu_fp8.py::test_fp8_dense_matches_reference_outputs."""
+import pytest
+import torch
+
+from helpers import fp8_lse_tol, fp8_p_round, structured_qkv
+
+pytestmark = pytest.mark.gpu
+F8 = torch.float8_e4m3fn
+D = 64
+
+
+@pytest.fixture(params=["encoded", "exp", "exact"], autouse=True)
+def p_mode(request, monkeypatch):
+    """The three forms of P (tests/test_gpu_fp8.py)."""
+    monkeypatch.delenv("LA_FP8_P", raising=False)
+    if request.param == "encoded":
+        monkeypatch.setenv("LA_FP8_P", "encoded")
+    elif request.param == "exp":
+        monkeypatch.setenv("LA_FP8_P", "mfma_rowsum")
+    return request.param
+
+
+def _tiles():
+    import liteattention_amd as L
+    return L.get_tile_sizes(D, 1)
+
+
+def _tol(o):
+    return 0.05 * o.abs().max().item() + 2e-2
+
+
+def _pad128(t):
+    return torch.nn.functional.pad(t.view(torch.uint8), (0, 128 - t.shape[-1])).view(F8)
+
+
+def test_the_library_serves_head_dim_64_natively():
+    import liteattention_amd as L
+    from liteattention_amd import _cabi
+    from liteattention_amd.flash_attn_interface import kernel_head_dim
+    assert _cabi.is_instantiated(64, 1, 0) and kernel_head_dim(64, 1) == 64 and kernel_head_dim(48, 1) == 64 and kernel_head_dim(80, 1) == 128
+    assert L.get_tile_sizes(64, 1) == (256, 64)
+
+
+@pytest.mark.parametrize("shape", [(2, 300, 4, 2, 1000), (1, 17, 1, 1, 17), (1, 700, 2, 2, 4224)])
+def test_native_64_equals_the_zero_padded_128_body_bit_for_bit_dense(shape):
+    import liteattention_amd as L
+    B, Sq, H, Hk, Sk = shape
+    g = torch.Generator().manual_seed(Sq + Sk)
+    q, k, v = (torch.randn(B, Sq, H, D, generator=g).to(F8).cuda(), torch.randn(B, Sk, Hk, D, generator=g).to(F8).cuda(),
+               torch.randn(B, Sk, Hk, D, generator=g).to(F8).cuda())
+    qd, kd, vd = [(0.5 + torch.rand(B, Hk, generator=g)).cuda() for _ in range(3)]
+    out, lse = L.flash_attn_func(q, k, v, q_descale=qd, k_descale=kd, v_descale=vd, return_softmax_lse=True)
+    out_p, lse_p = L.flash_attn_func(_pad128(q), _pad128(k), _pad128(v), softmax_scale=D ** -0.5, q_descale=qd, k_descale=kd, v_descale=vd,
+                                     return_softmax_lse=True)
+    assert out.shape == (B, Sq, H, D) and bool(torch.isfinite(out.float()).all())
+    assert torch.equal(out, out_p[..., :D]) and torch.equal(lse, lse_p)
+    assert not out_p[..., D:].any()
+
+
+def test_native_64_equals_the_zero_padded_128_body_bit_for_bit_lists():
+    """Three steps of lists on two LiteAttention objects (native / padded inputs): O, LSE and both lists equal after every step."""
+    import liteattention_amd as L
+    B, S, H, thr = 1, 2304, 3, -3.0
+    a64, a128 = L.LiteAttention(threshold=thr, max_batch_size=B), L.LiteAttention(threshold=thr, max_batch_size=B)
+    listed = []
+    for step in range(3):
+        q, k, v = [x.to(F8).cuda() for x in structured_qkv(B, S, H, D, seed=640 + step, alpha=9.0, dtype=torch.float32)]
+        out, lse = a64(q, k, v, return_softmax_lse=True)
+        out_p, lse_p = a128(_pad128(q), _pad128(k), _pad128(v), scale=D ** -0.5, return_softmax_lse=True)
+        assert torch.equal(out, out_p[..., :D]) and torch.equal(lse, lse_p)
+        for i in (0, 1):
+            assert torch.equal(a64._skip_list[i], a128._skip_list[i])
+        from oracle import oracle as orc
+        listed.append(orc.listed_tiles(a64._skip_list[a64._phase][:B].cpu()))
+    Qt, Kt = -(-S // _tiles()[0]), -(-S // _tiles()[1])
+    assert listed[-1] < 0.95 * B * H * Qt * Kt
+
+
+@pytest.mark.parametrize("shape", [(1, 17, 1, 17, 64), (2, 129, 3, 65, 64), (1, 1000, 2, 1250, 64), (1, 128, 1, 4224, 64), (1, 300, 2, 700, 48),
+                                   (1, 260, 2, 130, 32), (1, 70, 1, 333, 16)])
+def test_ragged_shapes_against_the_oracle(shape):
+    import liteattention_amd as L
+    from oracle import oracle as orc
+    B, Sq, H, Sk, d = shape
+    bm, bn = L.get_tile_sizes(d, 1)
+    g = torch.Generator().manual_seed(Sq * 7 + Sk + d)
+    q, k, v = [torch.randn(B, s, H, d, generator=g).to(F8) for s in (Sq, Sk, Sk)]
+    out, lse = L.flash_attn_func(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
+    o8, lse8, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, p_round=fp8_p_round())
+    assert out.shape == q.shape
+    assert (out.float().cpu() - o8).abs().max().item() <= _tol(o8)
+    assert (lse.cpu() - lse8).abs().max().item() <= fp8_lse_tol()
+
+
+def test_skip_lists_match_the_oracle_over_steps_with_descales_and_gqa():
+    import liteattention_amd as L
+    from oracle import oracle as orc
+    from test_gpu_parity import _compare_lists
+    bm, bn = _tiles()
+    B, S, H, Hk, thr = 1, 2560, 4, 2, -3.0           # 40 key tiles: the vote words wrap (32 bits per word)
+    Qt, Kt = S // bm, S // bn
+    att = L.LiteAttention(threshold=thr, max_batch_size=B)
+    md_row = orc.expand_must_do_ref([0, 0], bn, Kt + 1)
+    margins = torch.empty(B, H, Qt, Kt)
+    qd, kd, vd = torch.tensor([[0.7, 1.3]]), torch.tensor([[1.1, 0.9]]), torch.tensor([[0.5, 1.7]])
+    listed = []
+    for step in range(4):
+        q, k, v = [x.to(F8) for x in structured_qkv(B, S, H, D, seed=364, alpha=9.0, dtype=torch.float32)]
+        k, v = k[:, :, :Hk].contiguous(), v[:, :, :Hk].contiguous()
+        rd_idx = att._phase if att._skip_list is not None else 0
+        out, lse = att(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True, q_descale=qd.cuda(), k_descale=kd.cuda(), v_descale=vd.cuda())
+        rd, wr = att._skip_list[rd_idx].cpu(), att._skip_list[1 - rd_idx].cpu()
+        wr_orc = torch.zeros_like(wr)
+        o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=rd, write_list=wr_orc, must_do_list=md_row, thr=thr,
+                                           margins=margins, p_round=fp8_p_round(), q_descale=qd, k_descale=kd, v_descale=vd)
+        assert (out.float().cpu() - o_ref).abs().max().item() <= _tol(o_ref)
+        assert (lse.cpu() - lse_ref).abs().max().item() <= fp8_lse_tol()
+        bad, _ = _compare_lists(orc, rd, wr, wr_orc, margins, thr, B)
+        assert bad == 0
+        listed.append(orc.listed_tiles(wr[:B]))
+    assert listed[-1] < 0.95 * B * H * Qt * Kt and listed == sorted(listed, reverse=True)
+
+
+def test_running_max_that_grows_late_in_the_walk():
+    """The O^T rescale round trip of the head_dim-64 body (two d-blocks per q-block): tests/test_gpu_fp8.py, gain 8."""
+    import liteattention_amd as L
+    from oracle import oracle as orc
+    from test_gpu_parity import _compare_lists
+    bm, bn = _tiles()
+    B, S, H = 1, 1536, 2
+    g = torch.Generator().manual_seed(93)
+    q, k, v = [torch.randn(B, S, H, D, generator=g) for _ in range(3)]
+    k = k * torch.linspace(8.0, 1.0, S).view(1, S, 1, 1)
+    q, k, v = [x.to(F8) for x in (q, k, v)]
+    o8, lse8, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, p_round=fp8_p_round())
+    out, lse = L.flash_attn_func(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
+    assert bool(torch.isfinite(out.float()).all())
+    assert (out.float().cpu() - o8).abs().max().item() <= _tol(o8)
+    assert (lse.cpu() - lse8).abs().max().item() <= fp8_lse_tol()
+    Qt, Kt = -(-S // bm), -(-S // bn)
+    att = L.LiteAttention(threshold=-1.0, max_batch_size=B)
+    margins = torch.empty(B, H, Qt, Kt)
+    for _ in range(2):
+        rd_idx = att._phase if att._skip_list is not None else 0
+        out, lse = att(q.cuda(), k.cuda(), v.cuda(), return_softmax_lse=True)
+        rd, wr = att._skip_list[rd_idx].cpu(), att._skip_list[1 - rd_idx].cpu()
+        wr_orc = torch.zeros_like(wr)
+        o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, read_list=rd, write_list=wr_orc, thr=-1.0, margins=margins,
+                                           p_round=fp8_p_round())
+        assert (out.float().cpu() - o_ref).abs().max().item() <= _tol(o_ref)
+        assert (lse.cpu() - lse_ref).abs().max().item() <= fp8_lse_tol()
+        bad, _ = _compare_lists(orc, rd, wr, wr_orc, margins, -1.0, B)
+        assert bad == 0
+
+
+def test_static_map_equals_the_ticket_queues_and_q_windows_compose():
+    """Raw mha_fwd at head_dim 64: the static one-workgroup-per-item map and two q-tile windows give the results of the default launch."""
+    from liteattention_amd.flash_attn_interface import mha_fwd
+    g = torch.Generator().manual_seed(5)
+    B, S, H = 2, 1100, 3
+    q, k, v = [torch.randn(B, S, H, D, generator=g).to(F8).cuda() for _ in range(3)]
+    ref = mha_fwd(q, k, v)
+    st = mha_fwd(q, k, v, _static_sched=True)
+    assert torch.equal(ref[0], st[0]) and torch.equal(ref[1], st[1])
+    Qt = -(-S // _tiles()[0])
+    win = mha_fwd(q, k, v, _q_windows=[(0, 2), (2, Qt - 2)])
+    assert torch.equal(ref[0], win[0]) and torch.equal(ref[1], win[1])

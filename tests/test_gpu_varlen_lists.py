@@ -132,9 +132,10 @@ def test_block_sparse_packed_batch_is_one_launch_and_matches_the_per_sequence_fo
         L.flash_blocksparse_attn_qkvpacked_func(qkv, torch.tensor(cu, dtype=torch.int32).cuda(), bad, 0.0, max_s)
 
 
+@pytest.mark.parametrize("D", [128, 64])                       # 64: the native head_dim-64 fp8 body (round 6), prepared V^T tiles of 4 KiB
 @pytest.mark.parametrize("with_lists", [False, True])
-@pytest.mark.parametrize("p_mode", ["encoded", "exp"])
-def test_fp8_packed_batch_equals_the_fixed_length_path(with_lists, p_mode, monkeypatch):
+@pytest.mark.parametrize("p_mode", ["encoded", "exp", "reference"])
+def test_fp8_packed_batch_equals_the_fixed_length_path(with_lists, p_mode, D, monkeypatch):
     """fp8 (e4m3) with cu_seqlens (round 3): the V^T prepare pass reads cu_seqlens_k itself and writes every sequence's tiles onto the
     [B, Hk, Kt_max] grid, the forward kernel takes each item's rows / lengths from cu_seqlens - ONE forward launch. Per sequence the
     result must equal a fixed-length fp8 launch on that sequence with that sequence's descales - O, LSE and (with lists, three steps at
@@ -142,9 +143,10 @@ def test_fp8_packed_batch_equals_the_fixed_length_path(with_lists, p_mode, monke
     import liteattention_amd as L
     from liteattention_amd.flash_attn_interface import mha_fwd
     monkeypatch.delenv("LA_FP8_P", raising=False)
-    monkeypatch.setenv("LA_FP8_P", "mfma_rowsum" if p_mode == "exp" else "encoded")
+    if p_mode != "reference":
+        monkeypatch.setenv("LA_FP8_P", "mfma_rowsum" if p_mode == "exp" else "encoded")
     F8 = torch.float8_e4m3fn
-    D, H, Hk, thr = 128, 4, 2, -2.5
+    H, Hk, thr = 4, 2, -2.5
     bm, bn = L.get_tile_sizes(D, 1)
     lens_q = [700, 0, 40, 1300, 513, 100]
     lens_k = [900, 64, 130, 1300, 200, 0]

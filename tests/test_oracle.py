@@ -202,14 +202,15 @@ def test_fp8_log_linear_encoding_of_p_stays_inside_the_reference_rule(name):
     Round 5: the oracle restates the KERNEL's grid exactly - P~ relative to the lazy reference maximum m_ref (the first walked tile's row
     maximum; `lin_lazy`, the default) - where rounds 3-4 encoded relative to the true running maximum after every tile. That older grid
     represents a row's dominant key exactly (its exponent lands on a byte), the kernel's does not ((m_true - m_ref) c is no integer):
-    against the hardware rounding the kernel's grid has 1.6-2.1 x the rms error and up to 2.3 x the max error on these goldens, the older
+    against the hardware rounding the kernel's grid has 1.6-2.1 x the rms error and up to 2.3 x the max error on the head_dim-128 goldens
+    (2.8 x on the head_dim-64 one added in round 6: 0.028 against 0.010, where the reference's rule allows 0.098), the older
     restatement 1.2-1.9 x / 1.1-1.9 x. Both are held here; the first is the one the GPU tests compare the kernel with."""
     c = load_dense_case(name)
     kw = dict(q_descale=c["q_descale"], k_descale=c["k_descale"], v_descale=c["v_descale"])
     o8, lse8, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=256, block_n=64, p_round="fp8", **kw)
     e8 = (o8 - c["out_ref"]).abs().max().item()
     rms8 = (o8 - c["out_ref"]).pow(2).mean().sqrt().item()
-    for lazy, k_max, k_rms in ((True, 2.3, 2.1), (False, 1.9, 1.9)):
+    for lazy, k_max, k_rms in ((True, 2.8 if name.endswith("_d64") else 2.3, 2.1), (False, 1.9, 1.9)):
         ol, lsel, _ = orc.qkskip_fwd(c["q"], c["k"], c["v"], block_m=256, block_n=64, p_round="fp8_lin", lin_lazy=lazy, **kw)
         el = (ol - c["out_ref"]).abs().max().item()
         assert el <= 0.55 * ref_tolerance(c["out_ref"], c["pt_maxerr"]), (lazy, el, ref_tolerance(c["out_ref"], c["pt_maxerr"]))
