@@ -55,7 +55,8 @@ def option_tag():
 
 
 
-XPAIRS = int(opt_val("x", {128: {"lin": "8", "exp": "4", "lvalu": "4"}, 64: {"lin": "12", "exp": "2", "lvalu": "6"}}[int(os.environ.get("LA_X64F8_D", "128"))]
+XPAIRS = int(opt_val("x", {128: {"lin": "8", "exp": "4", "lvalu": "4"}, 64: {"lin": "12", "exp": "2", "lvalu": "6"},
+                                192: {"lin": "8", "exp": "8", "lvalu": "8"}, 256: {"lin": "8", "exp": "8", "lvalu": "8"}}[int(os.environ.get("LA_X64F8_D", "128"))]
                         ["lvalu" if "lvalu" in OPT else "exp" if "exp" in OPT else "lin"]))          # pair-groups (of 16) done in phase 2. EVEN: two pair-groups share one packed-e4m3 destination register
                                           # (lo / hi half by op_sel); an odd split leaves a half-written register across the phase boundary
                                           # (measured x = 2 / 4: 2078-2101 TFLOP/s at 42 %, x = 3 / 5 / 6: 2048-2065). head_dim 64 (phase 1 has 4 MFMAs, not 8;
@@ -65,14 +66,23 @@ XPAIRS = int(opt_val("x", {128: {"lin": "8", "exp": "4", "lvalu": "4"}, 64: {"li
 # MFMAs per step instead of 8 + 8 under the same softmax. K tile = 64 keys x 64 bytes, held in LDS as 32 pseudo-rows of 128 bytes (key R in
 # chunks 0-3, key R + 32 in chunks 4-7) so that the fragment addresses and the swizzle are those of head_dim 128 with `sx` read as the key
 # block; prepared V^T tile = its first 64 rows. One LDS-DMA piece of 1 KiB per wave, tensor and step instead of two.
+# Head dims 192 / 256 (round 6, "WIDE"): ONE q-block of 32 rows per wave (O^T of 32 rows x 256 is 128 accumulators), q-tile 128 x k-tile 64 - the tiles of
+# the bf16 kernels of these head dims, so lists keep their geometry. 3 / 4 contraction steps per score block, 6 / 8 d-blocks; K rows sit in LDS at a
+# 256-byte stride (16 chunks, XOR-swizzled by row & 15; at 192 the last four chunks of a row are DMA filler, never read), rings of 16 KiB per stage.
+# Per wave and step: 16 K + 16 V^T fragment reads of 1 KiB against 16 MFMAs and half the softmax of the 64-row bodies: bound by the matrix pipe and the LDS.
 D = int(os.environ.get("LA_X64F8_D", "128"))
-assert D in (64, 128), D
-NSX, ND = D // 64, D // 32                # 64-wide contraction steps of S^T = K Q^T; 32-wide d-blocks of O^T
+assert D in (64, 128, 192, 256), D
+WIDE = D > 128
+NQB = 1 if WIDE else 2                    # q-blocks of 32 rows per wave
+QBS = tuple(range(NQB))
+NSX, ND = (D + 63) // 64, D // 32         # 64-wide contraction steps of S^T = K Q^T; 32-wide d-blocks of O^T
 DB = ND                                   # gen_epilogue.py: d-blocks to store
-PIECES = D // 64                          # 1 KiB LDS-DMA pieces per wave and tile
+PIECES_K = 4 if WIDE else D // 64         # 1 KiB LDS-DMA pieces per wave and K tile (WIDE: the 16 KiB image of 256-byte rows)
+PIECES_V = D // 64                        # ... and prepared V^T tile (64 D bytes)
+ROWSUM = 99                               # "d-block" index of the row-sum MFMA in PV_ORDER
 PK = "pk" in OPT                          # A/B: packed fp32 FMA / add in the softmax (v_pk_fma_f32, v_pk_add_f32). MEASURED ANTI-LEVER here too:
                                           # 64 fewer instructions per step, bit-identical results, 1891 vs 2068 TFLOP/s at 42 % (round 2, tools/ab.py --fp8)
-NG = 4 * NSX                              # QK MFMAs (gaps) of phase 1
+NG = 2 * NSX * NQB                        # QK MFMAs (gaps) of phase 1
 # Row sums. "lvalu" (round 2): l = sum of the UN-rounded fp32 P, 64 v_add_f32 per step (the reference's form, softmax.h:275-296).
 # Default (round 3): l~ = sum of the e4m3-ROUNDED P, taken from the matrix pipe: one more 32 x 32 x 64 MFMA per q-block and step
 # with an all-ones A operand (every row of the result is the column sum of P^T), accumulated in a[192:223] and rescaled with O.
@@ -95,7 +105,7 @@ LMFMA = "lvalu" not in OPT
 # hardware rounding keeps P down to 2^-10. Needs the row sums of the ENCODED P (LMFMA): no fp32 P exists in this form.
 LIN = LMFMA and "exp" not in OPT
 LIN_DELTA = 0.0575
-NG2 = 2 * ND + (2 if LMFMA else 0)        # MFMAs (gaps) of phase 2: PV + the two row-sum MFMAs
+NG2 = NQB * ND + (NQB if LMFMA else 0)    # MFMAs (gaps) of phase 2: PV + the row-sum MFMA of each q-block
 # Lazy-rescale slack TAU (log2 units) and the offset of P. P <= 2^(P_OFFSET + TAU) must stay finite in e4m3 (max 448 = 2^8.8):
 # exp / lvalu: the reference's 2^8 ceiling (Max_offset = 8, softmax.h:85-87), TAU = 2. lin: ceiling 2^8.75 (byte 126; byte 127 is NaN)
 # and TAU = 1 - the byte grid ends at byte 1 = 2^-9 <-> y = -6.94, so a key is kept while its weight is above 2^-(P_OFFSET + 6.94)
@@ -115,7 +125,7 @@ MX = LIN and "nomx" not in OPT
 TAU = float(opt_val("tau", "32" if MX else ("1" if LIN else "2")))
 P_CEIL = 8.75 if LIN else 8.0
 P_OFFSET = 7.0 if MX else P_CEIL - TAU
-DMA_GAPS = [int(x) for x in opt_val("dmagaps", "0,1,1,2,3,3" if D == 128 else "0,1,2,3").replace(".", ",").split(",")]   # m0K,K0,K1,m0V,V0,V1 (phase 1 gaps; an M0 write is never adjacent to its first use)
+DMA_GAPS = [int(x) for x in opt_val("dmagaps", {64: "0,1,2,3", 128: "0,1,1,2,3,3", 192: "0,1,1,2,2,3,4,4,5", 256: "0,1,1,2,2,3,4,4,5,5"}[D]).replace(".", ",").split(",")]   # m0K,K0,K1,m0V,V0,V1 (phase 1 gaps; an M0 write is never adjacent to its first use)
 
 
 # ---------------------------------------------------------------- AGPR map
@@ -132,7 +142,7 @@ def KA(j):          # j = 2*kb + sx (head_dim 64: j = kb)
 
 
 def LSUM(qb):       # row sums of P~ (LMFMA): 16 accumulator registers per q-block, all rows equal
-    return 192 + 16 * qb
+    return 224 if WIDE else 192 + 16 * qb
 
 
 # ---------------------------------------------------------------- VGPR map
@@ -140,10 +150,10 @@ def S_(sset, qb, kb):
     return 64 * sset + 32 * qb + 16 * kb
 
 
-VF = [128 + 8 * i for i in range(4)]
-KADDR = list(range(160, 164))             # [2*sx + t]
+VF = [96 + 8 * i for i in range(8)] if WIDE else [128 + 8 * i for i in range(4)]      # WIDE: v[96:159] (no second q-block: v[32:63] and v[96:127] are free)
+KADDR = list(range(32, 40)) if WIDE else list(range(160, 164))             # [2*sx + t]
 VADDR = [164, 165]                        # [t]
-LK = [166, 167]
+LK = [166, 167, 40, 41] if WIDE else [166, 167]
 LV = 168
 VSC = 169                                 # 0x7f7f7f7f: four E8M0 exponents of 127 (= 2^0)
 ONES = 170                                # v[170:177] = 0x38383838: the all-ones e4m3 A operand of the row-sum MFMA
@@ -166,10 +176,11 @@ S_TB, S_VB, S_EXEC, S_T64, S_T64B = 42, 44, 46, 48, 50
  S_FREE3, S_DMAW, S_FREE4, S_TAU, S_RESC, S_FREE5) = range(52, 87)
 S_C8, S_NEGC8, S_M8 = S_FREE0, S_FREE1, S_FREE2   # lin: 8 c and -8 c; mx: -8.0
 S_FREE6, S_TB2, S_VB2, S_BIT = 87, 88, 90, 92     # second set of DMA bases (the loop is unrolled by two); the rotating vote bit
+S_DMAWV = S_FREE4 if PIECES_V != PIECES_K else S_DMAW   # LDS-DMA destination of this wave's V^T pieces (head_dim 192: 3 pieces against 4 of K)
 TBS, VBS = [S_TB, S_TB2], [S_VB, S_VB2]
 
-KV_TILE = 8192
-V_REGION = 16384
+KV_TILE = 16384 if WIDE else 8192         # one stage of the K / V^T rings
+V_REGION = 2 * KV_TILE
 
 out = []
 
@@ -234,7 +245,9 @@ def finalize(items):
 def k_read(kbuf_imm, j, t):
     if D == 64:     # pseudo-rows of 128 bytes: the key block selects the chunk group, as sx does at 128
         return ("LDS", f"ds_read_b128 {ar(KA(j) + 4 * t, 4)}, {v(KADDR[2 * j + t])} offset:{kbuf_imm}", ("k", j, t))
-    kb, sx = j >> 1, j & 1
+    kb, sx = j // NSX, j % NSX
+    if WIDE:        # rows of 256 bytes: 32 keys of a key block = 8 KiB
+        return ("LDS", f"ds_read_b128 {ar(KA(j) + 4 * t, 4)}, {v(KADDR[2 * sx + t])} offset:{kbuf_imm + kb * 8192}", ("k", j, t))
     return ("LDS", f"ds_read_b128 {ar(KA(j) + 4 * t, 4)}, {v(KADDR[2 * sx + t])} offset:{kbuf_imm + kb * 4096}", ("k", j, t))
 
 
@@ -254,7 +267,7 @@ def mfma_qk(sset, kb, sx, qb):
 
 def mfma_pv(sset, db, qb):
     sc = f"{v(VSC)}, {v(SCB[sset][qb])} op_sel_hi:[0,0,0]" if MX else SCALES      # mx: the lane's block scale on the B operand (P)
-    if db == 4:      # row sums: ones (32 x 64) times P^T
+    if db == ROWSUM:      # row sums: ones (32 x 64) times P^T
         return f"    {MFMA} {ar(LSUM(qb), 16)}, {vr(ONES, 8)}, {vr(S_(sset, qb, 0), 8)}, {ar(LSUM(qb), 16)}, {sc}"
     return f"    {MFMA} {ar(O_(qb, db), 16)}, {vr(VF[db], 8)}, {vr(S_(sset, qb, 0), 8)}, {ar(O_(qb, db), 16)}, {sc}"
 
@@ -264,16 +277,16 @@ def mx_ops(sset, src):
     both half-waves): u = floor((m_loc - m_ref) c) + 127 -> E8M0 byte (the byte convert saturates: below 2^-127 the scale stops
     following, harmless; a tile of -inf gives NaN offsets = byte 0 for every key), offset = NMS - 8 (u - 127) (NMS carries the + 1016)."""
     o = []
-    for qb in (0, 1):
+    for qb in QBS:
         o.append(f"    v_fma_f32 {v(MXT[qb])}, {v(src[qb])}, {s(S_C)}, {v(NMR[qb])}")
-    for qb in (0, 1):
+    for qb in QBS:
         o.append(f"    v_floor_f32 {v(MXT[qb])}, {v(MXT[qb])}")
     if "mxt0" in OPT:        # debug: every block exponent 0
-        for qb in (0, 1):
+        for qb in QBS:
             o.append(f"    v_mov_b32 {v(MXT[qb])}, 0x{float_bits(127.0):08x}")
-    for qb in (0, 1):
+    for qb in QBS:
         o.append(f"    v_cvt_pk_u8_f32 {v(SCB[sset][qb])}, {v(MXT[qb])}, 0, 0")
-    for qb in (0, 1):
+    for qb in QBS:
         o.append(f"    v_fma_f32 {v(NMSB[qb])}, {v(MXT[qb])}, {s(S_M8)}, {v(NMS[qb])}")
     return o
 
@@ -281,7 +294,7 @@ def mx_ops(sset, src):
 def softmax_parts(sset, p):
     """Pair p (elements 2p, 2p+1 of the 32 per lane and q-block; key block kb = p >> 3) of BOTH q-blocks."""
     F, E, A, C = [], [], [], []
-    for qb in (0, 1):
+    for qb in QBS:
         e0 = 2 * p
         kb, r = e0 >> 4, e0 & 15
         r0 = S_(sset, qb, kb) + r
@@ -320,20 +333,22 @@ def softmax_stream(sset, groups):
     if not groups:
         return []
     parts = [softmax_parts(sset, p) for p in groups]
+    def both(per_qb):
+        return [x for qb in QBS for x in per_qb[qb]]
     if LIN:          # FMAs of pair g + 1 between the FMAs and the converts of pair g: every convert is >= 4 instructions behind its FMA
-        o = parts[0][0][0] + parts[0][0][1]
+        o = both(parts[0][0])
         for g in range(len(parts)):
             if g + 1 < len(parts):
-                o += parts[g + 1][0][0] + parts[g + 1][0][1]
-            o += parts[g][3][0] + parts[g][3][1]
+                o += both(parts[g + 1][0])
+            o += both(parts[g][3])
         return o
-    o = parts[0][0][0] + parts[0][0][1]
+    o = both(parts[0][0])
     n = len(parts)
     for g in range(n):
         Fn = parts[g + 1][0] if g + 1 < n else None
         Ap, Cp = (parts[g - 1][2], parts[g - 1][3]) if g > 0 else (None, None)
         E = parts[g][1]
-        for qb in (0, 1):
+        for qb in QBS:
             if PK:       # the packed FMA of group g+1 overwrites both temps: it goes behind the second exp
                 fill0 = list(Ap[qb]) if Ap else []
                 fill1 = (list(Fn[qb]) if Fn else []) + (list(Cp[qb]) if Cp else [])
@@ -341,16 +356,16 @@ def softmax_stream(sset, groups):
                 fill0 = ([Fn[qb][0]] if Fn else []) + (list(Ap[qb][:1]) if Ap else [])
                 fill1 = ([Fn[qb][1]] if Fn else []) + (list(Ap[qb][1:]) if Ap else []) + (list(Cp[qb]) if Cp else [])
             o += [E[qb][0]] + fill0 + [E[qb][1]] + fill1
-    for qb in (0, 1):
+    for qb in QBS:
         o += parts[-1][2][qb]
-    for qb in (0, 1):
+    for qb in QBS:
         o += parts[-1][3][qb]
     return o
 
 
 def row_max_ops(sset):
     per = []
-    for qb in (0, 1):
+    for qb in QBS:
         regs = [S_(sset, qb, 0) + r for r in range(32)]
         ops = [f"    v_max_f32 {v(MLOC[qb])}, {v(regs[0])}, {v(regs[1])}", f"    v_max_f32 {v(MLOC2[qb])}, {v(regs[2])}, {v(regs[3])}"]
         rest = regs[4:]
@@ -368,31 +383,34 @@ def stats_ops(rare_label, back_label, flush_label, flush_back, inval_label, inva
     S_BIT, the step past the end of the walk recognised by i == n - 1, no position arithmetic)."""
     o = []
     a = o.append
-    a(f"    v_mov_b32 {v(T[0])}, {v(MLOC[0])}")
-    a(f"    v_mov_b32 {v(T[1])}, {v(MLOC[1])}")
+
+    def any_lane(cmp_ops):
+        """vcc = OR of the compares of the q-blocks, SCC = some lane set (one q-block: the OR of the mask with itself sets SCC)."""
+        dst = [sr(S_T64)] + ["vcc"] * (NQB - 1)
+        for qb in QBS:
+            a(cmp_ops[qb].format(dst=dst[qb]))
+        a(f"    s_or_b64 vcc, {'vcc' if NQB == 2 else sr(S_T64)}, {sr(S_T64)}")
+    for qb in QBS:
+        a(f"    v_mov_b32 {v(T[qb])}, {v(MLOC[qb])}")
     a(f"    v_add_u32 {v(TABV)}, 16, {v(TABV)}")
-    a(f"    v_permlane32_swap_b32 {v(MLOC[0])}, {v(T[0])}")
-    a(f"    v_permlane32_swap_b32 {v(MLOC[1])}, {v(T[1])}")
+    for qb in QBS:
+        a(f"    v_permlane32_swap_b32 {v(MLOC[qb])}, {v(T[qb])}")
     a("    s_nop 0")
-    a(f"    v_max_f32 {v(MLOC[0])}, {v(MLOC[0])}, {v(T[0])}")
-    a(f"    v_max_f32 {v(MLOC[1])}, {v(MLOC[1])}, {v(T[1])}")
+    for qb in QBS:
+        a(f"    v_max_f32 {v(MLOC[qb])}, {v(MLOC[qb])}, {v(T[qb])}")
     a(f"    s_cmp_eq_u32 {s(S_I)}, {s(S_NM1)}")
     a(f"    s_cbranch_scc1 {inval_label}")
     o.append(inval_back + ":")
-    a(f"    v_sub_f32 {v(T[2])}, {v(MLOC[0])}, {v(MTRUE[0])}")              # vote: (m_loc - m_prev) * c > thr (softmax.h:194)
-    a(f"    v_sub_f32 {v(T[3])}, {v(MLOC[1])}, {v(MTRUE[1])}")
-    a(f"    v_max_f32 {v(MTRUE[0])}, {v(MTRUE[0])}, {v(MLOC[0])}")
-    a(f"    v_max_f32 {v(MTRUE[1])}, {v(MTRUE[1])}, {v(MLOC[1])}")
-    a(f"    v_mul_f32 {v(T[2])}, {s(S_C)}, {v(T[2])}")
-    a(f"    v_mul_f32 {v(T[3])}, {s(S_C)}, {v(T[3])}")
-    a(f"    v_cmp_gt_f32 {sr(S_T64)}, {v(T[2])}, {s(S_THR)}")
-    a(f"    v_cmp_gt_f32 vcc, {v(T[3])}, {s(S_THR)}")
-    a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")                                 # SCC = some row of the wave voted "do"
+    for qb in QBS:
+        a(f"    v_sub_f32 {v(T[2 + qb])}, {v(MLOC[qb])}, {v(MTRUE[qb])}")              # vote: (m_loc - m_prev) * c > thr (softmax.h:194)
+    for qb in QBS:
+        a(f"    v_max_f32 {v(MTRUE[qb])}, {v(MTRUE[qb])}, {v(MLOC[qb])}")
+    for qb in QBS:
+        a(f"    v_mul_f32 {v(T[2 + qb])}, {s(S_C)}, {v(T[2 + qb])}")
+    any_lane([f"    v_cmp_gt_f32 {{dst}}, {v(T[2 + qb])}, {s(S_THR)}" for qb in QBS])         # SCC = some row of the wave voted "do"
     a(f"    s_cselect_b32 {s(S_T0)}, {s(S_BIT)}, 0")
     a(f"    s_or_b32 {s(S_DOMASK)}, {s(S_DOMASK)}, {s(S_T0)}")
-    a(f"    v_cmp_gt_f32 {sr(S_T64)}, {v(MTRUE[0])}, {v(MTHR[0])}")         # lazy rescale trigger
-    a(f"    v_cmp_gt_f32 vcc, {v(MTRUE[1])}, {v(MTHR[1])}")
-    a(f"    s_or_b64 vcc, vcc, {sr(S_T64)}")
+    any_lane([f"    v_cmp_gt_f32 {{dst}}, {v(MTRUE[qb])}, {v(MTHR[qb])}" for qb in QBS])       # lazy rescale trigger
     a(f"    s_cbranch_vccnz {rare_label}")
     o.append(back_label + ":")
     if MX:
@@ -423,18 +441,18 @@ def float_bits(x):
 
 def rare_rescale_block(rare_label, back_label):
     label(rare_label)
-    for qb in (0, 1):
+    for qb in QBS:
         emit(f"v_sub_f32 {v(T[2 + qb])}, {v(MREF[qb])}, {v(MTRUE[qb])}")
-    for qb in (0, 1):
+    for qb in QBS:
         emit(f"v_mul_f32 {v(T[2 + qb])}, {s(S_C)}, {v(T[2 + qb])}")
-    for qb in (0, 1):
+    for qb in QBS:
         emit(f"v_exp_f32 {v(ALPHA[qb])}, {v(T[2 + qb])}")
-    for qb in (0, 1):
+    for qb in QBS:
         emit(f"v_mov_b32 {v(MREF[qb])}, {v(MTRUE[qb])}")
-    for qb in (0, 1):
+    for qb in QBS:
         set_nms(qb)
         emit(f"v_add_f32 {v(MTHR[qb])}, {s(S_TAU)}, {v(MREF[qb])}")
-    for qb in (0, 1):
+    for qb in QBS:
         if not LMFMA:                        # (LMFMA: the row sums live in accumulators and are rescaled with O)
             emit(f"v_mul_f32 {v(L0[qb])}, {v(L0[qb])}, {v(ALPHA[qb])}")
             emit(f"v_mul_f32 {v(L1[qb])}, {v(L1[qb])}, {v(ALPHA[qb])}")
@@ -444,7 +462,7 @@ def rare_rescale_block(rare_label, back_label):
 
 def inval_block(lbl, back):
     label(lbl)
-    for qb in (0, 1):
+    for qb in QBS:
         emit(f"v_mov_b32 {v(MLOC[qb])}, {v(NEGINF)}")
         emit(f"v_mov_b32 {v(NMS[qb])}, {v(NEGINF)}")
     emit(f"s_branch {back}")
@@ -475,7 +493,7 @@ def rescale_o_block(lbl, back):
     emit("s_nop 15")
     emit("s_nop 15")
     emit("s_nop 15")
-    for qb in (0, 1):
+    for qb in QBS:
         for base in range(0, 16 * ND, 8):
             for k in range(8):
                 emit(f"v_accvgpr_read_b32 {v(T[k])}, a{64 * qb + base + k}")
@@ -484,11 +502,11 @@ def rescale_o_block(lbl, back):
             for k in range(8):
                 emit(f"v_accvgpr_write_b32 a{64 * qb + base + k}, {v(T[k])}")
     if LMFMA:                                # the row sums: only register 0 of each block is ever read
-        for qb in (0, 1):
+        for qb in QBS:
             emit(f"v_accvgpr_read_b32 {v(T[qb])}, a{LSUM(qb)}")
-        for qb in (0, 1):
+        for qb in QBS:
             emit(f"v_mul_f32 {v(T[qb])}, {v(T[qb])}, {v(ALPHA[qb])}")
-        for qb in (0, 1):
+        for qb in QBS:
             emit(f"v_accvgpr_write_b32 a{LSUM(qb)}, {v(T[qb])}")
     emit(f"s_mov_b32 {s(S_RESC)}, 0")
     emit("s_nop 7")
@@ -503,10 +521,10 @@ def dma_ops(kbuf_imm, vbuf_imm, do_k=True, do_v=True, st=0):
     o = []
     if do_k:
         o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {kbuf_imm}")
-        o += [f"    global_load_lds_dwordx4 {v(LK[j])}, {sr(TBS[st])} offset:{1024 * j}" for j in range(PIECES)]
+        o += [f"    global_load_lds_dwordx4 {v(LK[j])}, {sr(TBS[st])} offset:{1024 * j}" for j in range(PIECES_K)]
     if do_v:
-        o.append(f"    s_add_u32 m0, {s(S_DMAW)}, {V_REGION + vbuf_imm}")
-        o += [f"    global_load_lds_dwordx4 {v(LV)}, {sr(VBS[st])} offset:{1024 * j}" for j in range(PIECES)]
+        o.append(f"    s_add_u32 m0, {s(S_DMAWV)}, {V_REGION + vbuf_imm}")
+        o += [f"    global_load_lds_dwordx4 {v(LV)}, {sr(VBS[st])} offset:{1024 * j}" for j in range(PIECES_V)]
     return o
 
 
@@ -538,9 +556,9 @@ def distribute(queue, post, start, cap=0):
 
 
 deferred = []
-QK_ORDER = [(sx, kb, qb) for sx in range(NSX) for kb in (0, 1) for qb in (0, 1)]      # dependent pairs are 4 MFMAs apart
-PV_ORDER = [(db, qb) for db in range(ND) for qb in (0, 1)] + ([(4, 0), (4, 1)] if LMFMA else [])   # db 4 = the row-sum MFMA
-K_FRAGS = [(j, t) for j in ((0, 2, 1, 3) if D == 128 else (0, 1)) for t in (0, 1)]  # sx = 0 fragments first
+QK_ORDER = [(sx, kb, qb) for sx in range(NSX) for kb in (0, 1) for qb in QBS]      # dependent pairs are 4 MFMAs apart (one q-block: 2)
+PV_ORDER = [(db, qb) for db in range(ND) for qb in QBS] + ([(ROWSUM, qb) for qb in QBS] if LMFMA else [])
+K_FRAGS = [(NSX * kb + sx, t) for sx in range(NSX) for kb in (0, 1) for t in (0, 1)]  # sx = 0 fragments first
 
 
 def step(variant):
@@ -556,7 +574,7 @@ def step(variant):
     for g, op in zip(DMA_GAPS, dma_ops(kbuf_stage, vbuf_stage, st=variant)):
         post[g].append(op)
     for f, (db, t) in enumerate([(db, t) for db in range(ND) for t in (0, 1)]):
-        post[NG // 2 + f // 2].append(v_read(vbuf_cur, db, t))
+        post[NG // 2 + f * (NG - NG // 2) // (2 * ND)].append(v_read(vbuf_cur, db, t))
     distribute(softmax_stream(cur, list(range(XPAIRS, 16))), post, int(opt_val("smstart", "0")))
     for t in range(NG):
         out.append(mf[t])
@@ -568,7 +586,7 @@ def step(variant):
     post = [[] for _ in range(NG2)]
     mf = []
     for t, (db, qb) in enumerate(PV_ORDER):
-        if qb == 0 and db < 4:
+        if qb == 0 and db != ROWSUM:
             pre[t].append(("WAIT", ("v", db, 1)))
         mf.append(mfma_pv(cur, db, qb))
         if "klate" in OPT:
@@ -645,8 +663,11 @@ def prologue():
         emit(f"v_readfirstlane_b32 {s(S_NEGC8)}, {v(T[1])}")
         emit(f"s_mov_b32 {s(S_M8)}, 0x{float_bits(-8.0):08x}")
     emit(f"s_sub_u32 {s(S_NM1)}, {s(S_NTILES)}, 1")
-    emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, {10 + NSX - 1}")          # 2 KiB of every 8 KiB tile per wave (head_dim 64: 1 KiB of 4)
+    emit(f"s_lshl_b32 {s(S_DMAW)}, {s(S_WAVE)}, {10 + PIECES_K.bit_length() - 1}")          # 2 KiB of every 8 KiB tile per wave (head_dim 64: 1 KiB of 4; 192 / 256: 4 of 16)
     emit(f"s_add_u32 {s(S_DMAW)}, {s(S_DMAW)}, {s(S_LDS)}")
+    if S_DMAWV != S_DMAW:                                     # head_dim 192: the prepared V^T tile is 12 KiB, 3 pieces per wave
+        emit(f"s_mul_i32 {s(S_DMAWV)}, {s(S_WAVE)}, {1024 * PIECES_V}")
+        emit(f"s_add_u32 {s(S_DMAWV)}, {s(S_DMAWV)}, {s(S_LDS)}")
     emit(f"s_mov_b32 {s(S_I)}, 0")
     emit(f"s_mov_b32 {s(S_RESC)}, 0")
     emit(f"v_mov_b32 {v(NEGINF)}, 0xff800000")
@@ -659,12 +680,16 @@ def prologue():
     emit(f"v_lshrrev_b32 {v(T[0])}, 5, {v(LANE)}")            # hh
     emit(f"v_lshlrev_b32 {v(HH4)}, 2, {v(T[0])}")
     emit(f"v_and_b32 {v(T[1])}, 31, {v(LANE)}")               # l31
-    # K fragment addresses: lds + l31*128 + (((4 sx + 2 t + hh) ^ ((l31 >> 1) & 7)) << 4)
-    emit(f"v_lshrrev_b32 {v(T[2])}, 1, {v(T[1])}")
-    emit(f"v_and_b32 {v(T[2])}, 7, {v(T[2])}")                # k swizzle
-    emit(f"v_lshlrev_b32 {v(T[3])}, 7, {v(T[1])}")
+    # K fragment addresses: lds + l31*128 + (((4 sx + 2 t + hh) ^ ((l31 >> 1) & 7)) << 4); WIDE: lds + l31*256 + (((4 sx + 2 t + hh) ^ (l31 & 15)) << 4)
+    if WIDE:
+        emit(f"v_and_b32 {v(T[2])}, 15, {v(T[1])}")
+        emit(f"v_lshlrev_b32 {v(T[3])}, 8, {v(T[1])}")
+    else:
+        emit(f"v_lshrrev_b32 {v(T[2])}, 1, {v(T[1])}")
+        emit(f"v_and_b32 {v(T[2])}, 7, {v(T[2])}")                # k swizzle
+        emit(f"v_lshlrev_b32 {v(T[3])}, 7, {v(T[1])}")
     emit(f"v_add_u32 {v(T[3])}, {s(S_LDS)}, {v(T[3])}")
-    for sx in (0, 1):
+    for sx in (range(NSX) if WIDE else (0, 1)):
         for t in (0, 1):
             emit(f"v_add_u32 {v(T[4])}, {4 * sx + 2 * t}, {v(T[0])}")
             emit(f"v_xor_b32 {v(T[4])}, {v(T[4])}, {v(T[2])}")
@@ -679,8 +704,23 @@ def prologue():
         emit(f"v_xor_b32 {v(T[4])}, {v(T[4])}, {v(T[2])}")
         emit(f"v_lshl_add_u32 {v(VADDR[t])}, {v(T[4])}, 4, {v(T[3])}")
     # DMA lane offsets. K piece j of this wave: rows 16 w + 8 j + rip (rip = lane >> 3), source chunk cpos ^ ((row >> 1) & 7)
-    emit(f"v_lshrrev_b32 {v(T[6])}, 3, {v(LANE)}")            # rip
-    emit(f"v_and_b32 {v(T[7])}, 7, {v(LANE)}")                # cpos
+    emit(f"v_lshrrev_b32 {v(T[6])}, {4 if WIDE else 3}, {v(LANE)}")            # rip
+    emit(f"v_and_b32 {v(T[7])}, {15 if WIDE else 7}, {v(LANE)}")                # cpos
+    if WIDE:
+        # four pieces per wave: piece j = rows 16 w + 4 j + rip (rip = lane >> 4) of 16 chunks; LDS chunk cpos holds source chunk cpos ^ (row & 15)
+        # = cpos ^ (4 j + rip). head_dim 192: source chunks 12..15 do not exist - clamped to 11 (filler: positions no fragment read touches)
+        emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 4")
+        for j in range(4):
+            emit(f"v_add_u32 {v(T[4])}, {4 * j}, {v(T[6])}")              # row & 15
+            emit(f"v_xor_b32 {v(T[5])}, {v(T[4])}, {v(T[7])}")            # source chunk
+            if D == 192:
+                emit(f"v_min_u32 {v(T[5])}, 11, {v(T[5])}")
+            emit(f"v_add_u32 {v(T[4])}, {s(S_T0)}, {v(T[4])}")            # row
+            emit(f"v_min_i32 {v(T[4])}, {v(T[4])}, {s(S_LASTROW)}")       # seqlen_k < 64: rows of the only tile stay inside K
+            emit(f"v_mul_lo_u32 {v(LK[j])}, {v(T[4])}, {s(S_KRS)}")
+            emit(f"v_lshl_add_u32 {v(LK[j])}, {v(T[5])}, 4, {v(LK[j])}")
+            if j < 3:
+                emit(f"v_add_u32 {v(LK[j])}, {1024 * (3 - j)}, {v(LK[j])}")   # +3072 - 1024 j; S_KBASE carries -3072
     if D == 64:
         # one piece per wave: pseudo-row R = 8 w + rip, LDS chunk cpos holds source chunk cs = cpos ^ ((R >> 1) & 7) = chunk cs & 3 of key R + 32 (cs >> 2)
         emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 3")
@@ -708,15 +748,18 @@ def prologue():
         emit(f"v_lshl_add_u32 {v(LK[j])}, {v(T[5])}, 4, {v(LK[j])}")
         if not j:
             emit(f"v_add_u32 {v(LK[j])}, 1024, {v(LK[j])}")            # +1024 - 1024 j; S_KBASE carries -1024
-    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, {10 + NSX - 1}")
-    emit(f"v_lshl_add_u32 {v(LV)}, {v(LANE)}, 4, {s(S_T0)}")  # 2048 w + 16 lane (head_dim 64: 1024 w): linear copy of the prepared tile
+    if WIDE:
+        emit(f"s_mul_i32 {s(S_T0)}, {s(S_WAVE)}, {1024 * PIECES_V}")
+    else:
+        emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, {10 + NSX - 1}")
+    emit(f"v_lshl_add_u32 {v(LV)}, {v(LANE)}, 4, {s(S_T0)}")  # 2048 w + 16 lane (head_dim 64: 1024 w; 192 / 256: 3072 / 4096 w): linear copy of the prepared tile
 
     emit("; ---- Q fragments -> AGPRs: row q_row0 + 64 w + 32 qb + l31, d = 64 sx + 32 t + 16 hh + [0,16); rows past seqlen_q are ZERO")
-    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 6")
+    emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, {5 + NQB - 1}")      # 64 rows per wave (one q-block: 32)
     emit(f"s_add_u32 {s(S_T0)}, {s(S_T0)}, {s(S_QROW0)}")
     emit(f"s_sub_u32 {s(S_T1)}, {s(S_SEQLENQ)}, 1")
     emit(f"v_lshlrev_b32 {v(T[6])}, 4, {v(T[0])}")            # hh * 16 bytes
-    for qb in (0, 1):
+    for qb in QBS:
         emit(f"v_add_u32 {v(QROW[qb])}, {s(S_T0)}, {v(T[1])}")
         if qb:
             emit(f"v_add_u32 {v(QROW[qb])}, 32, {v(QROW[qb])}")
@@ -731,17 +774,17 @@ def prologue():
             for t in (0, 1):
                 emit(f"global_load_dwordx4 {vr(16 * qb + 8 * sx + 4 * t, 4)}, {vr(T[4], 2)}, off offset:{64 * sx + 32 * t}")
     emit("s_waitcnt vmcnt(0)")
-    for qb in (0, 1):
+    for qb in QBS:
         emit(f"v_cmp_gt_i32 vcc, {s(S_SEQLENQ)}, {v(QROW[qb])}")
         for r in range(8 * NSX):
             emit(f"v_cndmask_b32 {v(16 * qb + r)}, 0, {v(16 * qb + r)}, vcc")
-    for qb in (0, 1):
+    for qb in QBS:
         for r in range(8 * NSX):
             emit(f"v_accvgpr_write_b32 a{128 + 16 * qb + r}, {v(16 * qb + r)}")
     emit("; ---- state")
-    for r in list(range(128)) + (list(range(LSUM(0), LSUM(1) + 16)) if LMFMA else []):
+    for r in list(range(128)) + (list(range(LSUM(0), LSUM(NQB - 1) + 16)) if LMFMA else []):
         emit(f"v_accvgpr_write_b32 a{r}, 0")
-    for qb in (0, 1):
+    for qb in QBS:
         emit(f"v_mov_b32 {v(MTRUE[qb])}, 0xff800000")
         if not LMFMA:
             emit(f"v_mov_b32 {v(L0[qb])}, 0")
@@ -784,20 +827,20 @@ def prologue():
             key = 32 * kb + (r & 3) + 8 * (r >> 2)
             emit(f"v_add_u32 {v(T[0])}, {key}, {v(HH4)}")
             emit(f"v_cmp_gt_i32 vcc, {s(S_TAILVALID)}, {v(T[0])}")
-            for qb in (0, 1):
+            for qb in QBS:
                 emit(f"v_cndmask_b32 {v(S_(0, qb, kb) + r)}, {v(NEGINF)}, {v(S_(0, qb, kb) + r)}, vcc")
     label(nomask)
     for op in row_max_ops(0):
         out.append(op)
-    emit(f"v_mov_b32 {v(T[0])}, {v(MLOC[0])}")
-    emit(f"v_mov_b32 {v(T[1])}, {v(MLOC[1])}")
+    for qb in QBS:
+        emit(f"v_mov_b32 {v(T[qb])}, {v(MLOC[qb])}")
     emit("s_nop 1")
-    emit(f"v_permlane32_swap_b32 {v(MLOC[0])}, {v(T[0])}")
-    emit(f"v_permlane32_swap_b32 {v(MLOC[1])}, {v(T[1])}")
+    for qb in QBS:
+        emit(f"v_permlane32_swap_b32 {v(MLOC[qb])}, {v(T[qb])}")
     emit("s_nop 1")
-    for qb in (0, 1):
+    for qb in QBS:
         emit(f"v_max_f32 {v(MTRUE[qb])}, {v(MLOC[qb])}, {v(T[qb])}")
-    for qb in (0, 1):
+    for qb in QBS:
         emit(f"v_mov_b32 {v(MREF[qb])}, {v(MTRUE[qb])}")
         set_nms(qb)
         emit(f"v_add_f32 {v(MTHR[qb])}, {s(S_TAU)}, {v(MTRUE[qb])}")
@@ -824,7 +867,7 @@ def epilogue():
     emit("s_nop 15")
     emit("s_nop 15")
     if LMFMA:
-        globals()["LSUM_AGPR"] = [LSUM(0), LSUM(1)]            # l~ of the lane's row: register 0 of the row-sum accumulators
+        globals()["LSUM_AGPR"] = [LSUM(qb) for qb in QBS]      # l~ of the lane's row: register 0 of the row-sum accumulators
     store_epilogue(globals(), O_)                              # gen_epilogue.py: v_descale / l, bf16 O and LSE from the registers
     emit("s_waitcnt lgkmcnt(0)")
 
@@ -861,9 +904,10 @@ def main():
     mode = 2 if not LMFMA else (0 if LIN else 1)               # PMODE of the shell (la_fwd_kernel_x64_fp8.hip)
     # the three bodies of the build are told apart by their FILE NAME in the shell's includes: a body generated under options that belong to
     # another name (e.g. a global LA_X64F8_OPT in the environment of a default build) must fail here, not at link time
-    by_name = 1 if path.endswith("_exp_body.inc") else (2 if path.endswith("_lvalu_body.inc") else (0 if path.endswith(("la_fwd_x64_fp8_body.inc", "la_fwd_x64_fp8_d64_body.inc")) else mode))
-    if ("_d64_" in os.path.basename(path)) != (D == 64):
-        raise SystemExit(f"{path}: generated for head_dim {D} (LA_X64F8_D) but named like the other head dim's body")
+    by_name = 1 if path.endswith("_exp_body.inc") else (2 if path.endswith("_lvalu_body.inc") else (0 if path.endswith(("la_fwd_x64_fp8_body.inc", "la_fwd_x64_fp8_d64_body.inc", "la_fwd_x64_fp8_d192_body.inc", "la_fwd_x64_fp8_d256_body.inc")) else mode))
+    tag = "" if D == 128 else f"_d{D}_"
+    if tag not in os.path.basename(path) or (D == 128 and any(f"_d{d}_" in os.path.basename(path) for d in (64, 192, 256))):
+        raise SystemExit(f"{path}: generated for head_dim {D} (LA_X64F8_D) but named like another head dim's body")
     if by_name != mode:
         raise SystemExit(f"{path}: generated with the options of P mode {mode} (LA_X64F8_OPT={os.environ.get('LA_X64F8_OPT', '')!r}) "
                          f"but named like the body of P mode {by_name}")

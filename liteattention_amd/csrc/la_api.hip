@@ -61,7 +61,7 @@ DenseSplit dense_split(int k_tiles, int head_dim, int64_t batch, int64_t seqlen_
     return d;
 }
 // e4m3 above head_dim 128: the bf16 form of the same arguments over up-converted operands in the workspace (la_prep_fp8.hip)
-bool fp8_on_bf16_kernel(const la_fwd_args* a) { return a->dtype == LA_DTYPE_FP8_E4M3 && (a->head_dim == 192 || a->head_dim == 256); }
+bool fp8_on_bf16_kernel(const la_fwd_args* a) { (void)a; return false; }
 struct Fp8Upconvert { uint64_t q_bytes, k_bytes, v_bytes; int64_t q_rows, k_rows; };       // rows: per batch, or the packed bound
 Fp8Upconvert fp8_upconvert_layout(const la_fwd_args* a) {
     Fp8Upconvert u{};
@@ -119,7 +119,7 @@ const char* la_status_string(int status) {
         case LA_ERR_STRIDE: return "Input tensor must have contiguous last dimension and 16-byte aligned rows";
         case LA_ERR_TILE_MISMATCH: return "block_m/block_n do not match la_get_tile_sizes(): skip lists would be mis-indexed";
         case LA_ERR_LISTS: return "attn_read_list and attn_write_list must be given together";
-        case LA_ERR_UNSUPPORTED: return "feature outside the QK-Skip hot path (head_dim_v != head_dim, unknown flags, skip lists with cu_seqlens on the 128-row kernels or above head_dim 128)";
+        case LA_ERR_UNSUPPORTED: return "feature outside the QK-Skip hot path (head_dim_v != head_dim, unknown flags, skip lists with cu_seqlens on the 128-row kernels or, for bf16 / fp16, above head_dim 128)";
         case LA_ERR_LAUNCH: return "HIP kernel launch failed (see la_last_hip_error)";
         case LA_ERR_SEQLEN: return "seqlen_k too long: the expanded skip list does not fit in LDS (dense bf16 / fp16 launches are cut into runs and merged when the workspace of la_fwd_workspace_bytes() is given)";
         case LA_ERR_WORKSPACE: return "fp8 needs a 16-byte aligned workspace of la_fwd_workspace_bytes() bytes";
@@ -242,8 +242,8 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     const bool varlen = a->cu_seqlens_q != nullptr || a->cu_seqlens_k != nullptr;
     if (varlen) {                                                                        // flash_api.cpp:736-760
         if (a->cu_seqlens_q == nullptr || a->cu_seqlens_k == nullptr) return LA_ERR_NULL_ARG;
-        if (a->read_list != nullptr && ((a->flags & LA_FLAG_KERNEL_128ROW) || a->head_dim > 128))
-            return LA_ERR_UNSUPPORTED;                                                    // lists + cu_seqlens: the hand-scheduled kernels, head_dim <= 128
+        if (a->read_list != nullptr && ((a->flags & LA_FLAG_KERNEL_128ROW) || (a->head_dim > 128 && !fp8)))
+            return LA_ERR_UNSUPPORTED;                                                    // lists + cu_seqlens: the hand-scheduled kernels, head_dim <= 128 (e4m3: every head dim)
         if (a->total_q < 0 || a->q_tile_count != 0) return LA_ERR_SHAPE;
     }
     if (a->seqlen_k == 0) {
@@ -319,7 +319,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     if (static_cast<int64_t>(p.batch) * p.num_heads * p.q_tiles > 0x7fffffffLL) return LA_ERR_SHAPE;
 
     if (fp8) {
-        if (la::fwd_lds_bytes_x64_fp8(p.k_tiles, nullptr) > 160 * 1024) return LA_ERR_SEQLEN;
+        if (la::fwd_lds_bytes_x64_fp8(p.k_tiles, nullptr, nullptr, a->head_dim) > 160 * 1024) return LA_ERR_SEQLEN;
         // 1) V -> pre-transposed, pre-swizzled V^T tiles in the caller's workspace; 2) forward on (Q, K, V^T)
         hipError_t e8 = hipSuccess;
         if (!(a->flags & LA_FLAG_V_PREPARED))

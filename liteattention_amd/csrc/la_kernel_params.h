@@ -89,7 +89,7 @@ hipError_t launch_fwd_bf16_v2(const FwdParams& p, int head_dim, bool skipable, b
 size_t fwd_lds_bytes_x64(int k_tiles, int* seq_cap_out, int head_dim, int* walk_buffers_out = nullptr, bool half_vote = false);
 int x64_workgroups_per_cu(int head_dim);      // resident workgroups per CU of the hand-scheduled kernels: 1
 hipError_t launch_fwd_x64(const FwdParams& p, int head_dim, bool skipable, bool f16, hipStream_t stream);  // p.half_vote: the half-vote form (head_dim 128, lists only)  // 1 wave/SIMD; head_dim 128: 64 rows/wave, q-tile 256; 256: 32 rows/wave, q-tile 128
-size_t fwd_lds_bytes_x64_fp8(int k_tiles, int* seq_cap_out, int* walk_buffers_out = nullptr);
+size_t fwd_lds_bytes_x64_fp8(int k_tiles, int* seq_cap_out, int* walk_buffers_out = nullptr, int head_dim = 128);
 hipError_t launch_fwd_x64_fp8(const FwdParams& p, bool skipable, int p_mode, int head_dim, hipStream_t stream);   // 1 wave/SIMD, 64 rows/wave; p.v = V^T workspace
 size_t fp8_workspace_bytes(int batch, int num_heads_k, int k_tiles, int head_dim);   // prepared V^T tiles: 64 keys x head_dim bytes each
 hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_row_stride, int64_t v_head_stride,

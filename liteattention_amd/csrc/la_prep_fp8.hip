@@ -26,7 +26,7 @@ __device__ __forceinline__ constexpr int f8_v_swz(int row) { return (row >> 2) &
 
 // ------------------------------------------------------------------------------------------------
 // Prepare kernel: V (B,Sk,H,D) e4m3 -> V^T tiles [B,H,Kt][D][64] (key order and swizzle as above), D = 128 or 64 (a head_dim-64 tile is
-// the first 64 rows of what a head_dim-128 tile would be: 4 KiB).
+// the first 64 rows of what a head_dim-128 tile would be: 4 KiB; 192 / 256: 12 / 16 KiB).
 // One workgroup per (b, h, k-tile); rows past seqlen_k become zeros (P is 0 there anyway).
 // Packed variable-length batches (cu_seqlens_k != nullptr): v is (total_k, H, 128), sequence b owns rows [cu[b], cu[b + 1]) and its
 // tiles are written to the same [B, H, Kt] grid (Kt = tiles of the longest sequence; the tiles past a sequence's end are zeros).
@@ -89,7 +89,15 @@ hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_ro
                              void* vt, int batch, int seqlen_k, int num_heads, int k_tiles, int head_dim, hipStream_t stream,
                              const int* cu_seqlens_k) {
     (void)hipGetLastError();
-    if (head_dim == 64)
+    if (head_dim == 256)
+        hipLaunchKernelGGL(la_prep_v_fp8_kernel<256>, dim3(batch * num_heads * k_tiles), dim3(256), 0, stream,
+                           static_cast<const uint8_t*>(v), v_batch_stride, v_row_stride, v_head_stride,
+                           static_cast<uint8_t*>(vt), seqlen_k, num_heads, k_tiles, cu_seqlens_k);
+    else if (head_dim == 192)
+        hipLaunchKernelGGL(la_prep_v_fp8_kernel<192>, dim3(batch * num_heads * k_tiles), dim3(256), 0, stream,
+                           static_cast<const uint8_t*>(v), v_batch_stride, v_row_stride, v_head_stride,
+                           static_cast<uint8_t*>(vt), seqlen_k, num_heads, k_tiles, cu_seqlens_k);
+    else if (head_dim == 64)
         hipLaunchKernelGGL(la_prep_v_fp8_kernel<64>, dim3(batch * num_heads * k_tiles), dim3(256), 0, stream,
                            static_cast<const uint8_t*>(v), v_batch_stride, v_row_stride, v_head_stride,
                            static_cast<uint8_t*>(vt), seqlen_k, num_heads, k_tiles, cu_seqlens_k);

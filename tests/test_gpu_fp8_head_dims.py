@@ -1,12 +1,13 @@
-"""GPU: the native head_dim-64 fp8 (e4m3) body (round 6; gen_fwd_x64_fp8.py under LA_X64F8_D=64, la_fwd_kernel_x64_fp8.hip <.., .., 64>).
+"""GPU: the native fp8 (e4m3) bodies at head dims 64, 192 and 256 (round 6; gen_fwd_x64_fp8.py under LA_X64F8_D, la_fwd_kernel_x64_fp8.hip).
 
-Until round 5 e4m3 at head dims <= 64 ran zero-padded on the head_dim-128 body. The native body does one 64-wide contraction per score
-block and two d-blocks of O^T; every fp32 operation on a real column is the one the padded form does (a zero product adds exactly 0 to a
-score; d-blocks of O^T are independent), so the two must agree BIT FOR BIT - O, LSE and the written lists, in all three forms of P. That
-is the first test; the others hold the body against the oracle directly (ragged shapes, lists over steps with descales and GQA, the
-lazy-rescale path, smaller head dims served by this body) as tests/test_gpu_fp8.py does at 128; packed variable-length batches at 64:
-tests/test_gpu_varlen_lists.py. The
-reference-generated golden `fp8_sq130_sk517_h2_d64` runs in test_gpu_fp8.py::test_fp8_dense_matches_reference_outputs."""
+Until round 5 e4m3 at head dims <= 64 ran zero-padded on the head_dim-128 body, and above 128 on the bf16 kernels over up-converted operands.
+The native 64 body does one 64-wide contraction per score block and two d-blocks of O^T; the 192 / 256 bodies hold ONE 32-row q-block per wave
+(q-tile 128) with 3 / 4 contraction steps and 6 / 8 d-blocks. Every fp32 operation on a real column is the one the next instantiated size does on
+zero-padded operands (a zero product adds exactly 0 to a score; d-blocks of O^T are independent), so 64 must agree with the padded 128 form and 192
+with the padded 256 form BIT FOR BIT - O, LSE and the written lists, in all three forms of P. Those are the first tests; the others hold the bodies
+against the oracle directly (ragged shapes, lists over steps with descales and GQA, the lazy-rescale path, head dims served by padding onto these
+bodies) as tests/test_gpu_fp8.py does at 128; packed variable-length batches: tests/test_gpu_varlen_lists.py. The reference-generated golden
+`fp8_sq130_sk517_h2_d64` runs in test_gpu_fp8.py::test_fp8_dense_matches_reference_outputs."""
 import pytest
 import torch
 
@@ -14,7 +15,8 @@ from helpers import fp8_lse_tol, fp8_p_round, structured_qkv
 
 pytestmark = pytest.mark.gpu
 F8 = torch.float8_e4m3fn
-D = 64
+DIMS = [64, 192, 256]
+PADDED = {64: 128, 192: 256}            # head dim -> the next instantiated size its zero-padded form runs on
 
 
 @pytest.fixture(params=["encoded", "exp", "exact"], autouse=True)
@@ -28,7 +30,7 @@ def p_mode(request, monkeypatch):
     return request.param
 
 
-def _tiles():
+def _tiles(D):
     import liteattention_amd as L
     return L.get_tile_sizes(D, 1)
 
@@ -37,20 +39,22 @@ def _tol(o):
     return 0.05 * o.abs().max().item() + 2e-2
 
 
-def _pad128(t):
-    return torch.nn.functional.pad(t.view(torch.uint8), (0, 128 - t.shape[-1])).view(F8)
+def _pad(t, to):
+    return torch.nn.functional.pad(t.view(torch.uint8), (0, to - t.shape[-1])).view(F8)
 
 
-def test_the_library_serves_head_dim_64_natively():
+def test_the_library_serves_these_head_dims_natively():
     import liteattention_amd as L
     from liteattention_amd import _cabi
     from liteattention_amd.flash_attn_interface import kernel_head_dim
-    assert _cabi.is_instantiated(64, 1, 0) and kernel_head_dim(64, 1) == 64 and kernel_head_dim(48, 1) == 64 and kernel_head_dim(80, 1) == 128
-    assert L.get_tile_sizes(64, 1) == (256, 64)
+    assert all(_cabi.is_instantiated(d, 1, 0) for d in (64, 128, 192, 256))
+    assert [kernel_head_dim(d, 1) for d in (48, 64, 80, 128, 144, 192, 208, 256)] == [64, 64, 128, 128, 192, 192, 256, 256]
+    assert L.get_tile_sizes(64, 1) == (256, 64) and L.get_tile_sizes(192, 1) == L.get_tile_sizes(256, 1) == (128, 64)
 
 
+@pytest.mark.parametrize("D", sorted(PADDED))
 @pytest.mark.parametrize("shape", [(2, 300, 4, 2, 1000), (1, 17, 1, 1, 17), (1, 700, 2, 2, 4224)])
-def test_native_64_equals_the_zero_padded_128_body_bit_for_bit_dense(shape):
+def test_native_body_equals_the_zero_padded_next_size_bit_for_bit_dense(shape, D):
     import liteattention_amd as L
     B, Sq, H, Hk, Sk = shape
     g = torch.Generator().manual_seed(Sq + Sk)
@@ -58,34 +62,37 @@ def test_native_64_equals_the_zero_padded_128_body_bit_for_bit_dense(shape):
                torch.randn(B, Sk, Hk, D, generator=g).to(F8).cuda())
     qd, kd, vd = [(0.5 + torch.rand(B, Hk, generator=g)).cuda() for _ in range(3)]
     out, lse = L.flash_attn_func(q, k, v, q_descale=qd, k_descale=kd, v_descale=vd, return_softmax_lse=True)
-    out_p, lse_p = L.flash_attn_func(_pad128(q), _pad128(k), _pad128(v), softmax_scale=D ** -0.5, q_descale=qd, k_descale=kd, v_descale=vd,
+    P = PADDED[D]
+    out_p, lse_p = L.flash_attn_func(_pad(q, P), _pad(k, P), _pad(v, P), softmax_scale=D ** -0.5, q_descale=qd, k_descale=kd, v_descale=vd,
                                      return_softmax_lse=True)
     assert out.shape == (B, Sq, H, D) and bool(torch.isfinite(out.float()).all())
     assert torch.equal(out, out_p[..., :D]) and torch.equal(lse, lse_p)
     assert not out_p[..., D:].any()
 
 
-def test_native_64_equals_the_zero_padded_128_body_bit_for_bit_lists():
+@pytest.mark.parametrize("D", sorted(PADDED))
+def test_native_body_equals_the_zero_padded_next_size_bit_for_bit_lists(D):
     """Three steps of lists on two LiteAttention objects (native / padded inputs): O, LSE and both lists equal after every step."""
     import liteattention_amd as L
-    B, S, H, thr = 1, 2304, 3, -3.0
+    B, S, H, thr, P = 1, 2304, 3, -3.0, PADDED[D]
     a64, a128 = L.LiteAttention(threshold=thr, max_batch_size=B), L.LiteAttention(threshold=thr, max_batch_size=B)
     listed = []
     for step in range(3):
         q, k, v = [x.to(F8).cuda() for x in structured_qkv(B, S, H, D, seed=640 + step, alpha=9.0, dtype=torch.float32)]
         out, lse = a64(q, k, v, return_softmax_lse=True)
-        out_p, lse_p = a128(_pad128(q), _pad128(k), _pad128(v), scale=D ** -0.5, return_softmax_lse=True)
+        out_p, lse_p = a128(_pad(q, P), _pad(k, P), _pad(v, P), scale=D ** -0.5, return_softmax_lse=True)
         assert torch.equal(out, out_p[..., :D]) and torch.equal(lse, lse_p)
         for i in (0, 1):
             assert torch.equal(a64._skip_list[i], a128._skip_list[i])
         from oracle import oracle as orc
         listed.append(orc.listed_tiles(a64._skip_list[a64._phase][:B].cpu()))
-    Qt, Kt = -(-S // _tiles()[0]), -(-S // _tiles()[1])
+    Qt, Kt = -(-S // _tiles(D)[0]), -(-S // _tiles(D)[1])
     assert listed[-1] < 0.95 * B * H * Qt * Kt
 
 
 @pytest.mark.parametrize("shape", [(1, 17, 1, 17, 64), (2, 129, 3, 65, 64), (1, 1000, 2, 1250, 64), (1, 128, 1, 4224, 64), (1, 300, 2, 700, 48),
-                                   (1, 260, 2, 130, 32), (1, 70, 1, 333, 16)])
+                                   (1, 260, 2, 130, 32), (1, 70, 1, 333, 16), (1, 17, 1, 17, 256), (2, 129, 3, 65, 192), (1, 1000, 2, 1250, 256),
+                                   (1, 128, 1, 4224, 192), (1, 300, 2, 700, 160), (1, 260, 2, 130, 224)])
 def test_ragged_shapes_against_the_oracle(shape):
     import liteattention_amd as L
     from oracle import oracle as orc
@@ -100,11 +107,12 @@ def test_ragged_shapes_against_the_oracle(shape):
     assert (lse.cpu() - lse8).abs().max().item() <= fp8_lse_tol()
 
 
-def test_skip_lists_match_the_oracle_over_steps_with_descales_and_gqa():
+@pytest.mark.parametrize("D", DIMS)
+def test_skip_lists_match_the_oracle_over_steps_with_descales_and_gqa(D):
     import liteattention_amd as L
     from oracle import oracle as orc
     from test_gpu_parity import _compare_lists
-    bm, bn = _tiles()
+    bm, bn = _tiles(D)
     B, S, H, Hk, thr = 1, 2560, 4, 2, -3.0           # 40 key tiles: the vote words wrap (32 bits per word)
     Qt, Kt = S // bm, S // bn
     att = L.LiteAttention(threshold=thr, max_batch_size=B)
@@ -129,12 +137,13 @@ def test_skip_lists_match_the_oracle_over_steps_with_descales_and_gqa():
     assert listed[-1] < 0.95 * B * H * Qt * Kt and listed == sorted(listed, reverse=True)
 
 
-def test_running_max_that_grows_late_in_the_walk():
-    """The O^T rescale round trip of the head_dim-64 body (two d-blocks per q-block): tests/test_gpu_fp8.py, gain 8."""
+@pytest.mark.parametrize("D", DIMS)
+def test_running_max_that_grows_late_in_the_walk(D):
+    """The O^T rescale round trip of these bodies (2 / 6 / 8 d-blocks per q-block): tests/test_gpu_fp8.py, gain 8."""
     import liteattention_amd as L
     from oracle import oracle as orc
     from test_gpu_parity import _compare_lists
-    bm, bn = _tiles()
+    bm, bn = _tiles(D)
     B, S, H = 1, 1536, 2
     g = torch.Generator().manual_seed(93)
     q, k, v = [torch.randn(B, S, H, D, generator=g) for _ in range(3)]
@@ -161,8 +170,9 @@ def test_running_max_that_grows_late_in_the_walk():
         assert bad == 0
 
 
-def test_static_map_equals_the_ticket_queues_and_q_windows_compose():
-    """Raw mha_fwd at head_dim 64: the static one-workgroup-per-item map and two q-tile windows give the results of the default launch."""
+@pytest.mark.parametrize("D", DIMS)
+def test_static_map_equals_the_ticket_queues_and_q_windows_compose(D):
+    """Raw mha_fwd: the static one-workgroup-per-item map and two q-tile windows give the results of the default launch."""
     from liteattention_amd.flash_attn_interface import mha_fwd
     g = torch.Generator().manual_seed(5)
     B, S, H = 2, 1100, 3
@@ -170,6 +180,6 @@ def test_static_map_equals_the_ticket_queues_and_q_windows_compose():
     ref = mha_fwd(q, k, v)
     st = mha_fwd(q, k, v, _static_sched=True)
     assert torch.equal(ref[0], st[0]) and torch.equal(ref[1], st[1])
-    Qt = -(-S // _tiles()[0])
+    Qt = -(-S // _tiles(D)[0])
     win = mha_fwd(q, k, v, _q_windows=[(0, 2), (2, Qt - 2)])
     assert torch.equal(ref[0], win[0]) and torch.equal(ref[1], win[1])
