@@ -45,7 +45,7 @@ def opt_val(key, default):
 
 # Options that only move instructions or select one of the three product bodies (exp / lvalu): same results bit for bit as the body of
 # that name. Everything else is a pricing experiment; the first line of a generated body says which kind went in (see gen_fwd_x64.py).
-SCHEDULE_ONLY = {"x", "dmagaps", "align", "pad4", "smstart", "klate", "pk", "exp", "lvalu"}
+SCHEDULE_ONLY = {"x", "dmagaps", "align", "pad4", "smstart", "klate", "pk", "exp", "lvalu", "vspread"}
 
 
 def option_tag():
@@ -574,7 +574,8 @@ def step(variant):
     for g, op in zip(DMA_GAPS, dma_ops(kbuf_stage, vbuf_stage, st=variant)):
         post[g].append(op)
     for f, (db, t) in enumerate([(db, t) for db in range(ND) for t in (0, 1)]):
-        post[NG // 2 + f * (NG - NG // 2) // (2 * ND)].append(v_read(vbuf_cur, db, t))
+        v0 = 0 if "vspread" in OPT else NG // 2          # vspread (A/B): the V^T fragment reads over the whole of phase 1 instead of its second half
+        post[v0 + f * (NG - v0) // (2 * ND)].append(v_read(vbuf_cur, db, t))
     distribute(softmax_stream(cur, list(range(XPAIRS, 16))), post, int(opt_val("smstart", "0")))
     for t in range(NG):
         out.append(mf[t])

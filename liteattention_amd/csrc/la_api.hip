@@ -60,37 +60,6 @@ DenseSplit dense_split(int k_tiles, int head_dim, int64_t batch, int64_t seqlen_
                                                                                 // multiple of 16 bytes, head_dim_v % 8 == 0 - come first, so every O partial is 16-byte aligned)
     return d;
 }
-// e4m3 above head_dim 128: the bf16 form of the same arguments over up-converted operands in the workspace (la_prep_fp8.hip)
-bool fp8_on_bf16_kernel(const la_fwd_args* a) { (void)a; return false; }
-struct Fp8Upconvert { uint64_t q_bytes, k_bytes, v_bytes; int64_t q_rows, k_rows; };       // rows: per batch, or the packed bound
-Fp8Upconvert fp8_upconvert_layout(const la_fwd_args* a) {
-    Fp8Upconvert u{};
-    const bool varlen = a->cu_seqlens_q != nullptr;
-    u.q_rows = varlen ? a->total_q : a->seqlen_q;
-    u.k_rows = varlen ? static_cast<int64_t>(a->batch) * a->seqlen_k : a->seqlen_k;      // packed K / V: at most batch * max_seqlen_k rows (the kernel stops at cu_seqlens_k[batch])
-    const uint64_t nb = varlen ? 1 : static_cast<uint64_t>(a->batch);
-    u.q_bytes = (nb * u.q_rows * a->num_heads * a->head_dim * 2 + 15) & ~15ull;
-    u.k_bytes = (nb * u.k_rows * a->num_heads_k * a->head_dim * 2 + 15) & ~15ull;
-    u.v_bytes = u.k_bytes;
-    return u;
-}
-la_fwd_args bf16_form_of(const la_fwd_args* a, const Fp8Upconvert& u, unsigned char* ws) {
-    la_fwd_args b = *a;
-    const bool varlen = a->cu_seqlens_q != nullptr;
-    b.dtype = LA_DTYPE_BF16;
-    b.q = ws; b.k = ws + u.q_bytes; b.v = ws + u.q_bytes + u.k_bytes;
-    b.q_head_stride = b.k_head_stride = b.v_head_stride = a->head_dim;
-    b.q_row_stride = static_cast<int64_t>(a->num_heads) * a->head_dim;
-    b.k_row_stride = b.v_row_stride = static_cast<int64_t>(a->num_heads_k) * a->head_dim;
-    b.q_batch_stride = varlen ? 0 : u.q_rows * b.q_row_stride;
-    b.k_batch_stride = b.v_batch_stride = varlen ? 0 : u.k_rows * b.k_row_stride;
-    b.q_descale = b.k_descale = b.v_descale = nullptr;
-    b.flags &= ~(LA_FLAG_V_PREPARED | LA_FLAG_FP8_MFMA_ROWSUM | LA_FLAG_FP8_ENCODED_P);
-    const uint64_t used = u.q_bytes + u.k_bytes + u.v_bytes;
-    b.workspace = ws == nullptr ? nullptr : ws + used;
-    b.workspace_bytes = a->workspace_bytes > used ? a->workspace_bytes - used : 0;
-    return b;
-}
 constexpr uint64_t kSchedWorkspaceBytes = 1024;   // 16 ticket / steal counters of 64 bytes, all of them zeroed by prepare_work_queue (no slack)
 constexpr float kRescaleTauBf16 = 8.0f;           // lazy-rescale slack of the x64 kernel, log2 units (HISTORY.md section 3.1)
 }  // namespace
@@ -114,7 +83,7 @@ const char* la_status_string(int status) {
         case LA_ERR_NULL_ARG: return "required pointer is NULL";
         case LA_ERR_STRUCT_SIZE: return "la_fwd_args.struct_size mismatch (ABI version skew)";
         case LA_ERR_DTYPE: return "FlashAttention only supports fp16, bf16, and fp8_e4m3 type; this build instantiates all three";
-        case LA_ERR_HEAD_DIM: return "head_size not instantiated in this build (bf16 / fp16: 64, 96, 128, 192, 256 - under LA_FLAG_KERNEL_128ROW only 64, 128, 256; fp8: 64 and 128 natively, 192 / 256 on the bf16 kernels)";
+        case LA_ERR_HEAD_DIM: return "head_size not instantiated in this build (bf16 / fp16: 64, 96, 128, 192, 256 - under LA_FLAG_KERNEL_128ROW only 64, 128, 256; fp8: 64, 128, 192, 256)";
         case LA_ERR_SHAPE: return "invalid shape (batch, seqlen_q, heads and head_dim must be positive; number of heads in key/value must divide number of heads in query)";
         case LA_ERR_STRIDE: return "Input tensor must have contiguous last dimension and 16-byte aligned rows";
         case LA_ERR_TILE_MISMATCH: return "block_m/block_n do not match la_get_tile_sizes(): skip lists would be mis-indexed";
@@ -164,13 +133,6 @@ int64_t la_fwd_workspace_bytes(const la_fwd_args* a) {
         return need;
     }
     if (a->dtype != LA_DTYPE_FP8_E4M3) return LA_ERR_DTYPE;
-    if (fp8_on_bf16_kernel(a)) {                        // the up-converted operands, then whatever the bf16 launch wants
-        if (a->batch <= 0 || a->num_heads <= 0 || a->num_heads_k <= 0 || a->seqlen_q <= 0 || a->seqlen_k < 0) return LA_ERR_SHAPE;
-        const Fp8Upconvert u = fp8_upconvert_layout(a);
-        const la_fwd_args b = bf16_form_of(a, u, nullptr);
-        const int64_t rest = la_fwd_workspace_bytes(&b);
-        return rest < 0 ? rest : static_cast<int64_t>(u.q_bytes + u.k_bytes + u.v_bytes) + rest;
-    }
     int bm = 0, bn = 0;
     const int trc = la_get_tile_sizes_ex(a->head_dim, 1, a->flags, &bm, &bn);
     if (trc != LA_OK) return trc;
@@ -212,32 +174,6 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     if (a->k_row_stride > 0x3fffffff || a->v_row_stride > 0x3fffffff || a->o_row_stride > 0x3fffffff || a->q_row_stride > 0x3fffffff)
         return LA_ERR_STRIDE;                                                             // byte strides kept in 32 bits
     if (!aligned16(a->q) || !aligned16(a->k) || !aligned16(a->v) || !aligned16(a->o)) return LA_ERR_STRIDE;
-
-    if (fp8_on_bf16_kernel(a) && a->seqlen_k > 0) {
-        // e4m3 at head dims 192 / 256: up-convert q (x q_descale k_descale), k, v (x v_descale) into the workspace, then the bf16 launch of
-        // the same arguments (lists, windows, packed batches alike). LA_FLAG_V_PREPARED (a later q-tile window of the same call): the
-        // operands are already there.
-        if ((a->cu_seqlens_q == nullptr) != (a->cu_seqlens_k == nullptr)) return LA_ERR_NULL_ARG;
-        const Fp8Upconvert u = fp8_upconvert_layout(a);
-        if (a->workspace == nullptr || !aligned16(a->workspace) || a->workspace_bytes < u.q_bytes + u.k_bytes + u.v_bytes) return LA_ERR_WORKSPACE;
-        unsigned char* const ws = static_cast<unsigned char*>(a->workspace);
-        const la_fwd_args b = bf16_form_of(a, u, ws);
-        if (!(a->flags & LA_FLAG_V_PREPARED)) {
-            const int g = a->num_heads / a->num_heads_k;
-            hipError_t e = la::launch_upconvert_fp8(a->q, a->q_batch_stride, a->q_row_stride, a->q_head_stride, ws, a->batch, static_cast<int>(u.q_rows),
-                                                    a->num_heads, a->head_dim, a->q_descale, a->q_descale_batch_stride, a->q_descale_head_stride,
-                                                    a->k_descale, a->k_descale_batch_stride, a->k_descale_head_stride, g, a->cu_seqlens_q, stream);
-            if (e == hipSuccess)
-                e = la::launch_upconvert_fp8(a->k, a->k_batch_stride, a->k_row_stride, a->k_head_stride, ws + u.q_bytes, a->batch, static_cast<int>(u.k_rows),
-                                             a->num_heads_k, a->head_dim, nullptr, 0, 0, nullptr, 0, 0, 1, a->cu_seqlens_k, stream);
-            if (e == hipSuccess)
-                e = la::launch_upconvert_fp8(a->v, a->v_batch_stride, a->v_row_stride, a->v_head_stride, ws + u.q_bytes + u.k_bytes, a->batch,
-                                             static_cast<int>(u.k_rows), a->num_heads_k, a->head_dim, a->v_descale, a->v_descale_batch_stride,
-                                             a->v_descale_head_stride, nullptr, 0, 0, 1, a->cu_seqlens_k, stream);
-            if (e != hipSuccess) { g_last_hip_error = static_cast<int>(e); return LA_ERR_LAUNCH; }
-        }
-        return la_fwd(&b, stream_);
-    }
 
     const bool varlen = a->cu_seqlens_q != nullptr || a->cu_seqlens_k != nullptr;
     if (varlen) {                                                                        // flash_api.cpp:736-760

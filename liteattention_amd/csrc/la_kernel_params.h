@@ -95,9 +95,6 @@ size_t fp8_workspace_bytes(int batch, int num_heads_k, int k_tiles, int head_dim
 hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_row_stride, int64_t v_head_stride,
                              void* vt, int batch, int seqlen_k, int num_heads_k, int k_tiles, int head_dim, hipStream_t stream,
                              const int* cu_seqlens_k = nullptr);
-hipError_t launch_upconvert_fp8(const void* src, int64_t batch_stride, int64_t row_stride, int64_t head_stride, void* dst, int batch, int rows,
-                                int num_heads, int head_dim, const float* sa, int64_t sa_bs, int64_t sa_hs, const float* sb, int64_t sb_bs,
-                                int64_t sb_hs, int h_ratio, const int* cu_seqlens, hipStream_t stream);      // e4m3 -> bf16 x descales, contiguous (rows, H, D)
 hipError_t launch_empty_k_fill(uint16_t* o, float* lse, int64_t o_batch_stride, int64_t o_row_stride, int64_t o_head_stride,
                                int batch, int seqlen_q, int num_heads, int head_dim_v, hipStream_t stream);
 hipError_t launch_skip_list_stats(const int32_t* list, int rows, int k_tiles, int64_t* out, hipStream_t stream);

@@ -108,72 +108,6 @@ hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_ro
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------
-// e4m3 above head_dim 128 (192 / 256; round 6): no fp8 body is built there (the reference's own fp8 instantiations are compiled out of its
-// default build, hopper/setup.py:55), la_fwd serves it with the bf16 kernel of that head dim on operands up-converted HERE: one fused pass
-// per tensor - e4m3 -> fp32 (exact) x descale -> bf16 (round to nearest even) - into the caller's workspace (rounds 3-5 did it on the host
-// with torch elementwise passes). q carries q_descale * k_descale, v carries v_descale, k nothing: S = (q qd kd) . k and O = P (v vd) as in
-// the fp8 kernel (flash_fwd_kernel_sm90.h:505-512), each scaled operand rounded to bf16 once; P itself is bf16 there, i.e. MORE precise
-// than an fp8 kernel's. One thread = 16 elements of one (row, head).
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) la_upconvert_fp8_kernel(const uint8_t* __restrict__ src, int64_t batch_stride, int64_t row_stride,
-                                                               int64_t head_stride, uint16_t* __restrict__ dst, int batch, int rows,
-                                                               int num_heads, int head_dim, const float* __restrict__ sa, int64_t sa_bs,
-                                                               int64_t sa_hs, const float* __restrict__ sb, int64_t sb_bs, int64_t sb_hs,
-                                                               int h_ratio, const int* __restrict__ cu_seqlens) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef float f32x8 __attribute__((ext_vector_type(8)));
-    const int chunks = head_dim / 16;
-    // fixed length: (batch, rows) rows; packed: `rows` is the bound batch * max_seqlen, the real row count is cu_seqlens[batch]
-    const int64_t n_rows = cu_seqlens != nullptr ? min(static_cast<int64_t>(cu_seqlens[batch]), static_cast<int64_t>(rows)) : static_cast<int64_t>(batch) * rows;
-    const int64_t total = n_rows * num_heads * chunks;
-    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total; idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        const int ch = static_cast<int>(idx % chunks);
-        const int64_t rh = idx / chunks;
-        const int h = static_cast<int>(rh % num_heads);
-        const int64_t row = rh / num_heads;
-        int b;
-        const uint8_t* s;
-        if (cu_seqlens != nullptr) {
-            b = 0;
-            while (b + 1 < batch && row >= cu_seqlens[b + 1]) ++b;
-            s = src + row * row_stride + h * head_stride + ch * 16;
-        } else {
-            b = static_cast<int>(row / rows);
-            s = src + b * batch_stride + (row % rows) * row_stride + h * head_stride + ch * 16;
-        }
-        float scale = 1.0f;
-        const int hk = h / h_ratio;
-        if (sa != nullptr) scale *= sa[b * sa_bs + hk * sa_hs];
-        if (sb != nullptr) scale *= sb[b * sb_bs + hk * sb_hs];
-        const u32x4 in = *reinterpret_cast<const u32x4*>(s);
-        uint16_t* const d = dst + (row * num_heads + h) * head_dim + ch * 16;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const unsigned w0 = in[2 * half], w1 = in[2 * half + 1];
-            const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, true);
-            const f32x2 a2 = __builtin_amdgcn_cvt_pk_f32_fp8(w1, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8(w1, true);
-            f32x8 x = {a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
-            x *= scale;
-            *reinterpret_cast<bf16x8*>(d + 8 * half) = __builtin_convertvector(x, bf16x8);
-        }
-    }
-}
-
-hipError_t launch_upconvert_fp8(const void* src, int64_t batch_stride, int64_t row_stride, int64_t head_stride, void* dst, int batch, int rows,
-                                int num_heads, int head_dim, const float* sa, int64_t sa_bs, int64_t sa_hs, const float* sb, int64_t sb_bs,
-                                int64_t sb_hs, int h_ratio, const int* cu_seqlens, hipStream_t stream) {
-    const int64_t total = static_cast<int64_t>(batch) * rows * num_heads * (head_dim / 16);
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
-    if (blocks < 1) blocks = 1;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(la_upconvert_fp8_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, static_cast<const uint8_t*>(src), batch_stride,
-                       row_stride, head_stride, static_cast<uint16_t*>(dst), batch, rows, num_heads, head_dim, sa, sa_bs, sa_hs, sb, sb_bs, sb_hs,
-                       h_ratio, cu_seqlens);
-    return hipGetLastError();
-}
-
 size_t fp8_workspace_bytes(int batch, int num_heads, int k_tiles, int head_dim) {
     return static_cast<size_t>(batch) * num_heads * k_tiles * F8_BN * head_dim;
 }

@@ -32,8 +32,8 @@ constexpr TileShape tile_shape(int head_dim, int element_size) {
     if (element_size == 1) {
         if (head_dim == 128 || head_dim == 64) return {256, 64};  // fp8 e4m3: x64 structure on the block-scaled MFMA; K 8 KiB + V^T 8 KiB per stage
                                                                   // (round 6: head_dim 64 natively, half the MFMAs under the same softmax: 4 KiB + 4 KiB)
-        if (head_dim == 192 || head_dim == 256) return {128, 64};   // no fp8 body above 128: la_fwd up-converts the operands into the workspace
-                                                                    // (la_prep_fp8.hip) and runs the bf16 kernel of that head dim: ITS tiles
+        if (head_dim == 192 || head_dim == 256) return {128, 64};   // round 6: one 32-row q-block per wave (O^T of 32 rows x 256 is 128 accumulators),
+                                                                    // 3 / 4 contraction steps, 6 / 8 d-blocks; rings of 16 KiB per stage
     }
     return {0, 0};
 }

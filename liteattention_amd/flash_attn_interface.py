@@ -79,7 +79,7 @@ def kernel_head_dim(head_dim: int, element_size: int, flags: Optional[int] = Non
     zero-pads q, k, v to it (``mha_fwd``), which is exact: zero columns add 0 to every score and give zero output columns,
     which are sliced away. The reference instantiates 64/96/128/192/256 (hopper/setup.py:57-61) and picks the next size up the
     same way (flash_api.cpp round_up_headdim). bf16 / fp16: 64, 96, 128, 192, 256 are built (with LA_FWD_KERNEL=v2, the
-    hipcc-scheduled A/B kernels: 64, 128, 256); fp8: 64 and 128 natively, 192 / 256 on the bf16 kernels inside la_fwd; beyond that the library's typed error is raised. The library is
+    hipcc-scheduled A/B kernels: 64, 128, 256); fp8: 64, 128, 192 and 256 (round 6: native bodies at all four); beyond that the library's typed error is raised. The library is
     asked (``la_get_tile_sizes_ex``), there is no second table here."""
     if head_dim <= 0 or head_dim % (16 if element_size == 1 else 8) != 0:
         return head_dim                                      # la_get_tile_sizes / mha_fwd report the error
@@ -93,7 +93,7 @@ def kernel_head_dim(head_dim: int, element_size: int, flags: Optional[int] = Non
 
 def get_tile_sizes(head_dim: int, element_size: int) -> Tuple[int, int]:
     """(kBlockM, kBlockN) of the gfx950 kernel that serves this head_dim — the single source for skip-list geometry.
-    e4m3 above head_dim 128 is served by the bf16 kernel of that head dim (inside ``la_fwd``): the library answers with its tiles."""
+    e4m3 above head_dim 128 runs one 32-row q-block per wave: (128, 64), the tiles of the bf16 kernels of those head dims."""
     flags = _cabi.default_flags()
     return _cabi.get_tile_sizes(kernel_head_dim(head_dim, element_size, flags), element_size, flags)
 
@@ -252,10 +252,8 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
                 return res
 
     host_flags = _cabi.default_flags()                       # the environment is read ONCE per call
-    # (e4m3 at head dims 192 / 256 and the padded sizes between: no fp8 body is built there - the reference's own fp8 instantiations are
-    # compiled out of its default build, hopper/setup.py:55 - the LIBRARY serves them with the bf16 kernel of that head dim on operands it
-    # up-converts into the workspace, descales folded in (la_prep_fp8.hip; rounds 3-5 did that here with torch elementwise passes). Lists
-    # use that kernel's tiles, which is what la_get_tile_sizes answers for them.)
+    # (e4m3: native bodies at head dims 64 / 128 / 192 / 256 since round 6 - rounds 3-5 up-converted 192 / 256 here with torch elementwise passes
+    # and ran the bf16 kernels; the sizes between run zero-padded on the next one, like the 2-byte types)
     D_kernel = kernel_head_dim(D, q.element_size(), host_flags)
     if D_kernel != D:
         # head_dim between the instantiated sizes: zero-pad the last dim (one extra pass over q, k, v; exact, see

@@ -106,7 +106,7 @@ class HeadShardedLiteAttention:
             from .flash_attn_interface import device_slots, get_tile_sizes, q_tiles_per_item
             bm, _ = get_tile_sizes(q.shape[-1], q.element_size())
             # the library knows the device and the kernel it would run; both calls map the head dim / element size the same way
-            # (80 -> the 96 kernel, e4m3 above 128 -> the bf16 kernel of that head dim: ADVICE r4)
+            # (80 -> the 96 kernel, e4m3 144 -> its 192 body: ADVICE r4)
             cus, per_cu = device_slots(q.shape[-1], q.element_size())
             slots = cus * per_cu
             unit = q_tiles_per_item(q.shape[-1], q.element_size())

@@ -1,5 +1,5 @@
-"""GPU box: same-box A/B of library variants on e4m3 head_dim 64 (dense S = 16 384, H = 40; the three forms of P), one subprocess per
-(variant, repetition), interleaved.   python tools/debug/fp8_d64_ab.py [--reps 2] name=path/to/lib.so ...   (the in-tree library is "tree")"""
+"""GPU box: same-box A/B of library variants on e4m3 at one head dim (dense S = 16 384, H = 40; the three forms of P), one subprocess per
+(variant, repetition), interleaved.   python tools/debug/fp8_dim_ab.py [--dim 64] [--reps 2] name=path/to/lib.so ...   (the in-tree library is "tree")"""
 import os
 import statistics
 import subprocess
@@ -10,7 +10,7 @@ WORKER = r'''
 import os, sys, torch
 sys.path.insert(0, %r)
 import liteattention_amd as L
-S, H, D = 16384, 40, 64
+S, H, D = 16384, 40, %d
 g = torch.Generator(device="cuda").manual_seed(0)
 q, k, v = [torch.randn(1, S, H, D, device="cuda", generator=g).bfloat16().to(torch.float8_e4m3fn) for _ in range(3)]
 out = []
@@ -25,7 +25,7 @@ for form in ("reference", "mfma_rowsum", "encoded"):
     e1.record(); torch.cuda.synchronize()
     out.append("%%.4f" %% (e0.elapsed_time(e1) / 60))
 print("RESULT " + " ".join(out))
-''' % ROOT
+''' % (ROOT, int(sys.argv[sys.argv.index('--dim') + 1]) if '--dim' in sys.argv else 64)
 args = [a for a in sys.argv[1:] if "=" in a]
 reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 2
 variants = [("tree", None)] + [tuple(a.split("=", 1)) for a in args]
@@ -42,7 +42,7 @@ for r in range(reps):
             print(name, "FAILED", p.stderr[-400:])
             continue
         res[name].append([float(x) for x in line[0].split()[1:]])
-print(f"{'variant':24s} reference  mfma_rowsum  encoded   (ms, dense S=16384 H=40 D=64 e4m3; median of {reps})")
+print(f"{'variant':24s} reference  mfma_rowsum  encoded   (ms, dense S=16384 H=40 e4m3 at the head dim of --dim; median of {reps})")
 for name, rows in res.items():
     if rows:
         print(f"{name:24s} " + "  ".join(f"{statistics.median(r[i] for r in rows):8.4f}" for i in range(3)))
