@@ -591,6 +591,7 @@ def step(variant):
             pre[t].append(("WAIT", ("v", db, 1)))
         mf.append(mfma_pv(cur, db, qb))
         if "klate" in OPT:
+            assert len(K_FRAGS) == NG2, "klate: one K fragment read per phase-2 gap (the head_dim-128 exp / lvalu bodies only)"
             post[t].append(k_read(kbuf_read, *K_FRAGS[t]))
         elif t < len(K_FRAGS) // 2:              # K(i+2) fragments in the first half: nothing young is left for the drain
             post[t] += [k_read(kbuf_read, *K_FRAGS[2 * t]), k_read(kbuf_read, *K_FRAGS[2 * t + 1])]

@@ -13,7 +13,7 @@ def test_design_tables_are_generated_from_the_committed_profiles():
     assert r.returncode == 0, r.stdout + r.stderr
     text = open(os.path.join(ROOT, "MEASUREMENTS.md")).read()
     for name in ("headline", "rocprof_bf16", "rocprof_fp8", "traffic", "real_gap", "fp8_forms", "sched_sweep", "denoise50", "denoise50_survey",
-                 "half_vote", "joint_recipe"):
+                 "half_vote", "joint_recipe", "fp8_head_dims"):
         body = text.split(f"<!-- GEN:{name} -->")[1].split(f"<!-- /GEN:{name} -->")[0]
         assert body.strip(), f"generated block {name} is empty"
 

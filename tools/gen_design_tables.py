@@ -111,6 +111,18 @@ def blocks(tag):
             rows += [f"| {r['target']} | {r['thr']} | {100 * r['sparsity_last_step']:.1f} % | {r['ms_last_step']} | {r['total_ms_50_steps']} | {r['mean_abs_err_vs_dense']} / {r['max_abs_err_vs_dense']} |"
                      for r in sv["runs"]]
             out["denoise50_survey"] = rows
+        f8 = b.get("fp8") or {}
+        if any(f"head_dim_{hd}" in f8 for hd in (64, 192, 256)):
+            rows = ["| head_dim (tiles) | reference arithmetic (default): ms, TFLOP/s, of 5 PF | `LA_FLAG_FP8_MFMA_ROWSUM` | `LA_FLAG_FP8_ENCODED_P` | sampled rows ok |", "|---|---|---|---|---|"]
+            for hd in (64, 192, 256):
+                x = f8.get(f"head_dim_{hd}") or {}
+                fm = x.get("forms") or {}
+                if not fm:
+                    continue
+                cell = lambda k: (f"{fm[k]['ms']} ms, {fm[k]['tflops']}, {fm[k]['frac_of_mfma_peak']}" if k in fm else "n/a")      # noqa: E731
+                rows.append(f"| {hd} ({x['tiles'][0]} x {x['tiles'][1]}) | {cell('reference_arithmetic')} | {cell('mfma_rowsum')} | {cell('encoded_p')} | "
+                            f"{all(v['verified']['ok'] for v in fm.values())} |")
+            out["fp8_head_dims"] = rows
         jr = b.get("joint_recipe") or {}
         if "v2v" in jr:
             rows = ["| call | ms | TFLOP/s (GB/s for the merges) | of the MFMA (HBM) peak | launches timed |", "|---|---|---|---|---|"]
