@@ -36,22 +36,26 @@ bool uses_half_vote(int head_dim, int element_size, uint32_t flags) {
     return element_size == 2 && (head_dim == 128 || head_dim == 96 || head_dim == 64) && (flags & LA_FLAG_HALF_VOTE) != 0 &&
            (flags & LA_FLAG_KERNEL_128ROW) == 0;
 }
-// Long DENSE key ranges (bf16 / fp16, hand-scheduled kernels). A workgroup keeps the tile-address table of its walk in LDS, which bounds the key
+// Long DENSE key ranges (hand-scheduled kernels; e4m3 too: la_fwd's fp8 branch). A workgroup keeps the tile-address table of its walk in LDS, which bounds the key
 // tiles of ONE launch (~4 800 at head_dim <= 128, ~1 600 at 192 / 256). A skip list names its tiles over the whole key range and keeps that
 // bound (LA_ERR_SEQLEN); a dense launch does not need it: with the workspace la_fwd_workspace_bytes() asks for, la_fwd cuts the keys into
 // the fewest equal runs of tiles that fit, runs them as launches on partial O / LSE buffers in the workspace and merges them by LSE
 // (la_combine's kernel) - the reference has no such bound (its producer reads the list from global memory, mainloop...:47-115).
-int dense_tiles_per_launch(int head_dim) {
+size_t walk_lds_bytes(int k_tiles, int head_dim, int element_size) {
+    return element_size == 1 ? la::fwd_lds_bytes_x64_fp8(k_tiles, nullptr, nullptr, head_dim) : la::fwd_lds_bytes_x64(k_tiles, nullptr, head_dim);
+}
+int dense_tiles_per_launch(int head_dim, int element_size) {
     int lo = 1, hi = 1 << 20;                         // largest k_tiles whose walk fits (the LDS bytes grow with k_tiles)
     while (lo < hi) {
         const int mid = lo + (hi - lo + 1) / 2;
-        if (la::fwd_lds_bytes_x64(mid, nullptr, head_dim) <= 160 * 1024) lo = mid; else hi = mid - 1;
+        if (walk_lds_bytes(mid, head_dim, element_size) <= 160 * 1024) lo = mid; else hi = mid - 1;
     }
     return lo;
 }
 struct DenseSplit { int n, chunk_tiles; uint64_t o_bytes, lse_bytes; };
-DenseSplit dense_split(int k_tiles, int head_dim, int64_t batch, int64_t seqlen_q, int64_t num_heads, int64_t head_dim_v) {
-    const int per = dense_tiles_per_launch(head_dim);
+// (the partial O of a run is 16-bit for every input type: bf16 / fp16 as the inputs, bf16 for e4m3)
+DenseSplit dense_split(int k_tiles, int head_dim, int64_t batch, int64_t seqlen_q, int64_t num_heads, int64_t head_dim_v, int element_size = 2) {
+    const int per = dense_tiles_per_launch(head_dim, element_size);
     DenseSplit d{};
     d.n = (k_tiles + per - 1) / per;
     d.chunk_tiles = (k_tiles + d.n - 1) / d.n;
@@ -90,7 +94,7 @@ const char* la_status_string(int status) {
         case LA_ERR_LISTS: return "attn_read_list and attn_write_list must be given together";
         case LA_ERR_UNSUPPORTED: return "feature outside the QK-Skip hot path (head_dim_v != head_dim, unknown flags, skip lists with cu_seqlens on the 128-row kernels or, for bf16 / fp16, above head_dim 128)";
         case LA_ERR_LAUNCH: return "HIP kernel launch failed (see la_last_hip_error)";
-        case LA_ERR_SEQLEN: return "seqlen_k too long: the expanded skip list does not fit in LDS (dense bf16 / fp16 launches are cut into runs and merged when the workspace of la_fwd_workspace_bytes() is given)";
+        case LA_ERR_SEQLEN: return "seqlen_k too long: the expanded skip list does not fit in LDS (dense launches are cut into runs and merged when the workspace of la_fwd_workspace_bytes() is given)";
         case LA_ERR_WORKSPACE: return "fp8 needs a 16-byte aligned workspace of la_fwd_workspace_bytes() bytes";
         case LA_ERR_Q_WINDOW: return "q_tile_begin/q_tile_count outside the q-tiles of this problem (LA_FLAG_HALF_VOTE: windows start on an even q-tile and hold an even number unless they reach the last)";
         default: return "unknown la_status";
@@ -137,8 +141,16 @@ int64_t la_fwd_workspace_bytes(const la_fwd_args* a) {
     const int trc = la_get_tile_sizes_ex(a->head_dim, 1, a->flags, &bm, &bn);
     if (trc != LA_OK) return trc;
     if (a->batch <= 0 || a->num_heads <= 0 || a->num_heads_k <= 0 || a->seqlen_k < 0) return LA_ERR_SHAPE;
+    const int k_tiles = (a->seqlen_k + bn - 1) / bn;
+    if (a->read_list == nullptr && a->cu_seqlens_q == nullptr && a->seqlen_q > 0 && walk_lds_bytes(k_tiles, a->head_dim, 1) > 160 * 1024) {
+        // a dense key range longer than one launch's walk (see dense_split): the V^T tiles of ONE run (the runs follow each other on the
+        // stream), the ticket counters, the partial O / LSE of the runs
+        const DenseSplit d = dense_split(k_tiles, a->head_dim, a->batch, a->seqlen_q, a->num_heads, a->head_dim_v, 1);
+        return static_cast<int64_t>(la::fp8_workspace_bytes(a->batch, a->num_heads_k, d.chunk_tiles, a->head_dim) + kSchedWorkspaceBytes +
+                                    d.n * (d.o_bytes + d.lse_bytes));
+    }
     // V^T tiles, then the ticket counter of the dynamic work distribution
-    return static_cast<int64_t>(la::fp8_workspace_bytes(a->batch, a->num_heads_k, (a->seqlen_k + bn - 1) / bn, a->head_dim) + kSchedWorkspaceBytes);
+    return static_cast<int64_t>(la::fp8_workspace_bytes(a->batch, a->num_heads_k, k_tiles, a->head_dim) + kSchedWorkspaceBytes);
 }
 
 int la_fwd(const la_fwd_args* a, void* stream_) {
@@ -198,12 +210,19 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     }
 
     la::FwdParams p{};
+    size_t f8_tiles = 0;                               // fp8: bytes of prepared V^T tiles at the front of the workspace
+    bool f8_split = false;                             // fp8: a dense key range longer than one launch's walk, cut into runs (dense_split)
+    DenseSplit f8d{};
     if (fp8) {
-        const size_t tiles = la::fp8_workspace_bytes(a->batch, a->num_heads_k, (a->seqlen_k + bn - 1) / bn, a->head_dim);
-        if (a->workspace == nullptr || a->workspace_bytes < tiles + kSchedWorkspaceBytes || !aligned16(a->workspace))
+        const int kt = (a->seqlen_k + bn - 1) / bn;
+        f8_split = a->read_list == nullptr && !varlen && walk_lds_bytes(kt, a->head_dim, 1) > 160 * 1024;
+        if (f8_split) f8d = dense_split(kt, a->head_dim, a->batch, a->seqlen_q, a->num_heads, a->head_dim_v, 1);
+        f8_tiles = la::fp8_workspace_bytes(a->batch, a->num_heads_k, f8_split ? f8d.chunk_tiles : kt, a->head_dim);   // split: the tiles of ONE run
+        const uint64_t need = f8_tiles + kSchedWorkspaceBytes + (f8_split ? f8d.n * (f8d.o_bytes + f8d.lse_bytes) : 0);
+        if (a->workspace == nullptr || a->workspace_bytes < need || !aligned16(a->workspace))
             return LA_ERR_WORKSPACE;
         if (!(a->flags & LA_FLAG_STATIC_SCHED))        // lists or dense: persistent workgroups + ticket queues
-            p.work_counter = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(a->workspace) + tiles);
+            p.work_counter = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(a->workspace) + f8_tiles);
     }
     p.q = static_cast<const uint16_t*>(a->q);
     p.k = static_cast<const uint16_t*>(a->k);
@@ -255,7 +274,37 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
     if (static_cast<int64_t>(p.batch) * p.num_heads * p.q_tiles > 0x7fffffffLL) return LA_ERR_SHAPE;
 
     if (fp8) {
-        if (la::fwd_lds_bytes_x64_fp8(p.k_tiles, nullptr, nullptr, a->head_dim) > 160 * 1024) return LA_ERR_SEQLEN;
+        const int p_mode = (a->flags & LA_FLAG_FP8_ENCODED_P) ? 0 : (a->flags & LA_FLAG_FP8_MFMA_ROWSUM) ? 1 : 2;   // default: the reference's arithmetic
+        if (walk_lds_bytes(p.k_tiles, a->head_dim, 1) > 160 * 1024) {
+            // lists keep the bound; a dense launch is cut into runs of tiles that fit, as for bf16 / fp16 below: per run the V^T prepare pass of
+            // ITS keys into the one tile region (the runs follow each other on the stream), the forward on bf16 partial O / LSE, then the merge
+            if (!f8_split || p.q_tile_count != p.q_tiles || (a->flags & LA_FLAG_V_PREPARED)) return LA_ERR_SEQLEN;
+            unsigned char* const ws = static_cast<unsigned char*>(a->workspace);
+            uint16_t* const o_part = reinterpret_cast<uint16_t*>(ws + f8_tiles + kSchedWorkspaceBytes);
+            float* const lse_part = reinterpret_cast<float*>(ws + f8_tiles + kSchedWorkspaceBytes + f8d.n * f8d.o_bytes);
+            hipError_t e = hipSuccess;
+            for (int s = 0; s < f8d.n && e == hipSuccess; ++s) {
+                la::FwdParams ps = p;
+                const int64_t row0 = static_cast<int64_t>(s) * f8d.chunk_tiles * bn;
+                const int64_t left = a->seqlen_k - row0, full = static_cast<int64_t>(f8d.chunk_tiles) * bn;
+                ps.seqlen_k = static_cast<int>(left < full ? left : full);
+                ps.k_tiles = (ps.seqlen_k + bn - 1) / bn;
+                ps.k = reinterpret_cast<const uint16_t*>(static_cast<const unsigned char*>(a->k) + row0 * a->k_row_stride);     // 1-byte elements: strides are bytes
+                ps.v = static_cast<const uint16_t*>(a->workspace);
+                ps.o = o_part + s * (f8d.o_bytes / 2);
+                ps.o_head_stride = a->head_dim_v; ps.o_row_stride = static_cast<int64_t>(p.num_heads) * a->head_dim_v;
+                ps.o_batch_stride = static_cast<int64_t>(p.seqlen_q) * ps.o_row_stride;
+                ps.lse = lse_part + s * (f8d.lse_bytes / 4);
+                e = la::launch_prep_v_fp8(static_cast<const unsigned char*>(a->v) + row0 * a->v_row_stride, a->v_batch_stride, a->v_row_stride, a->v_head_stride,
+                                          a->workspace, a->batch, ps.seqlen_k, a->num_heads_k, ps.k_tiles, a->head_dim, stream, nullptr);
+                if (e == hipSuccess) e = la::launch_fwd_x64_fp8(ps, false, p_mode, a->head_dim, stream);
+            }
+            if (e == hipSuccess)
+                e = la::launch_combine(o_part, true, false, lse_part, p.o, a->lse, f8d.n, p.batch, p.seqlen_q, p.num_heads, a->head_dim_v, stream, false,
+                                       p.o_batch_stride, p.o_row_stride, p.o_head_stride);
+            if (e != hipSuccess) { g_last_hip_error = static_cast<int>(e); return LA_ERR_LAUNCH; }
+            return LA_OK;
+        }
         // 1) V -> pre-transposed, pre-swizzled V^T tiles in the caller's workspace; 2) forward on (Q, K, V^T)
         hipError_t e8 = hipSuccess;
         if (!(a->flags & LA_FLAG_V_PREPARED))
@@ -263,8 +312,7 @@ int la_fwd(const la_fwd_args* a, void* stream_) {
                                        a->batch, a->seqlen_k, a->num_heads_k, p.k_tiles, a->head_dim, stream, a->cu_seqlens_k);
         if (e8 == hipSuccess) {
             p.v = static_cast<const uint16_t*>(a->workspace);
-            e8 = la::launch_fwd_x64_fp8(p, a->read_list != nullptr,
-                                             (a->flags & LA_FLAG_FP8_ENCODED_P) ? 0 : (a->flags & LA_FLAG_FP8_MFMA_ROWSUM) ? 1 : 2, a->head_dim, stream);   // default: the reference's arithmetic
+            e8 = la::launch_fwd_x64_fp8(p, a->read_list != nullptr, p_mode, a->head_dim, stream);
         }
         if (e8 != hipSuccess) { g_last_hip_error = static_cast<int>(e8); return LA_ERR_LAUNCH; }
         return LA_OK;

@@ -183,3 +183,27 @@ def test_static_map_equals_the_ticket_queues_and_q_windows_compose(D):
     Qt = -(-S // _tiles(D)[0])
     win = mha_fwd(q, k, v, _q_windows=[(0, 2), (2, Qt - 2)])
     assert torch.equal(ref[0], win[0]) and torch.equal(ref[1], win[1])
+
+
+@pytest.mark.parametrize("D", [64, 256])
+def test_dense_key_range_beyond_one_launchs_walk(D, p_mode):
+    """The walk of a launch lives in LDS (~6 400 key tiles at head_dim <= 128, ~4 800 at 192 / 256 for e4m3). A DENSE call beyond that is cut into
+    runs inside la_fwd (per run: V^T prepare pass of its keys, forward on partial O / LSE, then the LSE merge), as for bf16 / fp16
+    (tests/test_gpu_head_dims.py); a call with skip lists keeps the bound and its typed error. Against fp32 torch on the same e4m3 inputs."""
+    import liteattention_amd as L
+    from liteattention_amd import _cabi
+    g = torch.Generator(device="cuda").manual_seed(D)
+    Sk = (6600 if D == 64 else 5000) * 64 - 9
+    q = torch.randn(1, 131, 1, D, device="cuda", generator=g).to(F8)
+    k = torch.randn(1, Sk, 1, D, device="cuda", generator=g).to(F8)
+    v = torch.randn(1, Sk, 1, D, device="cuda", generator=g).to(F8)
+    out, lse = L.flash_attn_func(q, k, v, return_softmax_lse=True)
+    sc = q.float()[0, :, 0] @ k.float()[0, :, 0].T / D ** 0.5
+    ref = torch.softmax(sc, -1) @ v.float()[0, :, 0]
+    assert bool(torch.isfinite(out.float()).all())
+    assert (out.float()[0, :, 0] - ref).abs().max().item() <= 0.05 * ref.abs().max().item() + 2e-3
+    assert (lse[0, 0] - torch.logsumexp(sc, -1)).abs().max().item() <= (1e-3 if p_mode == "exact" else 5e-3)
+    bm, bn = L.get_tile_sizes(D, 1)
+    lists = torch.zeros(2, 1, 1, -(-131 // bm), -(-Sk // bn) + 1, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match=_cabi.status_string(_cabi.LA_ERR_SEQLEN)[:20]):
+        L.flash_attn_func(q, k, v, attn_read_list=lists[0], attn_write_list=lists[1])
