@@ -316,7 +316,7 @@ def other_head_dims(L, dev, dims=(64, 96, 192, 256), S=16384, H=40):
 
 
 def fp8_head_dim(L, dev, D, S=16384, H=40):
-    """e4m3 at head_dim 64 / 192 / 256 on the native bodies of round 6 (until then 64 ran zero-padded on the head_dim-128 body and 192 / 256 on
+    """e4m3 at head_dim 64 / 96 / 192 / 256 on the native bodies of round 6 (until then 64 / 96 ran zero-padded on the head_dim-128 body and 192 / 256 on
     the bf16 kernels over up-converted operands), dense at the shape of `other_head_dims`, in the reference's arithmetic (the default) and in
     the two opt-in forms of P; sampled-row check of each timed output (fp8 bounds of the headline fp8 record)."""
     import torch
@@ -840,7 +840,7 @@ def main():
                     os.environ.pop("LA_FP8_P", None)
             result["fp8"]["reference_arithmetic"] = "value (the default form)"
             if not args.no_head_dims:
-                for hd in (64, 192, 256):
+                for hd in (64, 96, 192, 256):
                     result["fp8"][f"head_dim_{hd}"] = fp8_head_dim(L, dev, hd)
         except Exception as e:  # noqa: BLE001
             result["fp8"] = {"value": None, "error": repr(e)}
@@ -902,7 +902,7 @@ def main():
             for key in ("mfma_rowsum", "encoded_p"):
                 if key in result["fp8"]:
                     rf[f"fp8_{key}_frac"] = result["fp8"][key]["frac"]
-            for hd in (64, 192, 256):
+            for hd in (64, 96, 192, 256):
                 if "forms" in result["fp8"].get(f"head_dim_{hd}", {}):
                     rf[f"fp8_head_dim_{hd}_frac"] = {k: f["frac_of_mfma_peak"] for k, f in result["fp8"][f"head_dim_{hd}"]["forms"].items()}
         if "runs" in result.get("other_head_dims", {}):

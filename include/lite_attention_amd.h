@@ -169,7 +169,7 @@ typedef struct la_fwd_args {
 
     /* Caller-owned scratch (the library allocates nothing). Size from la_fwd_workspace_bytes(); 16-byte aligned;
      * contents are scratch, valid during the call (stream-ordered).
-     *   fp8: REQUIRED — the pre-transposed V tiles (64 keys x head_dim bytes per (batch, K/V head, key tile); head_dim 64, 128, 192, 256).
+     *   fp8: REQUIRED — the pre-transposed V tiles (64 keys x head_dim bytes per (batch, K/V head, key tile), 96 as 128; head_dim 64, 96, 128, 192, 256).
      *   bf16 / fp16: OPTIONAL, 1 KiB — eight ticket counters (one queue per XCD). With it the launch uses one
      *   persistent workgroup per CU and distributes the (batch, head, q-tile) items dynamically, which removes the
      *   cross-XCD imbalance real skip lists cause (items differ 2-3x in length; the hardware's workgroup->XCD

@@ -1,7 +1,7 @@
 """In-tree build of the HIP extension: ``hipcc --offload-arch=gfx950 -shared`` -> libliteattention_amd.so.
 
 Replaces the reference's nvcc/CUTLASS build (/root/reference/hopper/setup.py:381-674): no network, no
-downloaded toolchain, no feature-flag matrix — the build is {bf16 / fp16: head_dim 64/96/128/192/256, fp8 e4m3: head_dim 64/128/192/256} for
+downloaded toolchain, no feature-flag matrix — the build is {bf16 / fp16: head_dim 64/96/128/192/256, fp8 e4m3: head_dim 64/96/128/192/256} for
 gfx950 only (head dims in between run zero-padded on the next size up).
 The .so is written next to this file so that it travels with the source tree.
 """
@@ -165,7 +165,7 @@ def generate_bodies(gen_dir: str, variant: bool, defines=(), quiet=subprocess.DE
         extra = os.environ.get(f"LA_X64F8_{form.upper()}_OPT", "") if variant else ""
         generate(X64F8_GEN, inc, dict(base_env, LA_X64F8_OPT=",".join(x for x in (extra, form) if x)),
                  f"LA_X64F8_{form.upper()}_BODY_INC", f"LA_X64F8_{form.upper()}_CONSTS_INC")
-    for head_dim in (64, 192, 256):               # the other head dims (round 6): the three forms of P again, LA_X64F8_D=<head dim>
+    for head_dim in (64, 96, 192, 256):           # the other head dims (round 6): the three forms of P again, LA_X64F8_D=<head dim>
         for form in ("", "exp", "lvalu"):
             stem = f"d{head_dim}_" + (form + "_" if form else "")
             extra = os.environ.get(f"LA_X64F8_D{head_dim}_{form.upper() or 'DEFAULT'}_OPT", "") if variant else ""

@@ -55,7 +55,7 @@ def option_tag():
 
 
 
-XPAIRS = int(opt_val("x", {128: {"lin": "8", "exp": "4", "lvalu": "4"}, 64: {"lin": "12", "exp": "2", "lvalu": "6"},
+XPAIRS = int(opt_val("x", {128: {"lin": "8", "exp": "4", "lvalu": "4"}, 64: {"lin": "12", "exp": "2", "lvalu": "6"}, 96: {"lin": "8", "exp": "4", "lvalu": "4"},
                                 192: {"lin": "8", "exp": "8", "lvalu": "8"}, 256: {"lin": "8", "exp": "8", "lvalu": "8"}}[int(os.environ.get("LA_X64F8_D", "128"))]
                         ["lvalu" if "lvalu" in OPT else "exp" if "exp" in OPT else "lin"]))          # pair-groups (of 16) done in phase 2. EVEN: two pair-groups share one packed-e4m3 destination register
                                           # (lo / hi half by op_sel); an odd split leaves a half-written register across the phase boundary
@@ -70,15 +70,18 @@ XPAIRS = int(opt_val("x", {128: {"lin": "8", "exp": "4", "lvalu": "4"}, 64: {"li
 # the bf16 kernels of these head dims, so lists keep their geometry. 3 / 4 contraction steps per score block, 6 / 8 d-blocks; K rows sit in LDS at a
 # 256-byte stride (16 chunks, XOR-swizzled by row & 15; at 192 the last four chunks of a row are DMA filler, never read), rings of 16 KiB per stage.
 # Per wave and step: 16 K + 16 V^T fragment reads of 1 KiB against 16 MFMAs and half the softmax of the 64-row bodies: bound by the matrix pipe and the LDS.
+# Head dim 96: the 128 step with three d-blocks of O^T (8 QK + 6 PV MFMAs) - its contraction is one and a half 64-wide steps, so QK^T keeps both: the K tile
+# sits in LDS exactly as at 128 with the two chunk positions per row whose source would be chunk 6 / 7 filled by DMA filler (a copy of chunk 5: finite
+# data) and the matching quarter of the Q fragments ZERO; the prepared V^T tile is padded to the 128 tile's 8 KiB by the prepare pass.
 D = int(os.environ.get("LA_X64F8_D", "128"))
-assert D in (64, 128, 192, 256), D
+assert D in (64, 96, 128, 192, 256), D
 WIDE = D > 128
 NQB = 1 if WIDE else 2                    # q-blocks of 32 rows per wave
 QBS = tuple(range(NQB))
 NSX, ND = (D + 63) // 64, D // 32         # 64-wide contraction steps of S^T = K Q^T; 32-wide d-blocks of O^T
 DB = ND                                   # gen_epilogue.py: d-blocks to store
-PIECES_K = 4 if WIDE else D // 64         # 1 KiB LDS-DMA pieces per wave and K tile (WIDE: the 16 KiB image of 256-byte rows)
-PIECES_V = D // 64                        # ... and prepared V^T tile (64 D bytes)
+PIECES_K = 4 if WIDE else (D + 63) // 64  # 1 KiB LDS-DMA pieces per wave and K tile (WIDE: the 16 KiB image of 256-byte rows)
+PIECES_V = (D + 63) // 64                 # ... and prepared V^T tile (64 D bytes; 96: padded to 8 KiB)
 ROWSUM = 99                               # "d-block" index of the row-sum MFMA in PV_ORDER
 PK = "pk" in OPT                          # A/B: packed fp32 FMA / add in the softmax (v_pk_fma_f32, v_pk_add_f32). MEASURED ANTI-LEVER here too:
                                           # 64 fewer instructions per step, bit-identical results, 1891 vs 2068 TFLOP/s at 42 % (round 2, tools/ab.py --fp8)
@@ -125,7 +128,7 @@ MX = LIN and "nomx" not in OPT
 TAU = float(opt_val("tau", "32" if MX else ("1" if LIN else "2")))
 P_CEIL = 8.75 if LIN else 8.0
 P_OFFSET = 7.0 if MX else P_CEIL - TAU
-DMA_GAPS = [int(x) for x in opt_val("dmagaps", {64: "0,1,2,3", 128: "0,1,1,2,3,3", 192: "0,1,1,2,2,3,4,4,5", 256: "0,1,1,2,2,3,4,4,5,5"}[D]).replace(".", ",").split(",")]   # m0K,K0,K1,m0V,V0,V1 (phase 1 gaps; an M0 write is never adjacent to its first use)
+DMA_GAPS = [int(x) for x in opt_val("dmagaps", {64: "0,1,2,3", 96: "0,1,1,2,3,3", 128: "0,1,1,2,3,3", 192: "0,1,1,2,2,3,4,4,5", 256: "0,1,1,2,2,3,4,4,5,5"}[D]).replace(".", ",").split(",")]   # m0K,K0,K1,m0V,V0,V1 (phase 1 gaps; an M0 write is never adjacent to its first use)
 
 
 # ---------------------------------------------------------------- AGPR map
@@ -738,13 +741,15 @@ def prologue():
         emit(f"v_lshl_add_u32 {v(LK[0])}, {v(T[5])}, 4, {v(LK[0])}")
         emit(f"v_add_u32 {v(LK[0])}, 1024, {v(LK[0])}")            # S_KBASE carries -1024 (as at head_dim 128)
     emit(f"s_lshl_b32 {s(S_T0)}, {s(S_WAVE)}, 4")
-    for j in ((0, 1) if D == 128 else ()):
+    for j in ((0, 1) if D in (96, 128) else ()):
         emit(f"v_add_u32 {v(T[4])}, {s(S_T0)}, {v(T[6])}")
         if j:
             emit(f"v_add_u32 {v(T[4])}, 8, {v(T[4])}")
         emit(f"v_lshrrev_b32 {v(T[5])}, 1, {v(T[4])}")
         emit(f"v_and_b32 {v(T[5])}, 7, {v(T[5])}")
         emit(f"v_xor_b32 {v(T[5])}, {v(T[5])}, {v(T[7])}")
+        if D == 96:
+            emit(f"v_min_u32 {v(T[5])}, 5, {v(T[5])}")        # a row has six 16-byte chunks: positions whose source would be chunk 6 / 7 take a copy of chunk 5
         emit(f"v_min_i32 {v(T[4])}, {v(T[4])}, {s(S_LASTROW)}")   # seqlen_k < 64: rows of the only tile stay inside K
         emit(f"v_mul_lo_u32 {v(LK[j])}, {v(T[4])}, {s(S_KRS)}")
         emit(f"v_lshl_add_u32 {v(LK[j])}, {v(T[5])}, 4, {v(LK[j])}")
@@ -774,6 +779,10 @@ def prologue():
         emit(f"v_addc_co_u32 {v(T[5])}, vcc, {v(T[5])}, {v(T[7])}, vcc")
         for sx in range(NSX):
             for t in (0, 1):
+                if 64 * sx + 32 * t >= D:            # head_dim 96: d 96..127 does not exist - zero fragments (they meet the K tile's filler chunks)
+                    for r in range(4):
+                        emit(f"v_mov_b32 {v(16 * qb + 8 * sx + 4 * t + r)}, 0")
+                    continue
                 emit(f"global_load_dwordx4 {vr(16 * qb + 8 * sx + 4 * t, 4)}, {vr(T[4], 2)}, off offset:{64 * sx + 32 * t}")
     emit("s_waitcnt vmcnt(0)")
     for qb in QBS:
@@ -906,9 +915,9 @@ def main():
     mode = 2 if not LMFMA else (0 if LIN else 1)               # PMODE of the shell (la_fwd_kernel_x64_fp8.hip)
     # the three bodies of the build are told apart by their FILE NAME in the shell's includes: a body generated under options that belong to
     # another name (e.g. a global LA_X64F8_OPT in the environment of a default build) must fail here, not at link time
-    by_name = 1 if path.endswith("_exp_body.inc") else (2 if path.endswith("_lvalu_body.inc") else (0 if path.endswith(("la_fwd_x64_fp8_body.inc", "la_fwd_x64_fp8_d64_body.inc", "la_fwd_x64_fp8_d192_body.inc", "la_fwd_x64_fp8_d256_body.inc")) else mode))
+    by_name = 1 if path.endswith("_exp_body.inc") else (2 if path.endswith("_lvalu_body.inc") else (0 if path.endswith(("la_fwd_x64_fp8_body.inc", "la_fwd_x64_fp8_d64_body.inc", "la_fwd_x64_fp8_d96_body.inc", "la_fwd_x64_fp8_d192_body.inc", "la_fwd_x64_fp8_d256_body.inc")) else mode))
     tag = "" if D == 128 else f"_d{D}_"
-    if tag not in os.path.basename(path) or (D == 128 and any(f"_d{d}_" in os.path.basename(path) for d in (64, 192, 256))):
+    if tag not in os.path.basename(path) or (D == 128 and any(f"_d{d}_" in os.path.basename(path) for d in (64, 96, 192, 256))):
         raise SystemExit(f"{path}: generated for head_dim {D} (LA_X64F8_D) but named like another head dim's body")
     if by_name != mode:
         raise SystemExit(f"{path}: generated with the options of P mode {mode} (LA_X64F8_OPT={os.environ.get('LA_X64F8_OPT', '')!r}) "

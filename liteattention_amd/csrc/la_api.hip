@@ -87,7 +87,7 @@ const char* la_status_string(int status) {
         case LA_ERR_NULL_ARG: return "required pointer is NULL";
         case LA_ERR_STRUCT_SIZE: return "la_fwd_args.struct_size mismatch (ABI version skew)";
         case LA_ERR_DTYPE: return "FlashAttention only supports fp16, bf16, and fp8_e4m3 type; this build instantiates all three";
-        case LA_ERR_HEAD_DIM: return "head_size not instantiated in this build (bf16 / fp16: 64, 96, 128, 192, 256 - under LA_FLAG_KERNEL_128ROW only 64, 128, 256; fp8: 64, 128, 192, 256)";
+        case LA_ERR_HEAD_DIM: return "head_size not instantiated in this build (bf16 / fp16: 64, 96, 128, 192, 256 - under LA_FLAG_KERNEL_128ROW only 64, 128, 256; fp8: 64, 96, 128, 192, 256)";
         case LA_ERR_SHAPE: return "invalid shape (batch, seqlen_q, heads and head_dim must be positive; number of heads in key/value must divide number of heads in query)";
         case LA_ERR_STRIDE: return "Input tensor must have contiguous last dimension and 16-byte aligned rows";
         case LA_ERR_TILE_MISMATCH: return "block_m/block_n do not match la_get_tile_sizes(): skip lists would be mis-indexed";

@@ -36,6 +36,7 @@ __global__ void __launch_bounds__(256) la_prep_v_fp8_kernel(const uint8_t* __res
                                                             int64_t v_row_stride, int64_t v_head_stride,
                                                             uint8_t* __restrict__ vt, int seqlen_k, int num_heads,
                                                             int k_tiles, const int* __restrict__ cu_seqlens_k) {
+    constexpr int DP = D == 96 ? 128 : D;          // rows of the tile written (96: zero rows up to the 128 tile, so that the forward copies it in 1 KiB pieces)
     __shared__ __attribute__((aligned(16))) uint8_t tile[F8_BN][D + 16];   // [key][d], padded rows
     const int n = blockIdx.x % k_tiles;
     const int bh = blockIdx.x / k_tiles;
@@ -47,11 +48,12 @@ __global__ void __launch_bounds__(256) la_prep_v_fp8_kernel(const uint8_t* __res
         src = v + static_cast<int64_t>(k0) * v_row_stride + h * v_head_stride;
     }
     const int tid = threadIdx.x;
-    // coalesced load: 64 rows x D bytes = 4 D chunks of 16 bytes, D / 64 per thread
-    constexpr int kPerThread = D / 64, kRowChunks = D / 16;
+    // coalesced load: 64 rows x D bytes = 4 D chunks of 16 bytes, up to DP / 64 per thread
+    constexpr int kPerThread = DP / 64, kRowChunks = D / 16;
 #pragma unroll
     for (int it = 0; it < kPerThread; ++it) {
         const int cid = tid + 256 * it;
+        if (cid >= F8_BN * kRowChunks) continue;
         const int row = cid / kRowChunks, ch = cid % kRowChunks;
         u32x4 t = {0u, 0u, 0u, 0u};
         const int key = n * F8_BN + row;
@@ -59,8 +61,8 @@ __global__ void __launch_bounds__(256) la_prep_v_fp8_kernel(const uint8_t* __res
         *reinterpret_cast<u32x4*>(&tile[row][ch * 16]) = t;
     }
     __syncthreads();
-    // D rows (d) x 4 chunks of 16 bytes out, D / 64 per thread
-    uint8_t* dst = vt + (static_cast<int64_t>(bh) * k_tiles + n) * (F8_BN * D);
+    // DP rows (d) x 4 chunks of 16 bytes out, DP / 64 per thread
+    uint8_t* dst = vt + (static_cast<int64_t>(bh) * k_tiles + n) * (F8_BN * DP);
 #pragma unroll
     for (int it = 0; it < kPerThread; ++it) {
         const int cid = tid + 256 * it;
@@ -76,7 +78,7 @@ __global__ void __launch_bounds__(256) la_prep_v_fp8_kernel(const uint8_t* __res
                 const int byte = 4 * q4 + bi;             // 0..15 inside the chunk
                 const int kk = 2 * j + (byte >> 3), e = byte & 7;
                 const int key = 16 * kk + 4 * hh + (e & 3) + 8 * (e >> 2);
-                acc |= static_cast<uint32_t>(tile[key][d]) << (8 * bi);
+                if (d < D) acc |= static_cast<uint32_t>(tile[key][d]) << (8 * bi);
             }
             w[q4] = acc;
         }
@@ -97,6 +99,10 @@ hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_ro
         hipLaunchKernelGGL(la_prep_v_fp8_kernel<192>, dim3(batch * num_heads * k_tiles), dim3(256), 0, stream,
                            static_cast<const uint8_t*>(v), v_batch_stride, v_row_stride, v_head_stride,
                            static_cast<uint8_t*>(vt), seqlen_k, num_heads, k_tiles, cu_seqlens_k);
+    else if (head_dim == 96)
+        hipLaunchKernelGGL(la_prep_v_fp8_kernel<96>, dim3(batch * num_heads * k_tiles), dim3(256), 0, stream,
+                           static_cast<const uint8_t*>(v), v_batch_stride, v_row_stride, v_head_stride,
+                           static_cast<uint8_t*>(vt), seqlen_k, num_heads, k_tiles, cu_seqlens_k);
     else if (head_dim == 64)
         hipLaunchKernelGGL(la_prep_v_fp8_kernel<64>, dim3(batch * num_heads * k_tiles), dim3(256), 0, stream,
                            static_cast<const uint8_t*>(v), v_batch_stride, v_row_stride, v_head_stride,
@@ -109,7 +115,7 @@ hipError_t launch_prep_v_fp8(const void* v, int64_t v_batch_stride, int64_t v_ro
 }
 
 size_t fp8_workspace_bytes(int batch, int num_heads, int k_tiles, int head_dim) {
-    return static_cast<size_t>(batch) * num_heads * k_tiles * F8_BN * head_dim;
+    return static_cast<size_t>(batch) * num_heads * k_tiles * F8_BN * (head_dim == 96 ? 128 : head_dim);     // (96: tiles padded to the 128 tile)
 }
 
 }  // namespace la

@@ -30,8 +30,8 @@ constexpr TileShape tile_shape(int head_dim, int element_size) {
                                                                     // with 32 rows (O^T of 32 rows x 256 is 128 registers); 192: 24 of 32 fragments
     }
     if (element_size == 1) {
-        if (head_dim == 128 || head_dim == 64) return {256, 64};  // fp8 e4m3: x64 structure on the block-scaled MFMA; K 8 KiB + V^T 8 KiB per stage
-                                                                  // (round 6: head_dim 64 natively, half the MFMAs under the same softmax: 4 KiB + 4 KiB)
+        if (head_dim == 128 || head_dim == 64 || head_dim == 96) return {256, 64};  // fp8 e4m3: x64 structure on the block-scaled MFMA; K 8 KiB + V^T 8 KiB per stage
+                                                                  // (round 6: head_dim 64 natively, half the MFMAs under the same softmax: 4 KiB + 4 KiB; 96: three d-blocks of O^T)
         if (head_dim == 192 || head_dim == 256) return {128, 64};   // round 6: one 32-row q-block per wave (O^T of 32 rows x 256 is 128 accumulators),
                                                                     // 3 / 4 contraction steps, 6 / 8 d-blocks; rings of 16 KiB per stage
     }

@@ -79,7 +79,7 @@ def kernel_head_dim(head_dim: int, element_size: int, flags: Optional[int] = Non
     zero-pads q, k, v to it (``mha_fwd``), which is exact: zero columns add 0 to every score and give zero output columns,
     which are sliced away. The reference instantiates 64/96/128/192/256 (hopper/setup.py:57-61) and picks the next size up the
     same way (flash_api.cpp round_up_headdim). bf16 / fp16: 64, 96, 128, 192, 256 are built (with LA_FWD_KERNEL=v2, the
-    hipcc-scheduled A/B kernels: 64, 128, 256); fp8: 64, 128, 192 and 256 (round 6: native bodies at all four); beyond that the library's typed error is raised. The library is
+    hipcc-scheduled A/B kernels: 64, 128, 256); fp8: the same five (round 6: native bodies at all of them); beyond that the library's typed error is raised. The library is
     asked (``la_get_tile_sizes_ex``), there is no second table here."""
     if head_dim <= 0 or head_dim % (16 if element_size == 1 else 8) != 0:
         return head_dim                                      # la_get_tile_sizes / mha_fwd report the error
@@ -252,7 +252,7 @@ def mha_fwd(q, k, v, k_new=None, v_new=None, q_v=None, out=None, cu_seqlens_q=No
                 return res
 
     host_flags = _cabi.default_flags()                       # the environment is read ONCE per call
-    # (e4m3: native bodies at head dims 64 / 128 / 192 / 256 since round 6 - rounds 3-5 up-converted 192 / 256 here with torch elementwise passes
+    # (e4m3: native bodies at head dims 64 / 96 / 128 / 192 / 256 since round 6 - rounds 3-5 up-converted 192 / 256 here with torch elementwise passes
     # and ran the bf16 kernels; the sizes between run zero-padded on the next one, like the 2-byte types)
     D_kernel = kernel_head_dim(D, q.element_size(), host_flags)
     if D_kernel != D:

@@ -38,7 +38,7 @@ def test_a_poisoned_environment_yields_the_clean_product_bodies(tmp_path):
     clean_dir.mkdir(); dirty_dir.mkdir()
     a = _generate(clean_dir, False, {})
     b = _generate(dirty_dir, False, POISON)
-    assert len(a["generated"]) == 28 and [os.path.basename(p) for p in a["generated"]] == [os.path.basename(p) for p in b["generated"]]
+    assert len(a["generated"]) == 31 and [os.path.basename(p) for p in a["generated"]] == [os.path.basename(p) for p in b["generated"]]
     for pa, pb in zip(a["generated"], b["generated"]):
         assert open(pa, "rb").read() == open(pb, "rb").read(), os.path.basename(pa)        # byte for byte
         head = open(pb).read(400)
@@ -136,4 +136,4 @@ def test_every_loop_head_sits_at_its_pinned_code_placement():
                 key = next(k for k in want if k in m.group(1))
                 assert int(heads[0], 16) % 32 == want[key], (m.group(1), int(heads[0], 16) % 32, want[key])
                 seen += 1
-    assert seen == 50, seen            # 5 head dims x 2 element types x 2 (lists / dense) + the half-vote form of head dims 64 / 96 / 128 x 2 element types + 3 fp8 forms x 2 x 4 head dims
+    assert seen == 56, seen            # 5 head dims x 2 element types x 2 (lists / dense) + the half-vote form of head dims 64 / 96 / 128 x 2 element types + 3 fp8 forms x 2 x 5 head dims

@@ -12,7 +12,7 @@ import pytest
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "liteattention_amd", "csrc")
 CASES = [("gen_fwd_x64.py", {"LA_X64_D": str(d), "LA_X64_DTYPE": t}) for d in (96, 128, 192, 256) for t in ("bf16", "f16")] + \
         [("gen_fwd_x64.py", {"LA_X64_D": str(d), "LA_X64_DTYPE": "bf16", "LA_X64_FORM": "half"}) for d in (64, 96, 128)] + \
-        [("gen_fwd_x64_fp8.py", dict({"LA_X64F8_D": str(d)}, **({"LA_X64F8_OPT": o} if o else {}))) for d in (64, 128, 192, 256) for o in ("", "exp", "lvalu")]
+        [("gen_fwd_x64_fp8.py", dict({"LA_X64F8_D": str(d)}, **({"LA_X64F8_OPT": o} if o else {}))) for d in (64, 96, 128, 192, 256) for o in ("", "exp", "lvalu")]
 
 
 def _generate(tmp_path, gen, env):
@@ -66,7 +66,7 @@ def test_mfma_count_per_step(tmp_path, D, per_phase):
     assert "v_mfma_f32_32x32x16_f16" not in text
 
 
-@pytest.mark.parametrize("D,qk,pv", [(64, 4, 4), (128, 8, 8), (192, 6, 6), (256, 8, 8)])
+@pytest.mark.parametrize("D,qk,pv", [(64, 4, 4), (96, 8, 6), (128, 8, 8), (192, 6, 6), (256, 8, 8)])
 @pytest.mark.parametrize("form", ["", "exp", "lvalu"])
 def test_fp8_mfma_count_per_step(tmp_path, D, qk, pv, form):
     """fp8 bodies (gen_fwd_x64_fp8.py, LA_X64F8_D): prologue QK of tile 0 + two unrolled steps of (QK + PV [+ one row-sum MFMA per q-block in the
@@ -75,7 +75,7 @@ def test_fp8_mfma_count_per_step(tmp_path, D, qk, pv, form):
     text = _generate(tmp_path, "gen_fwd_x64_fp8.py", dict({"LA_X64F8_D": str(D)}, **({"LA_X64F8_OPT": form} if form else {})))
     rowsum = 0 if form == "lvalu" else (2 if D <= 128 else 1)
     assert text.count("v_mfma_scale_f32_32x32x64_f8f6f4") == qk + 2 * (qk + pv + rowsum)
-    assert ("v_min_u32" in text) == (D == 192)
+    assert ("v_min_u32" in text) == (D in (96, 192))
     assert text.count("s_barrier") == 2 + 2
 
 

@@ -1,9 +1,9 @@
-"""GPU: the native fp8 (e4m3) bodies at head dims 64, 192 and 256 (round 6; gen_fwd_x64_fp8.py under LA_X64F8_D, la_fwd_kernel_x64_fp8.hip).
+"""GPU: the native fp8 (e4m3) bodies at head dims 64, 96, 192 and 256 (round 6; gen_fwd_x64_fp8.py under LA_X64F8_D, la_fwd_kernel_x64_fp8.hip).
 
 Until round 5 e4m3 at head dims <= 64 ran zero-padded on the head_dim-128 body, and above 128 on the bf16 kernels over up-converted operands.
 The native 64 body does one 64-wide contraction per score block and two d-blocks of O^T; the 192 / 256 bodies hold ONE 32-row q-block per wave
 (q-tile 128) with 3 / 4 contraction steps and 6 / 8 d-blocks. Every fp32 operation on a real column is the one the next instantiated size does on
-zero-padded operands (a zero product adds exactly 0 to a score; d-blocks of O^T are independent), so 64 must agree with the padded 128 form and 192
+zero-padded operands (a zero product adds exactly 0 to a score; d-blocks of O^T are independent), so 64 and 96 must agree with the padded 128 form and 192
 with the padded 256 form BIT FOR BIT - O, LSE and the written lists, in all three forms of P. Those are the first tests; the others hold the bodies
 against the oracle directly (ragged shapes, lists over steps with descales and GQA, the lazy-rescale path, head dims served by padding onto these
 bodies) as tests/test_gpu_fp8.py does at 128; packed variable-length batches: tests/test_gpu_varlen_lists.py. The reference-generated golden
@@ -15,8 +15,8 @@ from helpers import fp8_lse_tol, fp8_p_round, structured_qkv
 
 pytestmark = pytest.mark.gpu
 F8 = torch.float8_e4m3fn
-DIMS = [64, 192, 256]
-PADDED = {64: 128, 192: 256}            # head dim -> the next instantiated size its zero-padded form runs on
+DIMS = [64, 96, 192, 256]
+PADDED = {64: 128, 96: 128, 192: 256}   # head dim -> a larger instantiated size its zero-padded form runs on
 
 
 @pytest.fixture(params=["encoded", "exp", "exact"], autouse=True)
@@ -47,8 +47,8 @@ def test_the_library_serves_these_head_dims_natively():
     import liteattention_amd as L
     from liteattention_amd import _cabi
     from liteattention_amd.flash_attn_interface import kernel_head_dim
-    assert all(_cabi.is_instantiated(d, 1, 0) for d in (64, 128, 192, 256))
-    assert [kernel_head_dim(d, 1) for d in (48, 64, 80, 128, 144, 192, 208, 256)] == [64, 64, 128, 128, 192, 192, 256, 256]
+    assert all(_cabi.is_instantiated(d, 1, 0) for d in (64, 96, 128, 192, 256))
+    assert [kernel_head_dim(d, 1) for d in (48, 64, 80, 96, 112, 128, 144, 192, 208, 256)] == [64, 64, 96, 96, 128, 128, 192, 192, 256, 256]
     assert L.get_tile_sizes(64, 1) == (256, 64) and L.get_tile_sizes(192, 1) == L.get_tile_sizes(256, 1) == (128, 64)
 
 
@@ -62,7 +62,7 @@ def test_native_body_equals_the_zero_padded_next_size_bit_for_bit_dense(shape, D
                torch.randn(B, Sk, Hk, D, generator=g).to(F8).cuda())
     qd, kd, vd = [(0.5 + torch.rand(B, Hk, generator=g)).cuda() for _ in range(3)]
     out, lse = L.flash_attn_func(q, k, v, q_descale=qd, k_descale=kd, v_descale=vd, return_softmax_lse=True)
-    P = PADDED[D]
+    P = PADDED[D]                      # (padding to 128 makes 96 run on the 128 body: the library never pads 96 itself any more)
     out_p, lse_p = L.flash_attn_func(_pad(q, P), _pad(k, P), _pad(v, P), softmax_scale=D ** -0.5, q_descale=qd, k_descale=kd, v_descale=vd,
                                      return_softmax_lse=True)
     assert out.shape == (B, Sq, H, D) and bool(torch.isfinite(out.float()).all())
@@ -91,7 +91,7 @@ def test_native_body_equals_the_zero_padded_next_size_bit_for_bit_lists(D):
 
 
 @pytest.mark.parametrize("shape", [(1, 17, 1, 17, 64), (2, 129, 3, 65, 64), (1, 1000, 2, 1250, 64), (1, 128, 1, 4224, 64), (1, 300, 2, 700, 48),
-                                   (1, 260, 2, 130, 32), (1, 70, 1, 333, 16), (1, 17, 1, 17, 256), (2, 129, 3, 65, 192), (1, 1000, 2, 1250, 256),
+                                   (1, 260, 2, 130, 32), (1, 70, 1, 333, 16), (2, 129, 3, 65, 96), (1, 1000, 2, 1250, 96), (1, 300, 2, 700, 80), (1, 17, 1, 17, 256), (2, 129, 3, 65, 192), (1, 1000, 2, 1250, 256),
                                    (1, 128, 1, 4224, 192), (1, 300, 2, 700, 160), (1, 260, 2, 130, 224)])
 def test_ragged_shapes_against_the_oracle(shape):
     import liteattention_amd as L

@@ -132,7 +132,7 @@ def test_block_sparse_packed_batch_is_one_launch_and_matches_the_per_sequence_fo
         L.flash_blocksparse_attn_qkvpacked_func(qkv, torch.tensor(cu, dtype=torch.int32).cuda(), bad, 0.0, max_s)
 
 
-@pytest.mark.parametrize("D", [128, 64, 192, 256])             # round 6: native fp8 bodies at 64 (prepared V^T tiles of 4 KiB) and 192 / 256 (q-tile 128)
+@pytest.mark.parametrize("D", [128, 64, 96, 192, 256])             # round 6: native fp8 bodies at 64 (prepared V^T tiles of 4 KiB) and 192 / 256 (q-tile 128)
 @pytest.mark.parametrize("with_lists", [False, True])
 @pytest.mark.parametrize("p_mode", ["encoded", "exp", "reference"])
 def test_fp8_packed_batch_equals_the_fixed_length_path(with_lists, p_mode, D, monkeypatch):

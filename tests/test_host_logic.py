@@ -316,7 +316,7 @@ def test_head_dim_is_served_by_the_next_instantiated_size(monkeypatch):
     from liteattention_amd.flash_attn_interface import get_tile_sizes, kernel_head_dim
     monkeypatch.delenv("LA_FWD_KERNEL", raising=False)
     assert [kernel_head_dim(d, 2) for d in (8, 64, 72, 96, 104, 128, 136, 192, 200, 256)] == [64, 64, 96, 96, 128, 128, 192, 192, 256, 256]
-    assert [kernel_head_dim(d, 1) for d in (16, 64, 96, 128)] == [64, 64, 128, 128]           # round 6: a native e4m3 body at head_dim 64
+    assert [kernel_head_dim(d, 1) for d in (16, 64, 96, 128)] == [64, 64, 96, 128]            # round 6: native e4m3 bodies at every instantiated head dim
     assert kernel_head_dim(264, 2) == 264 and kernel_head_dim(192, 1) == 192 and kernel_head_dim(100, 2) == 100    # left to the library's typed error
     assert get_tile_sizes(96, 2) == (256, 64) and get_tile_sizes(80, 2) == (256, 64)
     assert get_tile_sizes(192, 2) == get_tile_sizes(256, 2) == (128, 64) and get_tile_sizes(64, 2) == get_tile_sizes(40, 2) == (256, 64)

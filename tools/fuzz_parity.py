@@ -29,7 +29,7 @@ fails = []
 t_start = time.time()
 for case in range(n_cases):
     dtype = rng.choice(["bf16", "bf16", "fp16", "fp8", "fp8"])
-    D = rng.choice([128, 128, 64, 64, 48, 96, 192, 256, 160]) if dtype == "fp8" else rng.choice([64, 96, 128, 128, 192, 256, 80, 160])      # e4m3: 64, 128, 192, 256 natively (48 -> 64, 96 -> 128, 160 -> 192 zero-padded)
+    D = rng.choice([128, 128, 64, 48, 96, 80, 192, 256, 160]) if dtype == "fp8" else rng.choice([64, 96, 128, 128, 192, 256, 80, 160])      # e4m3: 64, 96, 128, 192, 256 natively (48 -> 64, 80 -> 96, 160 -> 192 zero-padded)
     B = rng.choice([1, 1, 2, 3])
     Hk = rng.choice([1, 2, 3])
     H = Hk * rng.choice([1, 1, 2, 4])

@@ -48,7 +48,7 @@ def make(dtype, B, S, H, D, seed, step=0, gen="structured"):
 for case in range(n_cases):
     kind = rng.choice(["windows", "packed", "descales", "splits", "static"])
     dtype = rng.choice(["bf16", "fp16", "fp8"])
-    D = rng.choice([64, 128, 192, 256]) if dtype == "fp8" else rng.choice([64, 96, 128, 192, 256])
+    D = rng.choice([64, 96, 128, 192, 256]) if dtype == "fp8" else rng.choice([64, 96, 128, 192, 256])
     seed = rng.randrange(1 << 20)
     desc = f"case {case}: {kind} {dtype} D{D} seed {seed}"
     for v_ in ("LA_SCHED",):
@@ -139,7 +139,7 @@ for case in range(n_cases):
                     break
                 rd = 1 - rd
         elif kind == "descales":
-            dtype, D = "fp8", rng.choice([64, 128, 192, 256])
+            dtype, D = "fp8", rng.choice([64, 96, 128, 192, 256])
             bm, bn = L.get_tile_sizes(D, 1)
             B, Hk = rng.choice([1, 2, 3]), rng.choice([1, 2])
             H = Hk * rng.choice([1, 2, 4])

@@ -112,9 +112,9 @@ def blocks(tag):
                      for r in sv["runs"]]
             out["denoise50_survey"] = rows
         f8 = b.get("fp8") or {}
-        if any(f"head_dim_{hd}" in f8 for hd in (64, 192, 256)):
+        if any(f"head_dim_{hd}" in f8 for hd in (64, 96, 192, 256)):
             rows = ["| head_dim (tiles) | reference arithmetic (default): ms, TFLOP/s, of 5 PF | `LA_FLAG_FP8_MFMA_ROWSUM` | `LA_FLAG_FP8_ENCODED_P` | sampled rows ok |", "|---|---|---|---|---|"]
-            for hd in (64, 192, 256):
+            for hd in (64, 96, 192, 256):
                 x = f8.get(f"head_dim_{hd}") or {}
                 fm = x.get("forms") or {}
                 if not fm:
