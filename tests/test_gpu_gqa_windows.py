@@ -251,29 +251,25 @@ def test_longest_supported_key_sequence_and_the_typed_error_beyond_it(dtype):
     # (step / value)^2 / 12 ~ 7e-4 of the sum, every row low); the default form (fp32 row sums) has neither (tests/test_gpu_fp8.py runs all three)
     assert (lse[0, 0] - torch.logsumexp(sc, -1)).abs().max().item() <= (2.5e-3 if dtype == "fp8" else 1e-3)
     assert att.get_skip_fraction() == 0.0
-    # past the limit: skip lists (and e4m3, dense or not) raise the typed error, nothing is launched; a dense bf16 / fp16 call is cut into
-    # runs inside la_fwd and merged (round 6): a strided `out` (a head slice of a wider tensor) is written in place by the merge
-    Sk2 = 6000 * 64 - 3
+    # past the limit: skip lists raise the typed error, nothing is launched; a DENSE call (every dtype, round 6) is cut into runs inside la_fwd and
+    # merged: a strided `out` (a head slice of a wider tensor) is written in place by the merge. (e4m3 walks fit ~6 400 tiles, bf16 ~4 800.)
+    Sk2 = (7000 if dtype == "fp8" else 6000) * 64 - 3
     k2 = torch.randn(1, Sk2, H, D, generator=g)
     v2 = torch.randn(1, Sk2, H, D, generator=g)
     k2, v2 = ([x.to(F8) for x in (k2, v2)] if dtype == "fp8" else [x.bfloat16() for x in (k2, v2)])
-    too_long = torch.zeros(1, 40000 * 64, H, D, dtype=q.dtype, device="cuda")
-    if dtype == "fp8":
-        with pytest.raises(RuntimeError, match="too long"):
-            L.flash_attn_func(q.cuda(), too_long, too_long)
-    else:
-        from liteattention_amd.flash_attn_interface import mha_fwd
-        wide = torch.full((1, Sq, 3, D), 7.0, dtype=torch.bfloat16, device="cuda")
-        o2, l2, *_ = mha_fwd(q.cuda(), k2.cuda(), v2.cuda(), out=wide[:, :, 1:2])
-        sc2 = qf @ k2.float().cuda()[0, :, 0].T / D ** 0.5
-        ref2 = torch.softmax(sc2, -1) @ v2.float().cuda()[0, :, 0]
-        assert (wide[0, :, 1].float() - ref2).abs().max().item() <= 2.0 ** -7 * ref2.abs().max().item() + 1e-3
-        assert (l2[0, 0] - torch.logsumexp(sc2, -1)).abs().max().item() <= 1e-3
-        assert (wide[:, :, 0] == 7.0).all() and (wide[:, :, 2] == 7.0).all()
-        bm, bn = L.get_tile_sizes(D, 2)
-        lists = torch.zeros(2, 1, H, -(-Sq // bm), -(-Sk2 // bn) + 1, dtype=torch.int32, device="cuda")
-        with pytest.raises(RuntimeError, match="too long"):
-            L.flash_attn_func(q.cuda(), k2.cuda(), v2.cuda(), attn_read_list=lists[0], attn_write_list=lists[1])
+    from liteattention_amd.flash_attn_interface import mha_fwd
+    wide = torch.full((1, Sq, 3, D), 7.0, dtype=torch.bfloat16, device="cuda")
+    o2, l2, *_ = mha_fwd(q.cuda(), k2.cuda(), v2.cuda(), out=wide[:, :, 1:2])
+    sc2 = qf @ k2.float().cuda()[0, :, 0].T / D ** 0.5
+    ref2 = torch.softmax(sc2, -1) @ v2.float().cuda()[0, :, 0]
+    tol2 = 0.05 * ref2.abs().max().item() + 2e-3 if dtype == "fp8" else 2.0 ** -7 * ref2.abs().max().item() + 1e-3
+    assert (wide[0, :, 1].float() - ref2).abs().max().item() <= tol2
+    assert (l2[0, 0] - torch.logsumexp(sc2, -1)).abs().max().item() <= (2.5e-3 if dtype == "fp8" else 1e-3)
+    assert (wide[:, :, 0] == 7.0).all() and (wide[:, :, 2] == 7.0).all()
+    bm, bn = L.get_tile_sizes(D, q.element_size())
+    lists = torch.zeros(2, 1, H, -(-Sq // bm), -(-Sk2 // bn) + 1, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="too long"):
+        L.flash_attn_func(q.cuda(), k2.cuda(), v2.cuda(), attn_read_list=lists[0], attn_write_list=lists[1])
 
 
 # ------------------------------------------------------------------------------------------ ticket queues cover every item
