@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Generates la_fwd_x64_fp8_body.inc: hand-scheduled gfx950 main loop of the fp8 (e4m3) / head_dim-128 QK-Skip forward with
+"""Generates la_fwd_x64_fp8[_d<D>]_body.inc: hand-scheduled gfx950 main loop of the fp8 (e4m3) QK-Skip forward, head_dim 128 (described here) and -
+LA_X64F8_D, see the parameter block below - 64 / 96 / 192 / 256, with
 ONE wave per SIMD and 64 query rows per wave (q-tile 256 x k-tile 64) - the structure of gen_fwd_x64.py (bf16) on the
 block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 (2x the bf16 MFMA rate; the non-scaled v_mfma_f32_32x32x16_fp8_fp8 runs at the
 bf16 rate). The E8M0 scales are 2^0 everywhere except on P in the default body, which is block-scaled per (row, tile): "mx" below. One instruction contracts 64 indices, 32 bytes of A and of B per lane; the
@@ -55,13 +56,6 @@ def option_tag():
 
 
 
-XPAIRS = int(opt_val("x", {128: {"lin": "8", "exp": "4", "lvalu": "4"}, 64: {"lin": "12", "exp": "2", "lvalu": "6"}, 96: {"lin": "8", "exp": "4", "lvalu": "4"},
-                                192: {"lin": "8", "exp": "8", "lvalu": "8"}, 256: {"lin": "8", "exp": "8", "lvalu": "8"}}[int(os.environ.get("LA_X64F8_D", "128"))]
-                        ["lvalu" if "lvalu" in OPT else "exp" if "exp" in OPT else "lin"]))          # pair-groups (of 16) done in phase 2. EVEN: two pair-groups share one packed-e4m3 destination register
-                                          # (lo / hi half by op_sel); an odd split leaves a half-written register across the phase boundary
-                                          # (measured x = 2 / 4: 2078-2101 TFLOP/s at 42 %, x = 3 / 5 / 6: 2048-2065). head_dim 64 (phase 1 has 4 MFMAs, not 8;
-                                          # tools/debug/fp8_d64_ab.py, dense S = 16 384: lvalu x = 2 / 4 / 6 / 8: 2.40 / 2.41 / 2.30 / 2.40 ms; exp 2 / 4 / 6 / 8: 2.11 / 2.18 /
-                                          # 2.13 / 2.19; lin 4 / 8 / 10 / 12 / 14: 1.66 / 1.60 / 1.65 / 1.585 / 1.68 against 1.67 of that session's x = 8)
 # Head dim (round 6): 128, or 64 = the same step with ONE 64-wide contraction per score block and two 32-wide d-blocks of O^T: 4 QK + 4 PV
 # MFMAs per step instead of 8 + 8 under the same softmax. K tile = 64 keys x 64 bytes, held in LDS as 32 pseudo-rows of 128 bytes (key R in
 # chunks 0-3, key R + 32 in chunks 4-7) so that the fragment addresses and the swizzle are those of head_dim 128 with `sx` read as the key
@@ -69,7 +63,7 @@ XPAIRS = int(opt_val("x", {128: {"lin": "8", "exp": "4", "lvalu": "4"}, 64: {"li
 # Head dims 192 / 256 (round 6, "WIDE"): ONE q-block of 32 rows per wave (O^T of 32 rows x 256 is 128 accumulators), q-tile 128 x k-tile 64 - the tiles of
 # the bf16 kernels of these head dims, so lists keep their geometry. 3 / 4 contraction steps per score block, 6 / 8 d-blocks; K rows sit in LDS at a
 # 256-byte stride (16 chunks, XOR-swizzled by row & 15; at 192 the last four chunks of a row are DMA filler, never read), rings of 16 KiB per stage.
-# Per wave and step: 16 K + 16 V^T fragment reads of 1 KiB against 16 MFMAs and half the softmax of the 64-row bodies: bound by the matrix pipe and the LDS.
+# Per wave and step: 16 K + 16 V^T fragment reads of 1 KiB against 16 MFMAs and half the softmax of the 64-row bodies (measured: the power cap, MFMA busy 56 % at 1.94 GHz, profiles/r06_fp8_dims_pmc.md).
 # Head dim 96: the 128 step with three d-blocks of O^T (8 QK + 6 PV MFMAs) - its contraction is one and a half 64-wide steps, so QK^T keeps both: the K tile
 # sits in LDS exactly as at 128 with the two chunk positions per row whose source would be chunk 6 / 7 filled by DMA filler (a copy of chunk 5: finite
 # data) and the matching quarter of the Q fragments ZERO; the prepared V^T tile is padded to the 128 tile's 8 KiB by the prepare pass.
@@ -83,6 +77,13 @@ DB = ND                                   # gen_epilogue.py: d-blocks to store
 PIECES_K = 4 if WIDE else (D + 63) // 64  # 1 KiB LDS-DMA pieces per wave and K tile (WIDE: the 16 KiB image of 256-byte rows)
 PIECES_V = (D + 63) // 64                 # ... and prepared V^T tile (64 D bytes; 96: padded to 8 KiB)
 ROWSUM = 99                               # "d-block" index of the row-sum MFMA in PV_ORDER
+XPAIRS = int(opt_val("x", {128: {"lin": "8", "exp": "4", "lvalu": "4"}, 64: {"lin": "12", "exp": "2", "lvalu": "6"}, 96: {"lin": "8", "exp": "4", "lvalu": "4"},
+                                192: {"lin": "8", "exp": "8", "lvalu": "8"}, 256: {"lin": "8", "exp": "8", "lvalu": "8"}}[D]
+                        ["lvalu" if "lvalu" in OPT else "exp" if "exp" in OPT else "lin"]))          # pair-groups (of 16) done in phase 2. EVEN: two pair-groups share one packed-e4m3 destination register
+                                          # (lo / hi half by op_sel); an odd split leaves a half-written register across the phase boundary
+                                          # (measured x = 2 / 4: 2078-2101 TFLOP/s at 42 %, x = 3 / 5 / 6: 2048-2065). head_dim 64 (phase 1 has 4 MFMAs, not 8;
+                                          # tools/debug/fp8_dim_ab.py, dense S = 16 384: lvalu x = 2 / 4 / 6 / 8: 2.40 / 2.41 / 2.30 / 2.40 ms; exp 2 / 4 / 6 / 8: 2.11 / 2.18 /
+                                          # 2.13 / 2.19; lin 4 / 8 / 10 / 12 / 14: 1.66 / 1.60 / 1.65 / 1.585 / 1.68 against 1.67 of that session's x = 8)
 PK = "pk" in OPT                          # A/B: packed fp32 FMA / add in the softmax (v_pk_fma_f32, v_pk_add_f32). MEASURED ANTI-LEVER here too:
                                           # 64 fewer instructions per step, bit-identical results, 1891 vs 2068 TFLOP/s at 42 % (round 2, tools/ab.py --fp8)
 NG = 2 * NSX * NQB                        # QK MFMAs (gaps) of phase 1
