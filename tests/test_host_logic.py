@@ -312,7 +312,7 @@ def test_functional_surface_signature_and_cpu_failure():
 def test_head_dim_is_served_by_the_next_instantiated_size(monkeypatch):
     """The reference rounds a head size up to the next instantiated one (flash_api.cpp round_up_headdim; 64/96/128/192/256 are its
     default instantiations, hopper/setup.py:57-61). Here the library's tile table decides (one table): 2-byte types have all five,
-    fp8 has 64 and 128; with LA_FWD_KERNEL=v2 (the hipcc-scheduled A/B kernels) 96 / 192 are padded onto 128 / 256."""
+    fp8 too (round 6); with LA_FWD_KERNEL=v2 (the hipcc-scheduled A/B kernels) 96 / 192 are padded onto 128 / 256."""
     from liteattention_amd.flash_attn_interface import get_tile_sizes, kernel_head_dim
     monkeypatch.delenv("LA_FWD_KERNEL", raising=False)
     assert [kernel_head_dim(d, 2) for d in (8, 64, 72, 96, 104, 128, 136, 192, 200, 256)] == [64, 64, 96, 96, 128, 128, 192, 192, 256, 256]

@@ -1,6 +1,5 @@
-"""e4m3 at head dims 64 / 96 / 128 / 192 / 256, dense S = 16 384, H = 40 (round 6): the native 64 and 128 bodies, 96 zero-padded onto the 128 body (the fp8
-step is bound by the vector pipe - 5 issue slots per score in the reference's arithmetic - so the padded MFMAs hide under the softmax), and what 192 / 256
-reach on the bf16 kernels behind the fused up-convert pass. (Until the native head_dim-64 body existed, 64 ran padded too: 2.72 ms where it now takes 2.30.)"""
+"""e4m3 at head dims 64 / 96 / 128 / 192 / 256, dense S = 16 384, H = 40 (round 6): the five native bodies (round 6; until then 64 / 96 ran zero-padded on the 128 body and 192 / 256 on the bf16
+kernels over up-converted operands - the tables of each stage: profiles/r06_fp8_head_dims.md)."""
 import os
 import sys
 
