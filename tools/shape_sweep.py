@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Round 6: the shapes beside the headline ("the shapes nobody has looked at") - dense and list-walking launches over sequence lengths,
 batch sizes, head counts, GQA, cross-attention shapes; HIP events in steady state; useful TFLOP/s and fraction of the bf16 MFMA peak. Every
-result is also checked for finiteness (a crash or a NaN here is a finding). -> gpurun_out/shape_sweep.json, profiles/r06_shape_sweep.md"""
+result is also checked for finiteness (a crash or a NaN here is a finding). -> gpurun_out/shape_sweep.json, profiles/r06_shape_sweep.md
+`--fp8`: the e4m3 kernels (all five native head dims; fraction of the 5 PF fp8 peak) -> gpurun_out/shape_sweep_fp8.json"""
 import json
 import os
 import sys
@@ -14,7 +15,8 @@ import liteattention_amd as L                                     # noqa: E402
 from tools.selfcheck import banded_rows, executed_flops, impose_lists     # noqa: E402
 
 dev = torch.device("cuda", 0)
-PEAK = 2500.0
+FP8 = "--fp8" in sys.argv
+PEAK = 5000.0 if FP8 else 2500.0
 
 
 def steady(fn, est_ms):
@@ -36,11 +38,13 @@ def run(B, Sq, Sk, H, Hk, D, sparsity=None, splits=1):
     q = torch.randn(B, Sq, H, D, device=dev, generator=g).bfloat16()
     k = torch.randn(B, Sk, Hk, D, device=dev, generator=g).bfloat16()
     v = torch.randn(B, Sk, Hk, D, device=dev, generator=g).bfloat16()
+    if FP8:
+        q, k, v = [x.to(torch.float8_e4m3fn) for x in (q, k, v)]
     flops = 4.0 * B * H * Sq * Sk * D
     if sparsity is None:
         fn = lambda: L.flash_attn_func(q, k, v, num_splits=splits)            # noqa: E731
     else:
-        bm, bn = L.get_tile_sizes(D, 2)
+        bm, bn = L.get_tile_sizes(D, 1 if FP8 else 2)
         att = L.LiteAttention(threshold=-10.0, max_batch_size=B)
         att.threshold = float("-inf")
         att._get_read_write_lists(q, k)
@@ -67,6 +71,15 @@ for B, S in ((2, 16384), (8, 4096), (16, 1024)):
 cases += [(1, 16384, 16384, 8, 8, 128, None, 1), (1, 16384, 16384, 8, 8, 128, None, -1), (1, 16384, 16384, 40, 8, 128, None, 1), (1, 16384, 16384, 40, 1, 128, 0.42, 1),
           (1, 75600, 512, 40, 40, 128, None, 1), (1, 512, 75600, 40, 40, 128, None, 1), (1, 512, 75600, 40, 40, 128, None, -1), (2, 4096, 77, 24, 24, 128, None, 1),
           (1, 4096, 4096, 24, 24, 64, None, 1), (1, 4096, 4096, 24, 24, 64, 0.42, 1), (1, 4096, 4096, 16, 16, 256, None, 1), (1, 4096, 4096, 16, 16, 256, None, -1)]
+if FP8:
+    cases = []
+    for S in (2048, 8192, 32768):
+        cases += [(1, S, S, 40, 40, 128, None, 1), (1, S, S, 40, 40, 128, 0.42, 1)]
+    for D in (64, 96, 192, 256):
+        cases += [(1, 8192, 8192, 40, 40, D, None, 1), (1, 8192, 8192, 40, 40, D, 0.42, 1)]
+    cases += [(8, 4096, 4096, 40, 40, 128, None, 1), (16, 1024, 1024, 40, 40, 64, 0.42, 1), (1, 16384, 16384, 40, 8, 256, None, 1), (1, 16384, 16384, 40, 1, 96, 0.42, 1),
+              (1, 75600, 512, 40, 40, 128, None, 1), (1, 512, 75600, 40, 40, 128, None, 1), (2, 4096, 77, 24, 24, 64, None, 1), (1, 4096, 4096, 16, 16, 80, None, 1),
+              (1, 4096, 4096, 16, 16, 160, 0.42, 1)]
 res = []
 for c in cases:
     try:
@@ -76,4 +89,4 @@ for c in cases:
     res.append(r)
     print(json.dumps(r), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(res, open(os.path.join(ROOT, "gpurun_out", "shape_sweep.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "shape_sweep_fp8.json" if FP8 else "shape_sweep.json"), "w"), indent=1)
