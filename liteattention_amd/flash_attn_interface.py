@@ -398,17 +398,19 @@ def _num_splits(B, H, Sq, Sk, D, element_size, requested):
     return num_splits_heuristic(B * H * -(-Sq // block_m), cus * per, k_tiles, keys=Sk)
 
 
-def _split_kv_one_sequence(q, k, v, n, chunk, out, softmax_scale):
+def _split_kv_one_sequence(q, k, v, n, chunk, out, softmax_scale, descales=(None, None, None)):
     """batch == 1 (the diffusion-inference case): the splits ARE the batch of a fixed-length launch - q with batch stride 0 (every split
     reads the same query rows: no replication), K / V with batch stride = one chunk of rows, partial O (n, Sq, H, D) and partial LSE
     (n, H, Sq) written in exactly the layout la_combine reads; a ragged last chunk is a second launch of batch 1. Two or three library
-    calls and three allocations in all (the packed-batch form above costs a dozen tensor ops, which is what a 0.3 ms kernel notices)."""
+    calls and three allocations in all (the packed-batch form above costs a dozen tensor ops, which is what a 0.3 ms kernel notices).
+    e4m3: the descales (1, Hk) ride with batch stride 0 like q; partial and merged O are bf16; one workspace for the prepared V^T tiles."""
     _, Sq, H, D = q.shape
     Sk, Hk = k.shape[1], k.shape[2]
     es = q.element_size()
     flags = _cabi.default_flags()
     block_m, block_n = _cabi.get_tile_sizes(D, es, flags)
-    o_dtype = q.dtype
+    is_fp8 = q.dtype == torch.float8_e4m3fn
+    o_dtype = torch.bfloat16 if is_fp8 else q.dtype
     if out is None:
         out = torch.empty((1, Sq, H, D), dtype=o_dtype, device=q.device)
     elif out.dtype != o_dtype or tuple(out.shape) != (1, Sq, H, D) or not out.is_contiguous():
@@ -418,7 +420,13 @@ def _split_kv_one_sequence(q, k, v, n, chunk, out, softmax_scale):
     lse = torch.empty((1, H, Sq), dtype=torch.float32, device=q.device)
     a = _cabi.LaFwdArgs()
     a.struct_size = ctypes.sizeof(_cabi.LaFwdArgs)
-    a.dtype = _cabi.LA_DTYPE_FP16 if q.dtype == torch.float16 else _cabi.LA_DTYPE_BF16
+    a.dtype = _cabi.LA_DTYPE_FP8_E4M3 if is_fp8 else (_cabi.LA_DTYPE_FP16 if q.dtype == torch.float16 else _cabi.LA_DTYPE_BF16)
+    o_cabi_dtype = _cabi.LA_DTYPE_BF16 if is_fp8 else a.dtype
+    for name, t in zip(("q", "k", "v"), descales):                # (1, Hk) fp32: every split reads the same row
+        if t is not None:
+            setattr(a, f"{name}_descale", t.data_ptr())
+            setattr(a, f"{name}_descale_batch_stride", 0)
+            setattr(a, f"{name}_descale_head_stride", t.stride(1))
     a.q, a.q_batch_stride, a.q_row_stride, a.q_head_stride = q.data_ptr(), 0, q.stride(1), q.stride(2)
     a.k_row_stride, a.k_head_stride, a.k_batch_stride = k.stride(1), k.stride(2), chunk * k.stride(1)
     a.v_row_stride, a.v_head_stride, a.v_batch_stride = v.stride(1), v.stride(2), chunk * v.stride(1)
@@ -426,9 +434,18 @@ def _split_kv_one_sequence(q, k, v, n, chunk, out, softmax_scale):
     a.seqlen_q, a.num_heads, a.num_heads_k, a.head_dim, a.head_dim_v = Sq, H, Hk, D, D
     a.softmax_scale = float(softmax_scale)
     a.block_m, a.block_n = block_m, block_n
-    a.flags = ((flags & (_cabi.GEOMETRY_FLAGS | _cabi.LA_FLAG_EXACT_RESCALE)) | (_scoped_flags() & _cabi.LA_FLAG_EXACT_RESCALE)) | _cabi.LA_FLAG_STATIC_SCHED
+    keep = (_cabi.LA_FLAG_EXACT_RESCALE | _cabi.LA_FLAG_FP8_MFMA_ROWSUM | _cabi.LA_FLAG_FP8_ENCODED_P) if is_fp8 else (_cabi.GEOMETRY_FLAGS | _cabi.LA_FLAG_EXACT_RESCALE)
+    a.flags = ((flags | _scoped_flags()) & keep & ~_scoped_clear()) | _cabi.LA_FLAG_STATIC_SCHED
     full = n if Sk == n * chunk else n - 1                      # equal chunks; then the ragged one
     lib = _cabi.load()
+    workspace = None
+    if is_fp8:                                                  # the prepared V^T tiles of the larger of the two launches
+        a.batch, a.seqlen_k = max(full, 1), chunk
+        need = lib.la_fwd_workspace_bytes(ctypes.byref(a))
+        if need < 0:
+            raise RuntimeError(f"lite_attention::fwd (split-KV): {_cabi.status_string(int(need))}")
+        workspace = torch.empty(int(need), dtype=torch.uint8, device=q.device)
+        a.workspace, a.workspace_bytes = workspace.data_ptr(), int(need)
     with torch.cuda.device(q.device):
         stream = ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
         for first, count, keys in ((0, full, chunk), (full, n - full, Sk - full * chunk)):
@@ -436,11 +453,11 @@ def _split_kv_one_sequence(q, k, v, n, chunk, out, softmax_scale):
                 continue
             a.batch, a.seqlen_k = count, keys
             a.k, a.v = k.data_ptr() + first * chunk * k.stride(1) * es, v.data_ptr() + first * chunk * v.stride(1) * es
-            a.o, a.lse = o_part.data_ptr() + first * Sq * H * D * es, lse_part.data_ptr() + first * H * Sq * 4
+            a.o, a.lse = o_part.data_ptr() + first * Sq * H * D * 2, lse_part.data_ptr() + first * H * Sq * 4
             rc = lib.la_fwd(ctypes.byref(a), stream)
             if rc != _cabi.LA_OK:
                 raise RuntimeError(f"lite_attention::fwd (split-KV): {_cabi.status_string(rc)}")
-        rc = lib.la_combine(o_part.data_ptr(), 1, lse_part.data_ptr(), out.data_ptr(), a.dtype, lse.data_ptr(), n, 1, Sq, H, D, stream)
+        rc = lib.la_combine(o_part.data_ptr(), 1, lse_part.data_ptr(), out.data_ptr(), o_cabi_dtype, lse.data_ptr(), n, 1, Sq, H, D, stream)
     if rc != _cabi.LA_OK:
         raise RuntimeError(f"la_combine (split-KV): {_cabi.status_string(rc)}")
     empty = torch.empty(0, dtype=torch.float32, device=q.device)
@@ -465,8 +482,8 @@ def _mha_fwd_split_kv(q, k, v, n, out, softmax_scale, descales):
     n = -(-Sk // chunk)                                         # (no empty trailing split)
     if n <= 1:
         return None
-    if B == 1 and q.dtype != torch.float8_e4m3fn and kernel_head_dim(D, q.element_size()) == D and all(t is None for t in descales):
-        return _split_kv_one_sequence(q, k, v, n, chunk, out, softmax_scale)
+    if B == 1 and kernel_head_dim(D, q.element_size()) == D and (q.dtype == torch.float8_e4m3fn or all(t is None for t in descales)):
+        return _split_kv_one_sequence(q, k, v, n, chunk, out, softmax_scale, descales)
     key = (B, n, Sq, Sk, chunk, str(q.device))
     cu = _SPLIT_CU.get(key)
     if cu is None:

@@ -207,3 +207,28 @@ def test_dense_key_range_beyond_one_launchs_walk(D, p_mode):
     lists = torch.zeros(2, 1, 1, -(-131 // bm), -(-Sk // bn) + 1, dtype=torch.int32, device="cuda")
     with pytest.raises(RuntimeError, match=_cabi.status_string(_cabi.LA_ERR_SEQLEN)[:20]):
         L.flash_attn_func(q, k, v, attn_read_list=lists[0], attn_write_list=lists[1])
+
+
+@pytest.mark.parametrize("D", [64, 128, 256])
+@pytest.mark.parametrize("B", [1, 2])
+def test_host_split_kv_of_e4m3_calls(D, B):
+    """`num_splits` for e4m3 (round 6: batch 1 takes the one-sequence path - the splits are the batch of ONE fixed-length launch, q and the
+    (1, Hk) descales with batch stride 0, bf16 partials merged by la_combine; batch > 1 the packed path). Every split rounds P to e4m3 against
+    ITS running maximum, so O agrees with the unsplit launch inside the fp8 bound, not to a bf16 step; the LSE (fp32 row sums of the
+    un-rounded P in the default form) agrees to 1e-5 - by form of P otherwise - and with the oracle."""
+    import liteattention_amd as L
+    from oracle import oracle as orc
+    g = torch.Generator().manual_seed(40 + D + B)
+    Sq, Sk, H, Hk = 300, 9000, 4, 2
+    q, k, v = torch.randn(B, Sq, H, D, generator=g).to(F8), torch.randn(B, Sk, Hk, D, generator=g).to(F8), torch.randn(B, Sk, Hk, D, generator=g).to(F8)
+    qd, kd, vd = [0.5 + torch.rand(B, Hk, generator=g) for _ in range(3)]
+    kw = dict(q_descale=qd.cuda(), k_descale=kd.cuda(), v_descale=vd.cuda(), return_softmax_lse=True)
+    o1, l1 = L.flash_attn_func(q.cuda(), k.cuda(), v.cuda(), **kw)
+    bm, bn = L.get_tile_sizes(D, 1)
+    o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, p_round=fp8_p_round(), q_descale=qd, k_descale=kd, v_descale=vd)
+    for ns in (3, 4):
+        o2, l2 = L.flash_attn_func(q.cuda(), k.cuda(), v.cuda(), num_splits=ns, **kw)
+        assert o2.dtype == torch.bfloat16 and o2.shape == o1.shape
+        assert (o2.float() - o1.float()).abs().max().item() <= _tol(o_ref)
+        assert (o2.float().cpu() - o_ref).abs().max().item() <= _tol(o_ref)
+        assert (l2 - l1).abs().max().item() <= fp8_lse_tol() and (l2.cpu() - lse_ref).abs().max().item() <= fp8_lse_tol()

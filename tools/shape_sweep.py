@@ -78,7 +78,7 @@ if FP8:
     for D in (64, 96, 192, 256):
         cases += [(1, 8192, 8192, 40, 40, D, None, 1), (1, 8192, 8192, 40, 40, D, 0.42, 1)]
     cases += [(8, 4096, 4096, 40, 40, 128, None, 1), (16, 1024, 1024, 40, 40, 64, 0.42, 1), (1, 16384, 16384, 40, 8, 256, None, 1), (1, 16384, 16384, 40, 1, 96, 0.42, 1),
-              (1, 75600, 512, 40, 40, 128, None, 1), (1, 512, 75600, 40, 40, 128, None, 1), (2, 4096, 77, 24, 24, 64, None, 1), (1, 4096, 4096, 16, 16, 80, None, 1),
+              (1, 75600, 512, 40, 40, 128, None, 1), (1, 512, 75600, 40, 40, 128, None, 1), (1, 512, 75600, 40, 40, 128, None, -1), (2, 4096, 77, 24, 24, 64, None, 1), (1, 4096, 4096, 16, 16, 80, None, 1),
               (1, 4096, 4096, 16, 16, 160, 0.42, 1)]
 res = []
 for c in cases:
