@@ -90,6 +90,27 @@ def test_recipe_at_a_threshold_that_skips_nothing_is_one_full_attention():
     assert att.get_skip_fraction() == 0.0
 
 
+@pytest.mark.parametrize("D", [128, 256])
+def test_recipe_in_e4m3_is_one_full_attention(D):
+    """The same recipe on e4m3 inputs (bf16 partials, fp32 LSE; the dense calls with few items split over the keys as for bf16): at a threshold
+    that skips nothing, one oracle attention over the concatenated sequence in the kernel's form of P, inside the fp8 bound; LSE to 1e-3 (the
+    default form: fp32 row sums of the un-rounded P)."""
+    import liteattention_amd as L
+    from oracle import oracle as orc
+    F8 = torch.float8_e4m3fn
+    B, H, text_len, video_len = 1, 3, 200, 1500
+    q, k, v = [x.to(F8) for x in structured_qkv(B, text_len + video_len, H, D, seed=9, dtype=torch.float32)]
+    att = L.LiteAttention(threshold=-60.0, max_batch_size=B)
+    bm, bn = L.get_tile_sizes(D, 1)
+    o_ref, lse_ref, _ = orc.qkskip_fwd(q, k, v, block_m=bm, block_n=bn, p_round="fp8")
+    for _ in range(2):
+        out, lse = _recipe(L, att, q.cuda(), k.cuda(), v.cuda(), text_len)
+        assert out.dtype == torch.bfloat16
+        assert (out.float().cpu() - o_ref).abs().max().item() <= 0.05 * o_ref.abs().max().item() + 2e-2
+        assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-3
+    assert att.get_skip_fraction() == 0.0
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,Sq,Sk,H,Hk,n", [(1, 512, 9000, 8, 8, -1), (2, 300, 5000, 4, 2, -1), (1, 100, 3000, 2, 2, 5), (3, 64, 700, 2, 1, 3)])
 def test_split_kv_of_dense_launches_with_few_items(B, Sq, Sk, H, Hk, n, dtype):
