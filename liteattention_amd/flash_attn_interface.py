@@ -508,7 +508,7 @@ def _mha_fwd_varlen(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_
                     softmax_scale, attn_read_list, attn_write_list, attn_must_do_list=None, thr=-3.0, _must_do_is_1d=False):
     """Packed variable-length batches (flash_api.cpp:672-674, 736-760): q (total_q, H, D), k/v (total_k, Hk, D), cu_seqlens_*
     int32 [B+1] on the device, max_seqlen_* size the grid. ONE launch, no host sync (fp8: plus the V^T prepare pass, which reads
-    cu_seqlens_k itself). bf16 / fp16 at every head dim, e4m3 at head_dim 128 with descales (B, Hk). lse is (H, total_q).
+    cu_seqlens_k itself). bf16 / fp16 / e4m3 at every head dim, e4m3 with descales (B, Hk). lse is (H, total_q).
     Skip lists (extension; the reference's varlen entry point has none, hopper/_internal/flash_attn_interface.py:638-682):
     ``[>= B, H, ceil(max_seqlen_q / kBlockM), ceil(max_seqlen_k / kBlockN) + 1]``, row (b, h, m) describing q-tile m of sequence b
     over THAT sequence's k-tiles - what the static block-sparse adapter needs to run a packed batch in one launch."""
