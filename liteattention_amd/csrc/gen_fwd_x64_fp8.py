@@ -81,7 +81,8 @@ XPAIRS = int(opt_val("x", {128: {"lin": "8", "exp": "4", "lvalu": "4"}, 64: {"li
                                 192: {"lin": "8", "exp": "8", "lvalu": "8"}, 256: {"lin": "8", "exp": "8", "lvalu": "8"}}[D]
                         ["lvalu" if "lvalu" in OPT else "exp" if "exp" in OPT else "lin"]))          # pair-groups (of 16) done in phase 2. EVEN: two pair-groups share one packed-e4m3 destination register
                                           # (lo / hi half by op_sel); an odd split leaves a half-written register across the phase boundary
-                                          # (measured x = 2 / 4: 2078-2101 TFLOP/s at 42 %, x = 3 / 5 / 6: 2048-2065). head_dim 64 (phase 1 has 4 MFMAs, not 8;
+                                          # (measured x = 2 / 4: 2078-2101 TFLOP/s at 42 %, x = 3 / 5 / 6: 2048-2065; round 6, the lvalu body as the default: x = 2 / 4 / 6 / 8 ->
+                                          # 2062 / 2089 / 2037 / 2079). head_dim 64 (phase 1 has 4 MFMAs, not 8;
                                           # tools/debug/fp8_dim_ab.py, dense S = 16 384: lvalu x = 2 / 4 / 6 / 8: 2.40 / 2.41 / 2.30 / 2.40 ms; exp 2 / 4 / 6 / 8: 2.11 / 2.18 /
                                           # 2.13 / 2.19; lin 4 / 8 / 10 / 12 / 14: 1.66 / 1.60 / 1.65 / 1.585 / 1.68 against 1.67 of that session's x = 8)
 PK = "pk" in OPT                          # A/B: packed fp32 FMA / add in the softmax (v_pk_fma_f32, v_pk_add_f32). MEASURED ANTI-LEVER here too:
