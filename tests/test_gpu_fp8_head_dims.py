@@ -232,3 +232,36 @@ def test_host_split_kv_of_e4m3_calls(D, B):
         assert (o2.float() - o1.float()).abs().max().item() <= _tol(o_ref)
         assert (o2.float().cpu() - o_ref).abs().max().item() <= _tol(o_ref)
         assert (l2 - l1).abs().max().item() <= fp8_lse_tol() and (l2.cpu() - lse_ref).abs().max().item() <= fp8_lse_tol()
+
+
+@pytest.mark.parametrize("D", DIMS)
+def test_race_screen_100_iterations(D):
+    """The reference's race screen (hopper/tests/test_flash_attn.py:1144-1175; tests/test_gpu_head_dims.py for the bf16 bodies) on the e4m3 bodies
+    of this module: real, fragmented, unequal lists, more items than CUs (persistent loop, ticket stealing), a co-running memory hog on a
+    second stream; every launch identical to the first in O, LSE and the write list (the V^T prepare pass rewrites the same workspace bytes)."""
+    import liteattention_amd as L
+    B, S, H, thr = 1, 8192, 8, -2.0
+    q, k, v = [x.to(F8).cuda() for x in structured_qkv(B, S, H, D, seed=700, alpha=7.0, frames=16, dtype=torch.float32)]
+    att = L.LiteAttention(threshold=thr, max_batch_size=B)
+    for _ in range(3):
+        att(q, k, v)
+    base, phase = att._skip_list.clone(), att._phase
+    assert 0.02 < att.get_skip_fraction(batch=B) < 0.95
+
+    def run():
+        att._skip_list.copy_(base)
+        att._phase = phase
+        return att(q, k, v, return_softmax_lse=True)
+
+    hog_stream = torch.cuda.Stream()
+    hog_a = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    hog_b = torch.empty_like(hog_a)
+    out0, lse0 = run()
+    out0, lse0, lists0 = out0.clone(), lse0.clone(), att._skip_list.clone()
+    for it in range(100):
+        if it % 4 == 0:
+            with torch.cuda.stream(hog_stream):
+                hog_b.copy_(hog_a)
+        out, lse = run()
+        assert torch.equal(out, out0) and torch.equal(lse, lse0) and torch.equal(att._skip_list, lists0), it
+    torch.cuda.synchronize()
