@@ -2,7 +2,7 @@
 """The reference's text + video recipe (/root/reference/README.md:225-246) at the Wan2.1 shape: text = 512 tokens, video = 75 088,
 H = 40, D = 128, bf16 - ms and fraction of the MFMA peak of each of the four calls (t2t, t2v, v2t dense; v2v on an imposed 42 % list) and
 of the two merges, by HIP events on the launch stream in steady state. `bench.py` imports `joint_recipe` for its sub-record.
-    python tools/joint_recipe_bench.py > gpurun_out/joint_recipe.json"""
+    python tools/joint_recipe_bench.py [--fp8] > gpurun_out/joint_recipe.json"""
 import json
 import os
 import sys
@@ -27,16 +27,20 @@ def _steady(launch, est_ms, warm_ms=150.0, timed_ms=300.0, min_reps=5):
     return sorted(a.elapsed_time(b) for a, b in ev)[reps // 2], reps
 
 
-def joint_recipe(L, dev, qkv=None, text_len=512, S=75600, H=40, D=128, sparsity=0.42):
+def joint_recipe(L, dev, qkv=None, text_len=512, S=75600, H=40, D=128, sparsity=0.42, fp8=False):
+    """fp8: the same recipe on e4m3 inputs (`--fp8` on the command line; fractions of the 5 PF fp8 peak; the partials are bf16 either way)."""
     if qkv is None:
         g = torch.Generator(device=dev).manual_seed(1234)
         qkv = [torch.randn(1, S, H, D, device=dev, generator=g).bfloat16() for _ in range(3)]
+    if fp8:
+        qkv = [x.to(torch.float8_e4m3fn) for x in qkv]
+    es, peak = (1, 5000.0) if fp8 else (2, MFMA_BF16_PEAK_TFLOPS)
     q, k, v = qkv
     video = S - text_len
     qt_, qv = q[:, :text_len], q[:, text_len:]
     kt_, kv = k[:, :text_len], k[:, text_len:]
     vt_, vv = v[:, :text_len], v[:, text_len:]
-    bm, bn = L.get_tile_sizes(D, 2)
+    bm, bn = L.get_tile_sizes(D, es)
     att = L.LiteAttention(threshold=-10.0, max_batch_size=1)
     att.threshold = float("-inf")                      # the imposed v2v list is a fixed point
     att._get_read_write_lists(qv, kv)
@@ -59,10 +63,10 @@ def joint_recipe(L, dev, qkv=None, text_len=512, S=75600, H=40, D=128, sparsity=
         outs[name] = fn()
         ms, reps = _steady(fn, est_ms=max(0.05, flops / 1.2e12 * 1e3))
         res[name] = {"ms": round(ms, 4), "launches_timed": reps, "tflops": round(flops / ms / 1e9, 1),
-                     "frac_of_mfma_peak": round(flops / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)}
+                     "frac_of_mfma_peak": round(flops / ms / 1e9 / peak, 4)}
     from liteattention_amd.flash_attn_interface import _num_splits
-    res["t2v"]["num_splits"] = _num_splits(1, H, text_len, video, D, 2, 0)      # what num_splits = -1 (LiteAttention's dense calls) resolves to
-    res["t2t"]["num_splits"] = _num_splits(1, H, text_len, text_len, D, 2, 0)
+    res["t2v"]["num_splits"] = _num_splits(1, H, text_len, video, D, es, 0)      # what num_splits = -1 (LiteAttention's dense calls) resolves to
+    res["t2t"]["num_splits"] = _num_splits(1, H, text_len, text_len, D, es, 0)
     merges = {"merge_text": (lambda: L.flash_attn_combine([outs["t2t"][0], outs["t2v"][0]], [outs["t2t"][1], outs["t2v"][1]]), text_len),
               "merge_video": (lambda: L.flash_attn_combine([outs["v2t"][0], outs["v2v"][0]], [outs["v2t"][1], outs["v2v"][1]]), video)}
     for name, (fn, rows_) in merges.items():
@@ -74,7 +78,7 @@ def joint_recipe(L, dev, qkv=None, text_len=512, S=75600, H=40, D=128, sparsity=
     small = sum(res[n]["ms"] for n in ("t2t", "t2v", "v2t", "merge_text", "merge_video"))
     res["everything_but_v2v_ms"] = round(small, 4)
     res["everything_but_v2v_over_v2v"] = round(small / res["v2v"]["ms"], 4)
-    res["what"] = (f"reference README.md:225-246 at text = {text_len}, video = {video}, H = {H}, D = {D} bf16: t2t / t2v / v2t dense through "
+    res["what"] = (f"reference README.md:225-246 at text = {text_len}, video = {video}, H = {H}, D = {D} {'e4m3' if fp8 else 'bf16'}: t2t / t2v / v2t dense through "
                    f"LiteAttention with enable_skip_optimization(False) (host-side split-KV where items < workgroup slots), v2v on the imposed "
                    f"{sparsity:.0%} list, merges by flash_attn_combine on the separate partials (la_combine_list); HIP events, steady state, median; tiles {bm}x{bn}")
     return res
@@ -82,4 +86,4 @@ def joint_recipe(L, dev, qkv=None, text_len=512, S=75600, H=40, D=128, sparsity=
 
 if __name__ == "__main__":
     import liteattention_amd as L
-    print(json.dumps(joint_recipe(L, torch.device("cuda", 0))))
+    print(json.dumps(joint_recipe(L, torch.device("cuda", 0), fp8="--fp8" in sys.argv)))
